@@ -1,0 +1,695 @@
+/*
+ * oracle.c — CPU restatement of imgProcessor's per-pixel hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under imgprocessor_amd/ may import, link
+ * or execute this file.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and there only as the checker / CPU comparator.
+ *
+ * What it restates (reference file:line, all relative to /root/reference):
+ *   - imgProcessor/filters/_extendArrayForConvolution.py:5-97  -> orc_extend_array
+ *   - imgProcessor/filters/maskedConvolve.py:24-43             -> orc_masked_convolve
+ *   - scipy.ndimage.correlate / gaussian_filter as the reference calls them
+ *     (filters/standardDeviation.py:23, filters/fastFilter.py:42,
+ *      filters/varYSizeGaussianFilter.py:46)                   -> orc_conv2d, orc_sepconv2d,
+ *                                                                 orc_gaussian_kernel1d
+ *   - imgProcessor/filters/varYSizeGaussianFilter.py:53-68     -> orc_conv_ydep
+ *   - imgProcessor/filters/standardDeviation.py:34-70          -> orc_std2d
+ *   - imgProcessor/interpolate/interpolate2dStructuredIDW.py:26-65      -> orc_idw
+ *   - imgProcessor/interpolate/interpolate2dStructuredFastIDW.py:29-63  -> orc_fast_idw
+ *   - imgProcessor/camera/LensDistortion.py:316-330,342-358 (cv2.remap,
+ *     cv2.initUndistortRectifyMap)                             -> orc_remap, orc_build_undistort_map
+ *   - imgProcessor/camera/PerspectiveCorrection.py:374-406 (cv2.warpPerspective)
+ *                                                              -> orc_warp_perspective
+ *
+ * Pinning status:
+ *   - in-tree stencils: pinned against the reference itself, imported here
+ *     through a numba identity shim (tests/golden/gen_golden.py, fixtures in
+ *     tests/golden/).
+ *   - remap INTER_LINEAR (exact coordinates): pinned against
+ *     scipy.ndimage.map_coordinates(order=1, mode='grid-constant') and
+ *     skimage.transform.warp(order=1).  Keys bicubic a=-0.5: pinned against
+ *     skimage.transform.warp(order=3).
+ *   - OpenCV-specific modes (1/32-px coordinate quantisation "q5", bicubic
+ *     a=-0.75, Lanczos4, the uint8 fixed-point path): cv2 is a third-party,
+ *     un-vendored, un-pinned dependency (setup.py:40) that is not importable
+ *     in the build container -> these follow OpenCV's published algorithm
+ *     (imgproc/imgwarp.cpp: remapBilinear/remapBicubic/remapLanczos4,
+ *     interpolateCubic, interpolateLanczos4, initInterTab1D) and are
+ *     **parity unpinned**.
+ *
+ * Arithmetic: every floating-point accumulation is done in double (that is
+ * what numba's type unification, scipy.ndimage and skimage's _warp_fast do),
+ * then rounded once to the output dtype.  The HIP path computes float32
+ * images in float32; tests compare at the 1e-5 relative tolerance of
+ * BASELINE.json.  The uint8->uint8 path is integer fixed point and bit-exact.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -fopenmp -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <float.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_U8 0
+#define ORC_U16 1
+#define ORC_F32 2
+#define ORC_F64 3
+
+/* interpolation ids follow cv2's numbering where one exists */
+#define ORC_NEAREST 0
+#define ORC_LINEAR 1
+#define ORC_CUBIC_CV 2   /* Keys a = -0.75 (cv2.INTER_CUBIC) */
+#define ORC_LANCZOS4 4   /* cv2.INTER_LANCZOS4, always q5 */
+#define ORC_CUBIC_KEYS 5 /* Keys a = -0.5 (skimage order=3) */
+#define ORC_Q5 0x100     /* coordinates rounded to 1/32 px like cv2 */
+
+/* border ids follow cv2 */
+#define ORC_CONSTANT 0
+#define ORC_REPLICATE 1
+#define ORC_REFLECT 2 /* fedcba|abcdef  == numpy 'symmetric' == scipy 'reflect' */
+#define ORC_WRAP 3
+#define ORC_REFLECT101 4 /* scipy 'mirror' */
+
+static int g_threads = 1;
+void orc_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int orc_get_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static inline size_t dtype_size(int dt) {
+  switch (dt) {
+    case ORC_U8: return 1;
+    case ORC_U16: return 2;
+    case ORC_F32: return 4;
+    case ORC_F64: return 8;
+  }
+  return 0;
+}
+
+static inline double load_px(const void* p, int dt, long idx) {
+  switch (dt) {
+    case ORC_U8: return ((const uint8_t*)p)[idx];
+    case ORC_U16: return ((const uint16_t*)p)[idx];
+    case ORC_F32: return ((const float*)p)[idx];
+    default: return ((const double*)p)[idx];
+  }
+}
+
+/* cv::saturate_cast<uchar/ushort>(double) = round-half-even, then clamp */
+static inline void store_px(void* p, int dt, long idx, double v) {
+  switch (dt) {
+    case ORC_U8: {
+      double r = nearbyint(v);
+      if (!(r > 0)) r = 0; /* NaN -> 0 */
+      if (r > 255) r = 255;
+      ((uint8_t*)p)[idx] = (uint8_t)r;
+      break;
+    }
+    case ORC_U16: {
+      double r = nearbyint(v);
+      if (!(r > 0)) r = 0;
+      if (r > 65535) r = 65535;
+      ((uint16_t*)p)[idx] = (uint16_t)r;
+      break;
+    }
+    case ORC_F32: ((float*)p)[idx] = (float)v; break;
+    default: ((double*)p)[idx] = v; break;
+  }
+}
+
+/* index resolution for an out-of-range coordinate; -1 means "use cval" */
+static inline long resolve_idx(long i, long n, int mode) {
+  if (i >= 0 && i < n) return i;
+  switch (mode) {
+    case ORC_CONSTANT: return -1;
+    case ORC_REPLICATE: return i < 0 ? 0 : n - 1;
+    case ORC_REFLECT: {
+      if (n == 1) return 0;
+      long p = 2 * n;
+      long m = i % p;
+      if (m < 0) m += p;
+      return m < n ? m : p - 1 - m;
+    }
+    case ORC_REFLECT101: {
+      if (n == 1) return 0;
+      long p = 2 * n - 2;
+      long m = i % p;
+      if (m < 0) m += p;
+      return m < n ? m : p - m;
+    }
+    case ORC_WRAP: {
+      long m = i % n;
+      if (m < 0) m += n;
+      return m;
+    }
+  }
+  return -1;
+}
+
+/* ------------------------------------------------------------------ */
+/* interpolation weights                                               */
+/* ------------------------------------------------------------------ */
+
+/* OpenCV interpolateCubic (imgwarp.cpp), generalised over A */
+static void cubic_weights(double t, double A, double* w) {
+  w[0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A;
+  w[1] = ((A + 2) * t - (A + 3)) * t * t + 1;
+  w[2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1;
+  w[3] = 1.0 - w[0] - w[1] - w[2];
+}
+
+/* OpenCV interpolateLanczos4 (imgwarp.cpp): float coefficients */
+void orc_lanczos4_weights(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0},  {-s45, -s45}, {0, 1},  {s45, -s45},
+                                 {-1, 0}, {s45, s45},   {0, -1}, {-s45, s45}};
+  if (x < FLT_EPSILON) {
+    for (int i = 0; i < 8; i++) coeffs[i] = 0;
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  double y0 = -(x + 3) * M_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; i++) {
+    double y = -(x + 3 - i) * M_PI * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+typedef struct {
+  const void* src;
+  int dt;
+  long h, w, pitch;
+  int interp; /* base id without Q5 */
+  int q5;
+  int border;
+  double cval;
+} sampler_t;
+
+static inline int ntaps_of(int interp) {
+  switch (interp) {
+    case ORC_NEAREST: return 1;
+    case ORC_LINEAR: return 2;
+    case ORC_LANCZOS4: return 8;
+    default: return 4;
+  }
+}
+
+/* split a coordinate into first-tap index and fractional weights */
+static inline void axis_weights(const sampler_t* s, double c, long* i0, double* w) {
+  int interp = s->interp;
+  double fl, t;
+  if (s->q5 || interp == ORC_LANCZOS4) {
+    /* cvRound(c * INTER_TAB_SIZE): round-half-even at 1/32 px */
+    double q = nearbyint(c * 32.0);
+    if (q > 2147483647.0) q = 2147483647.0;
+    if (q < -2147483648.0) q = -2147483648.0;
+    long qi = (long)q;
+    long ip = qi >> 5; /* arithmetic shift == floor */
+    fl = (double)ip;
+    t = (double)(qi & 31) / 32.0;
+  } else {
+    fl = floor(c);
+    t = c - fl;
+  }
+  switch (interp) {
+    case ORC_NEAREST:
+      /* cv2.remap INTER_NEAREST: cvRound(coordinate) */
+      *i0 = (long)nearbyint(c);
+      w[0] = 1.0;
+      break;
+    case ORC_LINEAR:
+      *i0 = (long)fl;
+      w[0] = 1.0 - t;
+      w[1] = t;
+      break;
+    case ORC_CUBIC_CV:
+      *i0 = (long)fl - 1;
+      cubic_weights(t, -0.75, w);
+      break;
+    case ORC_CUBIC_KEYS:
+      *i0 = (long)fl - 1;
+      cubic_weights(t, -0.5, w);
+      break;
+    case ORC_LANCZOS4: {
+      float cf[8];
+      orc_lanczos4_weights((float)t, cf);
+      *i0 = (long)fl - 3;
+      for (int k = 0; k < 8; k++) w[k] = cf[k];
+      break;
+    }
+  }
+}
+
+static double sample(const sampler_t* s, double sx, double sy) {
+  /* NaN / absurd coordinates behave like "far outside" */
+  if (!(sx > -1e9 && sx < 1e9 && sy > -1e9 && sy < 1e9)) {
+    if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return s->cval;
+    sx = sx < -1e9 ? -1e9 : (sx > 1e9 ? 1e9 : sx);
+    sy = sy < -1e9 ? -1e9 : (sy > 1e9 ? 1e9 : sy);
+  }
+  int n = ntaps_of(s->interp);
+  long ix0 = 0, iy0 = 0;
+  double wx[8], wy[8];
+  axis_weights(s, sx, &ix0, wx);
+  axis_weights(s, sy, &iy0, wy);
+  if (s->border == ORC_CONSTANT &&
+      (ix0 >= s->w || ix0 + n <= 0 || iy0 >= s->h || iy0 + n <= 0))
+    return s->cval; /* whole footprint outside */
+  double out = 0.0;
+  for (int r = 0; r < n; r++) {
+    long yy = resolve_idx(iy0 + r, s->h, s->border);
+    double rs = 0.0;
+    for (int c = 0; c < n; c++) {
+      long xx = resolve_idx(ix0 + c, s->w, s->border);
+      double v = (yy < 0 || xx < 0) ? s->cval : load_px(s->src, s->dt, yy * s->pitch + xx);
+      rs += wx[c] * v;
+    }
+    out += wy[r] * rs;
+  }
+  return out;
+}
+
+/* OpenCV's uint8 bilinear: q5 coordinates, 15-bit integer weights
+ * (BilinearTab_i = (32-fx)(32-fy)*32 etc., exact), rounded shift. */
+static uint8_t sample_u8_fixed(const sampler_t* s, double sx, double sy, uint8_t cv8) {
+  if (!(sx > -1e9 && sx < 1e9 && sy > -1e9 && sy < 1e9)) {
+    if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return cv8;
+    sx = sx < -1e9 ? -1e9 : (sx > 1e9 ? 1e9 : sx);
+    sy = sy < -1e9 ? -1e9 : (sy > 1e9 ? 1e9 : sy);
+  }
+  long qx = (long)nearbyint(sx * 32.0), qy = (long)nearbyint(sy * 32.0);
+  long ix = qx >> 5, iy = qy >> 5;
+  int fx = (int)(qx & 31), fy = (int)(qy & 31);
+  int w[4] = {(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32};
+  int acc = 0;
+  for (int r = 0; r < 2; r++) {
+    long yy = resolve_idx(iy + r, s->h, s->border);
+    for (int c = 0; c < 2; c++) {
+      long xx = resolve_idx(ix + c, s->w, s->border);
+      int v = (yy < 0 || xx < 0) ? cv8 : ((const uint8_t*)s->src)[yy * s->pitch + xx];
+      acc += v * w[r * 2 + c];
+    }
+  }
+  int o = (acc + (1 << 14)) >> 15;
+  return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
+static inline uint8_t sat_u8(double v) {
+  double r = nearbyint(v);
+  if (!(r > 0)) r = 0;
+  if (r > 255) r = 255;
+  return (uint8_t)r;
+}
+
+static void init_sampler(sampler_t* s, const void* src, int dt, long h, long w, long pitch,
+                         int interp, int border, double cval) {
+  s->src = src; s->dt = dt; s->h = h; s->w = w; s->pitch = pitch;
+  s->interp = interp & 0xff;
+  s->q5 = (interp & ORC_Q5) != 0;
+  s->border = border; s->cval = cval;
+}
+
+/* cv2.remap(src, mapx, mapy, interp, borderMode, borderValue) —
+ * camera/LensDistortion.py:323-326 */
+int orc_remap(const void* src, int src_dt, long sh, long sw, long src_pitch, const float* mapx,
+              const float* mapy, long map_pitch, void* dst, int dst_dt, long dh, long dw,
+              long dst_pitch, int interp, int border, double cval) {
+  sampler_t s;
+  init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
+  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  uint8_t cv8 = sat_u8(cval);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long v = 0; v < dh; v++) {
+    for (long u = 0; u < dw; u++) {
+      double sx = mapx[v * map_pitch + u], sy = mapy[v * map_pitch + u];
+      if (fixed)
+        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+      else
+        store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
+    }
+  }
+  return 0;
+}
+
+/* 3x3 inverse (double) */
+static int inv3(const double* m, double* o) {
+  double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  if (det == 0) return -1;
+  double id = 1.0 / det;
+  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+  o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+  o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+  return 0;
+}
+
+/* the distortion model of cv2.initUndistortRectifyMap with R = I
+ * (camera/LensDistortion.py:355-357); dist = [k1,k2,p1,p2,k3] (:370,380) */
+static inline void undistort_coord(const double* K, const double* d, const double* ir, long u,
+                                   long v, double* sx, double* sy) {
+  double _x = ir[0] * u + ir[1] * v + ir[2];
+  double _y = ir[3] * u + ir[4] * v + ir[5];
+  double _w = ir[6] * u + ir[7] * v + ir[8];
+  double iw = 1.0 / _w;
+  double x = _x * iw, y = _y * iw;
+  double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+  double kr = 1 + ((d[4] * r2 + d[1]) * r2 + d[0]) * r2;
+  double xd = x * kr + d[2] * _2xy + d[3] * (r2 + 2 * x2);
+  double yd = y * kr + d[2] * (r2 + 2 * y2) + d[3] * _2xy;
+  *sx = K[0] * xd + K[2];
+  *sy = K[4] * yd + K[5];
+}
+
+int orc_build_undistort_map(const double* K, const double* dist5, const double* newK, long h,
+                            long w, float* mapx, float* mapy, long map_pitch) {
+  double ir[9];
+  if (inv3(newK, ir)) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long v = 0; v < h; v++)
+    for (long u = 0; u < w; u++) {
+      double sx, sy;
+      undistort_coord(K, dist5, ir, u, v, &sx, &sy);
+      mapx[v * map_pitch + u] = (float)sx;
+      mapy[v * map_pitch + u] = (float)sy;
+    }
+  return 0;
+}
+
+/* analytic undistort = build float32 map value on the fly, then remap */
+int orc_undistort(const void* src, int src_dt, long sh, long sw, long src_pitch, const double* K,
+                  const double* dist5, const double* newK, void* dst, int dst_dt, long dh, long dw,
+                  long dst_pitch, int interp, int border, double cval) {
+  sampler_t s;
+  init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
+  double ir[9];
+  if (inv3(newK, ir)) return -1;
+  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  uint8_t cv8 = sat_u8(cval);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long v = 0; v < dh; v++)
+    for (long u = 0; u < dw; u++) {
+      double sx, sy;
+      undistort_coord(K, dist5, ir, u, v, &sx, &sy);
+      sx = (double)(float)sx; /* CV_32FC1 map storage */
+      sy = (double)(float)sy;
+      if (fixed)
+        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+      else
+        store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
+    }
+  return 0;
+}
+
+/* cv2.warpPerspective: dst(x,y) = src(M·(x,y,1)) with M the dst->src matrix
+ * (inverse of H unless WARP_INVERSE_MAP) — camera/PerspectiveCorrection.py:377-378,401-405.
+ * Coordinates are kept in double (skimage _warp_fast semantics); the q5 flag
+ * applies cv2's 1/32-px rounding. */
+int orc_warp_perspective(const void* src, int src_dt, long sh, long sw, long src_pitch,
+                         const double* M, void* dst, int dst_dt, long dh, long dw, long dst_pitch,
+                         int interp, int border, double cval) {
+  sampler_t s;
+  init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
+  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  uint8_t cv8 = sat_u8(cval);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long v = 0; v < dh; v++)
+    for (long u = 0; u < dw; u++) {
+      double X = M[0] * u + M[1] * v + M[2];
+      double Y = M[3] * u + M[4] * v + M[5];
+      double W = M[6] * u + M[7] * v + M[8];
+      double sx, sy;
+      if (W != 0) { double iw = 1.0 / W; sx = X * iw; sy = Y * iw; }
+      else { sx = 0; sy = 0; } /* cv2: W ? 1/W : 0 */
+      if (fixed)
+        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+      else
+        store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
+    }
+  return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* filters                                                             */
+/* ------------------------------------------------------------------ */
+
+/* filters/_extendArrayForConvolution.py:5-97.  kx,ky are the *kernel sizes*
+ * along x (columns) and y (rows); padding is k//2 per side.  'reflect'
+ * repeats the edge pixel (numpy 'symmetric'); modex may be 'wrap'.
+ * out has shape (h + 2*(ky/2), w + 2*(kx/2)), dense. */
+int orc_extend_array(const void* arr, int dt, long h, long w, long kx, long ky, int modex,
+                     int modey, void* out) {
+  long px = kx / 2, py = ky / 2;
+  if (!(py < h && px < w)) return -2; /* the reference asserts */
+  if (modey != ORC_REFLECT) return -3; /* modey=='wrap' raises in the reference (:57 typo) */
+  if (modex != ORC_REFLECT && modex != ORC_WRAP) return -3;
+  long ow = w + 2 * px, oh = h + 2 * py;
+  size_t es = dtype_size(dt);
+  for (long y = 0; y < oh; y++) {
+    long sy = resolve_idx(y - py, h, modey);
+    for (long x = 0; x < ow; x++) {
+      long sx = resolve_idx(x - px, w, modex);
+      memcpy((char*)out + (y * ow + x) * es, (const char*)arr + (sy * w + sx) * es, es);
+    }
+  }
+  return 0;
+}
+
+/* centred correlation, scipy.ndimage.correlate semantics (origin 0, centre at
+ * k//2), per-axis border mode, optional mask (unmasked -> 0), double accumulate */
+int orc_conv2d(const void* src, int dt, long h, long w, long pitch, const double* kern, long kh,
+               long kw, const uint8_t* mask, long mask_pitch, void* dst, long dst_pitch,
+               int border_x, int border_y, double cval) {
+  long cy = kh / 2, cx = kw / 2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long y = 0; y < h; y++)
+    for (long x = 0; x < w; x++) {
+      if (mask && !mask[y * mask_pitch + x]) { store_px(dst, dt, y * dst_pitch + x, 0.0); continue; }
+      double acc = 0.0;
+      for (long i = 0; i < kh; i++) {
+        long yy = resolve_idx(y + i - cy, h, border_y);
+        for (long j = 0; j < kw; j++) {
+          long xx = resolve_idx(x + j - cx, w, border_x);
+          double v = (yy < 0 || xx < 0) ? cval : load_px(src, dt, yy * pitch + xx);
+          acc += kern[i * kw + j] * v;
+        }
+      }
+      store_px(dst, dt, y * dst_pitch + x, acc);
+    }
+  return 0;
+}
+
+/* filters/maskedConvolve.py:13-43 as written: pad with extendArray, then
+ * kernel[ii,jj] with ii,jj in [-h..h] — NEGATIVE indices wrap (python), so
+ * the effective centred kernel is np.fft.fftshift(kernel).  Square odd kernels only. */
+int orc_masked_convolve(const void* arr, int dt, long h, long w, const double* kern, long k,
+                        const uint8_t* mask, int mode, void* out) {
+  if (k % 2 == 0) return -2;
+  long hk = k / 2;
+  /* the wrapper passes modex=modey=mode and modey=='wrap' raises (:57 typo):
+   * 'reflect' is the only mode the reference function can run with */
+  if (mode != ORC_REFLECT) return -3;
+  int my = mode, mx = mode;
+  long ow = w + 2 * hk, oh = h + 2 * hk;
+  size_t es = dtype_size(dt);
+  void* ext = malloc((size_t)ow * oh * es);
+  if (!ext) return -1;
+  int rc = orc_extend_array(arr, dt, h, w, k, k, mx, my, ext);
+  if (rc) { free(ext); return rc; }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = hk; i < oh - hk; i++)
+    for (long j = hk; j < ow - hk; j++) {
+      long oi = i - hk, oj = j - hk;
+      if (!mask[oi * w + oj]) { store_px(out, dt, oi * w + oj, 0.0); continue; }
+      double val = 0;
+      for (long ii = -hk; ii <= hk; ii++)
+        for (long jj = -hk; jj <= hk; jj++) {
+          long ki = ii < 0 ? ii + k : ii, kj = jj < 0 ? jj + k : jj; /* python negative index */
+          val += kern[ki * k + kj] * load_px(ext, dt, (i + ii) * ow + (j + jj));
+        }
+      store_px(out, dt, oi * w + oj, val);
+    }
+  free(ext);
+  return 0;
+}
+
+/* scipy.ndimage._filters._gaussian_kernel1d(sigma, order=0, radius) */
+int orc_gaussian_kernel1d(double sigma, long radius, double* out) {
+  double s2 = sigma * sigma, sum = 0;
+  for (long i = -radius; i <= radius; i++) {
+    out[i + radius] = exp(-0.5 / s2 * (double)(i * i));
+    sum += out[i + radius];
+  }
+  for (long i = 0; i <= 2 * radius; i++) out[i] /= sum;
+  return 0;
+}
+
+/* scipy.ndimage.gaussian_filter-style separable correlation: axis 0 (y) first
+ * with ky, result stored in the image dtype, then axis 1 (x) with kx.
+ * nky==0 or nkx==0 skips that axis (scipy skips sigma<=1e-15). */
+int orc_sepconv2d(const void* src, int dt, long h, long w, long pitch, const double* ky, long nky,
+                  const double* kx, long nkx, void* dst, long dst_pitch, int border_y,
+                  int border_x, double cval) {
+  size_t es = dtype_size(dt);
+  void* tmp = malloc((size_t)h * w * es);
+  if (!tmp) return -1;
+  long cy = nky / 2, cx = nkx / 2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long y = 0; y < h; y++)
+    for (long x = 0; x < w; x++) {
+      double acc;
+      if (nky > 0) {
+        acc = 0;
+        for (long i = 0; i < nky; i++) {
+          long yy = resolve_idx(y + i - cy, h, border_y);
+          acc += ky[i] * (yy < 0 ? cval : load_px(src, dt, yy * pitch + x));
+        }
+      } else acc = load_px(src, dt, y * pitch + x);
+      store_px(tmp, dt, y * w + x, acc);
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long y = 0; y < h; y++)
+    for (long x = 0; x < w; x++) {
+      double acc;
+      if (nkx > 0) {
+        acc = 0;
+        for (long j = 0; j < nkx; j++) {
+          long xx = resolve_idx(x + j - cx, w, border_x);
+          acc += kx[j] * (xx < 0 ? cval : load_px(tmp, dt, y * w + xx));
+        }
+      } else acc = load_px(tmp, dt, y * w + x);
+      store_px(dst, dt, y * dst_pitch + x, acc);
+    }
+  free(tmp);
+  return 0;
+}
+
+/* filters/varYSizeGaussianFilter.py:53-68 restricted to its well-defined
+ * output range: out[r,c] = sum_{ii<k0,jj<k1} kernels[r,ii,jj]*ext[r+ii,c+jj],
+ * NaN pixels skipped.  ext is the (h+2*(k0/2)) x (w+2*(k1/2)) padded array. */
+int orc_conv_ydep(const void* ext, int dt, long h, long w, const double* kernels, long k0, long k1,
+                  void* out) {
+  long ow = w + 2 * (k1 / 2);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long r = 0; r < h; r++)
+    for (long c = 0; c < w; c++) {
+      double v = 0;
+      for (long ii = 0; ii < k0; ii++)
+        for (long jj = 0; jj < k1; jj++) {
+          double a = load_px(ext, dt, (r + ii) * ow + (c + jj));
+          if (a == a) v += kernels[(r * k0 + ii) * k1 + jj] * a;
+        }
+      store_px(out, dt, r * w + c, v);
+    }
+  return 0;
+}
+
+/* filters/standardDeviation.py:34-70, quirks included: window
+ * [i-h, min(i+h,gx)) x [j-h, min(j+h,gy)), divisor = (n_i-1)*(n_j-1) (last loop indices) */
+int orc_std2d(const void* img, int dt, long gx, long gy, long ksx, long ksy, const void* blurred,
+              void* std) {
+  long hkx = ksx / 2, hky = ksy / 2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      long xmn = i - hkx < 0 ? 0 : i - hkx, xmx = i + hkx > gx ? gx : i + hkx;
+      long ymn = j - hky < 0 ? 0 : j - hky, ymx = j + hky > gy ? gy : j + hky;
+      double val = 0, mean = load_px(blurred, dt, i * gy + j);
+      for (long ii = 0; ii < xmx - xmn; ii++)
+        for (long jj = 0; jj < ymx - ymn; jj++) {
+          double d = load_px(img, dt, (xmn + ii) * gy + (ymn + jj)) - mean;
+          val += d * d;
+        }
+      double npx = (double)((xmx - xmn - 1) * (ymx - ymn - 1));
+      store_px(std, dt, i * gy + j, sqrt(val / npx));
+    }
+  return 0;
+}
+
+/* interpolate/interpolate2dStructuredIDW.py:26-65.  In-place on grid.
+ * The reference clamps xmx to gx (not gx-1) and then reads index gx: out of
+ * bounds (UB under numba).  Here the window is clamped to the array, which is
+ * identical wherever the reference is well defined. */
+int orc_idw(void* grid, int dt, const uint8_t* mask, long gx, long gy, long kernel,
+            const double* weights) {
+  long kw = 2 * kernel + 1;
+  size_t es = dtype_size(dt);
+  void* in = malloc((size_t)gx * gy * es);
+  if (!in) return -1;
+  memcpy(in, grid, (size_t)gx * gy * es); /* masked px are never read: copy == in-place */
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      if (!mask[i * gy + j]) continue;
+      long xmn = i - kernel < 0 ? 0 : i - kernel, xmx = i + kernel > gx - 1 ? gx - 1 : i + kernel;
+      long ymn = j - kernel < 0 ? 0 : j - kernel, ymx = j + kernel > gy - 1 ? gy - 1 : j + kernel;
+      double sumWi = 0, value = 0;
+      for (long xi = xmn; xi <= xmx; xi++)
+        for (long yi = ymn; yi <= ymx; yi++)
+          if ((xi != i || yi != j) && !mask[xi * gy + yi]) {
+            double wi = weights[(xi - i + kernel) * kw + (yi - j + kernel)];
+            sumWi += wi;
+            value += wi * load_px(in, dt, xi * gy + yi);
+          }
+      if (sumWi != 0) store_px(grid, dt, i * gy + j, value / sumWi);
+    }
+  free(in);
+  return 0;
+}
+
+/* interpolate/interpolate2dStructuredFastIDW.py:29-63.  indices: (n,2) int64
+ * offsets in growing-distance order, weights[n]; minnvals already decremented
+ * by the wrapper (it passes minnvals-1). */
+int orc_fast_idw(void* grid, int dt, const uint8_t* mask, long s0, long s1, const int64_t* indices,
+                 const double* weights, long n, long minnvals) {
+  size_t es = dtype_size(dt);
+  void* in = malloc((size_t)s0 * s1 * es);
+  if (!in) return -1;
+  memcpy(in, grid, (size_t)s0 * s1 * es);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (long i = 0; i < s0; i++)
+    for (long j = 0; j < s1; j++) {
+      if (!mask[i * s1 + j]) continue;
+      double sumWi = 0, value = 0;
+      long c = 0;
+      for (long k = 0; k < n; k++) {
+        long iii = i + indices[2 * k], jjj = j + indices[2 * k + 1];
+        if (iii >= 0 && iii < s0 && jjj >= 0 && jjj < s1) {
+          if (!mask[iii * s1 + jjj]) {
+            double wi = weights[k];
+            sumWi += wi;
+            value += wi * load_px(in, dt, iii * s1 + jjj);
+            if (c == minnvals) break;
+            c++;
+          }
+        } else if (c > 0 && (iii < -1 || iii > s0 + 1) && (jjj < -1 || jjj > s1 + 1))
+          break;
+      }
+      if (sumWi != 0) store_px(grid, dt, i * s1 + j, value / sumWi);
+    }
+  free(in);
+  return 0;
+}
+
+/* headline chain for the CPU baseline: map-based undistort then K x K filter */
+int orc_remap_conv2d(const void* src, int src_dt, long h, long w, const float* mapx,
+                     const float* mapy, const double* kern, long kh, long kw, void* tmp, void* dst,
+                     int dst_dt, int interp, int border, double cval, int cborder_x,
+                     int cborder_y) {
+  int rc = orc_remap(src, src_dt, h, w, w, mapx, mapy, w, tmp, dst_dt, h, w, w, interp, border, cval);
+  if (rc) return rc;
+  return orc_conv2d(tmp, dst_dt, h, w, w, kern, kh, kw, NULL, 0, dst, w, cborder_x, cborder_y, 0.0);
+}

@@ -1,0 +1,357 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ — runs ONLY in the build
+container (needs /root/reference, scipy; the skimage part needs
+/opt/conda/bin/python3.9 and is run as a child process).
+
+How the reference is executed: its in-tree numba stencils are plain
+Python+numpy under ``@jit(nopython=True)``; a throw-away identity shim for the
+``numba`` module (created in a temp dir, never committed) lets the SAME source
+run interpretively.  The cv2-backed parts (cv2 is an un-vendored, un-pinned
+dependency that is not installable here) cannot be imported; for those the
+fixtures hold the outputs of the libraries the north-star names as the parity
+target: scipy.ndimage.map_coordinates(order=1, 'grid-constant') and
+skimage.transform.warp(order=1/3).
+
+Fixtures are DATA (inputs + expected outputs as .npz); no reference source,
+bytecode or media file is copied.
+
+    python tests/golden/gen_golden.py            # writes tests/golden/*.npz
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+warnings.filterwarnings('ignore')
+
+
+def install_shim():
+    d = tempfile.mkdtemp(prefix='numba_shim_')
+    os.makedirs(os.path.join(d, 'numba'))
+    with open(os.path.join(d, 'numba', '__init__.py'), 'w') as f:
+        f.write(
+            "def _ident(*a, **k):\n"
+            "    if len(a) == 1 and callable(a[0]) and not k:\n"
+            "        return a[0]\n"
+            "    return lambda fn: fn\n"
+            "jit = njit = vectorize = guvectorize = _ident\n"
+            "boolean = bool\n")
+    sys.path.insert(0, d)
+    sys.path.insert(1, REF)
+
+
+def synth(shape, seed, dtype=np.float32):
+    """SURVEY §8(d) image content: smooth + noise, clipped to [0,1]"""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:shape[0], 0:shape[1]].astype(np.float64)
+    img = 0.5 + 0.25 * np.sin(2 * np.pi * x / 97) + 0.25 * np.cos(2 * np.pi * y / 61)
+    img += 0.05 * rng.standard_normal(shape)
+    return np.clip(img, 0, 1).astype(dtype)
+
+
+def gauss2d(n, sigma=1.0):
+    g = np.exp(-0.5 * (np.arange(n) - n // 2) ** 2 / sigma ** 2)
+    g /= g.sum()
+    return np.outer(g, g)
+
+
+def gen_stencils():
+    import io
+    import contextlib
+    from imgProcessor.filters._extendArrayForConvolution import extendArrayForConvolution
+    from imgProcessor.filters.maskedConvolve import maskedConvolve
+    from imgProcessor.filters.varYSizeGaussianFilter import varYSizeGaussianFilter
+    from imgProcessor.filters.standardDeviation import standardDeviation2d
+    from imgProcessor.interpolate.interpolate2dStructuredIDW import interpolate2dStructuredIDW
+    from imgProcessor.interpolate.interpolate2dStructuredFastIDW import \
+        interpolate2dStructuredFastIDW
+    from imgProcessor.utils.growPositions import growPositions
+
+    # (2) extendArrayForConvolution ------------------------------------
+    out = {}
+    arr = synth((20, 26), 7, np.float64)
+    out['arr'] = arr
+    for (kx, ky) in [(3, 3), (5, 5), (9, 5), (1, 5), (5, 1)]:
+        for modex in ('reflect', 'wrap'):
+            out['ext_kx%d_ky%d_%s' % (kx, ky, modex)] = extendArrayForConvolution(
+                arr, (kx, ky), modex=modex, modey='reflect')
+    np.savez_compressed(os.path.join(HERE, 'extend_array.npz'), **out)
+
+    # (1) maskedConvolve -------------------------------------------------
+    out = {}
+    H, W = 48, 64
+    rng = np.random.default_rng(11)
+    kernels = {
+        'box3': np.ones((3, 3)) / 9,
+        'eye5': np.eye(5),
+        'asym5': rng.random((5, 5)),
+        'gauss5c': gauss2d(5),
+        'gauss5s': np.fft.ifftshift(gauss2d(5)),
+        'rand7': rng.random((7, 7)) / 49,
+        'rand11': rng.random((11, 11)) / 121,
+    }
+    masks = {'all': np.ones((H, W), bool)}
+    m = np.zeros((H, W), bool)
+    m[20:24] = True
+    m[:, 30:34] = True
+    masks['cross'] = m
+    masks['rand10'] = rng.random((H, W)) < 0.1
+    imgs = {'f32s0': synth((H, W), 0, np.float32), 'f32s1': synth((H, W), 1, np.float32),
+            'f64s2': synth((H, W), 2, np.float64)}
+    for k, v in kernels.items():
+        out['kernel_' + k] = v
+    for k, v in masks.items():
+        out['mask_' + k] = v
+    for k, v in imgs.items():
+        out['img_' + k] = v
+    cases = []
+    for kn in kernels:
+        cases.append(('f32s0', kn, 'all'))
+    for kn in ('asym5', 'rand7'):
+        cases += [('f32s1', kn, 'cross'), ('f64s2', kn, 'rand10'), ('f64s2', kn, 'all')]
+    for (im, kn, mk) in cases:
+        with contextlib.redirect_stdout(io.StringIO()):  # the reference prints the padded shape
+            o = maskedConvolve(imgs[im], kernels[kn], masks[mk])
+        out['out_%s_%s_%s' % (im, kn, mk)] = o
+    # the reference's own pinned assertion (filters/maskedConvolve.py:56-73), scaled down
+    a = np.fromfunction(lambda x, y: np.sin(x) + np.cos(y), (60, 80))
+    mk = np.zeros_like(a, dtype=bool)
+    mk[40:44] = True
+    mk[:, 40:44] = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        o = maskedConvolve(a, np.eye(5), mk)
+    from scipy.ndimage import convolve
+    o2 = convolve(a, np.eye(5))
+    o2[~mk] = 0
+    assert np.allclose(o, o2)
+    out['selftest_arr'] = a
+    out['selftest_mask'] = mk
+    out['selftest_out'] = o
+    np.savez_compressed(os.path.join(HERE, 'masked_convolve.npz'), **out)
+
+    # (3) varYSizeGaussianFilter ---------------------------------------
+    out = {}
+    a = synth((40, 40), 3, np.float64)
+    out['arr'] = a
+    out['out_0_4_1'] = varYSizeGaussianFilter(a.copy(), (0, 4), 1)
+    out['out_3_0'] = varYSizeGaussianFilter(a.copy(), 3, 0)
+    an = a.copy()
+    an[10, :] = np.nan
+    an[25, 3:9] = np.nan
+    out['arr_nan'] = an
+    out['out_nan_0_4_1'] = varYSizeGaussianFilter(an.copy(), (0, 4), 1)
+    out['out_1_3_2_reflect'] = varYSizeGaussianFilter(a.copy(), (1, 3), 2, modex='reflect')
+    np.savez_compressed(os.path.join(HERE, 'var_y_gauss.npz'), **out)
+
+    # (4) standardDeviation2d ---------------------------------------------
+    out = {}
+    a = synth((40, 52), 4, np.float64)
+    out['img'] = a
+    for k in (5, 11):
+        out['std_k%d' % k] = standardDeviation2d(a, ksize=k)
+    a32 = synth((40, 52), 5, np.float32)
+    out['img32'] = a32
+    out['std32_k5'] = standardDeviation2d(a32, ksize=5)
+    np.savez_compressed(os.path.join(HERE, 'std2d.npz'), **out)
+
+    # (5) IDW / FastIDW ------------------------------------------------------
+    out = {}
+    H = W = 64
+    g = synth((H, W), 6, np.float64)
+    out['grid'] = g
+    rng = np.random.default_rng(12)
+    for kern in (3, 5, 15):
+        m = rng.random((H, W)) < 0.15
+        m[10:16, 20:27] = True  # a hole bigger than kernel=3/5 windows can bridge only partly
+        m[H - kern - 1:, :] = False  # keep masked px >= kernel+1 from bottom/right (reference OOB quirk)
+        m[:, W - kern - 1:] = False
+        out['mask_k%d' % kern] = m
+        for power in (1, 2, 3):
+            gg = g.copy()
+            out['idw_k%d_p%d' % (kern, power)] = interpolate2dStructuredIDW(gg, m, kern, power)
+        gg = g.copy()
+        out['idw_k%d_p2_fx2_fy05' % kern] = interpolate2dStructuredIDW(gg, m, kern, 2, 2, 0.5)
+        for power, minn in ((2, 5), (1, 3), (3, 9)):
+            gg = g.copy()
+            out['fidw_k%d_p%d_n%d' % (kern, power, minn)] = interpolate2dStructuredFastIDW(
+                gg, m, kern, power, minn)
+    g32 = g.astype(np.float32)
+    out['idw32_k5_p2'] = interpolate2dStructuredIDW(g32.copy(), out['mask_k5'], 5, 2)
+    # fully masked block in the middle bigger than the window: those px stay untouched
+    m = np.zeros((H, W), bool)
+    m[20:40, 20:40] = True
+    out['mask_block'] = m
+    out['idw_block_k3'] = interpolate2dStructuredIDW(g.copy(), m, 3, 2)
+    out['fidw_block_k3'] = interpolate2dStructuredFastIDW(g.copy(), m, 3, 2, 5)
+    pos, dist = growPositions(4)
+    out['grow4_pos'] = pos
+    out['grow4_dist'] = dist
+    np.savez_compressed(os.path.join(HERE, 'idw.npz'), **out)
+
+
+# ---------------------------------------------------------------------------
+def undistort_map_np(K, d, newK, h, w):
+    """documented cv2.initUndistortRectifyMap formula (R = I), float64 numpy,
+    written independently of oracle.c"""
+    k1, k2, p1, p2, k3 = d
+    ir = np.linalg.inv(np.asarray(newK, float))
+    v, u = np.mgrid[0:h, 0:w].astype(np.float64)
+    X = ir[0, 0] * u + ir[0, 1] * v + ir[0, 2]
+    Y = ir[1, 0] * u + ir[1, 1] * v + ir[1, 2]
+    Wd = ir[2, 0] * u + ir[2, 1] * v + ir[2, 2]
+    x = X / Wd
+    y = Y / Wd
+    r2 = x * x + y * y
+    kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2
+    xd = x * kr + 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+    yd = y * kr + p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+    K = np.asarray(K, float)
+    return ((K[0, 0] * xd + K[0, 2]).astype(np.float32),
+            (K[1, 1] * yd + K[1, 2]).astype(np.float32))
+
+
+def perspective_from_quad(quad, dst):
+    A = np.zeros((8, 8))
+    b = np.zeros(8)
+    for i, ((x, y), (u, v)) in enumerate(zip(quad, dst)):
+        A[i] = [x, y, 1, 0, 0, 0, -x * u, -y * u]
+        A[i + 4] = [0, 0, 0, x, y, 1, -x * v, -y * v]
+        b[i], b[i + 4] = u, v
+    return np.append(np.linalg.solve(A, b), 1).reshape(3, 3)
+
+
+REMAP_CASES = {
+    # name: (fx, fy, cx, cy, [k1,k2,p1,p2,k3])
+    'zero': (128.0, 128.0, 63.5, 47.5, [0, 0, 0, 0, 0]),
+    'radial': (128.0, 128.0, 63.5, 47.5, [-0.12, 0.03, 1e-3, -5e-4, 0]),
+    # in-tree synthetic default of camera/lens/estimateSystematicErrorLensCorrection.py:99-114
+    'synthdefault': (96.0, 96.0, 48.0, 64.0, [0.0, 0.01, 0.1, 0.01, 0.001]),
+    'strong': (100.0, 110.0, 60.0, 50.0, [0.35, -0.1, 5e-3, 3e-3, 0.02]),
+}
+
+
+def gen_remap_scipy():
+    from scipy.ndimage import map_coordinates, correlate, gaussian_filter
+    H, W = 96, 128
+    out = {}
+    img = synth((H, W), 0, np.float32)
+    img16 = np.round(synth((H, W), 1, np.float64) * 4095).astype(np.uint16)
+    out['img'] = img
+    out['img16'] = img16
+    for name, (fx, fy, cx, cy, d) in REMAP_CASES.items():
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.]])
+        newK = K.copy()
+        if name == 'strong':
+            newK = np.array([[90., 0, 66], [0, 95., 45], [0, 0, 1.]])
+        mx, my = undistort_map_np(K, d, newK, H, W)
+        out['K_' + name] = K
+        out['newK_' + name] = newK
+        out['dist_' + name] = np.array(d, float)
+        out['mapx_' + name] = mx
+        out['mapy_' + name] = my
+        for cv, cname in ((0.0, 'c0'), (np.nan, 'cnan'), (0.37, 'c037')):
+            if cname != 'c0' and name not in ('radial', 'strong'):
+                continue
+            out['lin_%s_%s' % (name, cname)] = map_coordinates(
+                img, [my, mx], order=1, mode='grid-constant', cval=cv, output=np.float32)
+        out['lin16_%s' % name] = map_coordinates(
+            img16.astype(np.float32), [my, mx], order=1, mode='grid-constant', cval=0,
+            output=np.float32)
+        # other border modes of the same gather (scipy names -> cv2 ids in the test)
+        if name == 'strong':
+            for smode in ('nearest', 'reflect', 'mirror', 'grid-wrap'):
+                out['lin_%s_%s' % (name, smode)] = map_coordinates(
+                    img, [my, mx], order=1, mode=smode, output=np.float32)
+    # headline chain at fixture size: undistort then 5x5 explicit Gaussian
+    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
+    g /= g.sum()
+    k5 = np.outer(g, g)
+    out['k5'] = k5
+    und = out['lin_radial_c0']
+    out['chain_radial_k5'] = correlate(und, k5.astype(np.float64), mode='reflect')
+    # filters as the reference obtains them
+    out['corr_box3'] = correlate(img, np.ones((3, 3)) / 9, mode='reflect')
+    rk = np.random.default_rng(123).random((7, 7))
+    rk /= rk.sum()
+    out['k7'] = rk
+    out['corr_k7'] = correlate(img, rk, mode='reflect')
+    for smode in ('nearest', 'mirror', 'wrap', 'constant'):
+        out['corr_k7_' + smode] = correlate(img, rk, mode=smode, cval=0.25)
+    rk11 = np.random.default_rng(321).random((11, 11))
+    rk11 /= rk11.sum()
+    out['k11'] = rk11
+    out['corr_k11'] = correlate(img, rk11, mode='reflect')
+    out['corr_k3x7'] = correlate(img, rk[:3, :], mode='reflect')
+    out['corr_k6x4'] = correlate(img, rk[:6, :4], mode='reflect')  # even sizes: centre k//2
+    for s in (0.5, 1.0, 1.25, 2.0):
+        out['gauss_s%s' % str(s).replace('.', 'p')] = gaussian_filter(img, s)
+    out['gauss_s1_2p5'] = gaussian_filter(img, (1.0, 2.5))
+    out['gauss64_s1'] = gaussian_filter(img.astype(np.float64), 1.0)
+    np.savez_compressed(os.path.join(HERE, 'remap_scipy.npz'), **out)
+
+
+SKIMAGE_CHILD = r'''
+import sys, warnings
+import numpy as np
+warnings.filterwarnings('ignore')
+from skimage.transform import warp
+d = dict(np.load(sys.argv[1]))
+out = {}
+img = d['img']
+for name in [k[2:] for k in d if k.startswith('M_')]:
+    M = d['M_' + name]
+    shp = tuple(int(v) for v in d['shape_' + name])
+    for order in (1, 3):
+        for cname, cv in (('c0', 0.0), ('c05', 0.5)):
+            out['warp_%s_o%d_%s' % (name, order, cname)] = warp(
+                img.astype(np.float64), M, output_shape=shp, order=order, mode='constant',
+                cval=cv, clip=False, preserve_range=True)
+    out['warp_%s_o1_edge' % name] = warp(img.astype(np.float64), M, output_shape=shp, order=1,
+                                         mode='edge', clip=False, preserve_range=True)
+np.savez_compressed(sys.argv[2], **out)
+'''
+
+
+def gen_warp_skimage():
+    H, W = 96, 128
+    img = synth((H, W), 2, np.float32)
+    d = {'img': img}
+    # demo quad of camera/PerspectiveCorrection.py:866-869 scaled to the fixture, -> full rect
+    quad = np.array([(8, 2), (120, 6), (122, 90), (5, 93)], float)
+    for name, (sy, sx, b) in {'quad': (96, 128, 0), 'quadb': (80, 100, 7)}.items():
+        dst = np.array([[b, b], [sx - b, b], [sx - b, sy - b], [b, sy - b]], float)
+        Hm = perspective_from_quad(quad, dst)
+        d['H_' + name] = Hm
+        d['M_' + name] = np.linalg.inv(Hm)  # dst -> src
+        d['shape_' + name] = np.array([sy, sx])
+    # rotation by 7 deg + mild perspective (SURVEY C5 style)
+    a = np.deg2rad(7.0)
+    R = np.array([[np.cos(a), -np.sin(a), 10.0], [np.sin(a), np.cos(a), -6.0], [2e-4, -1e-4, 1.0]])
+    d['M_rot7'] = R
+    d['H_rot7'] = np.linalg.inv(R)
+    d['shape_rot7'] = np.array([H, W])
+    tmp_in = os.path.join(tempfile.mkdtemp(), 'in.npz')
+    np.savez(tmp_in, **d)
+    tmp_out = tmp_in.replace('in.npz', 'out.npz')
+    child = tmp_in.replace('in.npz', 'child.py')
+    with open(child, 'w') as f:
+        f.write(SKIMAGE_CHILD)
+    subprocess.check_call(['/opt/conda/bin/python3.9', child, tmp_in, tmp_out])
+    o = dict(np.load(tmp_out))
+    d.update(o)
+    np.savez_compressed(os.path.join(HERE, 'warp_skimage.npz'), **d)
+
+
+if __name__ == '__main__':
+    install_shim()
+    gen_stencils()
+    gen_remap_scipy()
+    gen_warp_skimage()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print('%-24s %7.1f KB' % (f, os.path.getsize(os.path.join(HERE, f)) / 1024))

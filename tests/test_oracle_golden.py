@@ -1,0 +1,234 @@
+"""CPU: the oracle (oracle/oracle.c) against the golden fixtures.
+
+Fixtures come from the reference itself (in-tree numba stencils run through an
+identity shim), scipy.ndimage and skimage — see tests/golden/gen_golden.py.
+"""
+import numpy as np
+import pytest
+
+from .conftest import load_golden, assert_close
+
+F32 = 2.5e-7  # one float32 ulp-ish: oracle accumulates in double, output is float32
+
+
+def test_extend_array(oracle):
+    g = load_golden('extend_array.npz')
+    arr = g['arr']
+    n = 0
+    for k, want in g.items():
+        if not k.startswith('ext_'):
+            continue
+        _, kx, ky, modex = k.split('_')
+        got = oracle.extendArrayForConvolution(arr, (int(kx[2:]), int(ky[2:])), modex=modex)
+        assert np.array_equal(got, want), k
+        n += 1
+    assert n == 10
+    # numpy equivalents
+    assert np.array_equal(oracle.extendArrayForConvolution(arr, (9, 5)),
+                          np.pad(arr, ((2, 2), (4, 4)), mode='symmetric'))
+    with pytest.raises(RuntimeError):  # modey='wrap' is not supported by the reference (:57)
+        oracle.extendArrayForConvolution(arr, (3, 3), modey='wrap')
+
+
+def test_masked_convolve(oracle):
+    g = load_golden('masked_convolve.npz')
+    n = 0
+    for k, want in g.items():
+        if not k.startswith('out_'):
+            continue
+        _, im, kn, mk = k.split('_')
+        img = g['img_' + im]
+        got = oracle.maskedConvolve(img, g['kernel_' + kn], g['mask_' + mk])
+        assert got.dtype == want.dtype
+        assert_close(got, want, rtol=F32 if img.dtype == np.float32 else 1e-13,
+                     atol=1e-7 if img.dtype == np.float32 else 1e-15, what=k)
+        # identity of SURVEY §8(b): maskedConvolve == where(mask, correlate(arr, fftshift(k)), 0)
+        c = oracle.conv2d(img, np.fft.fftshift(g['kernel_' + kn]), 'reflect', mask=g['mask_' + mk])
+        assert np.array_equal(c, got), k
+        n += 1
+    assert n == 13
+    got = oracle.maskedConvolve(g['selftest_arr'], np.eye(5), g['selftest_mask'])
+    assert_close(got, g['selftest_out'], rtol=1e-13, atol=1e-15, what='selftest')
+
+
+def test_var_y_gauss(oracle):
+    g = load_golden('var_y_gauss.npz')
+    assert_close(oracle.varYSizeGaussianFilter(g['arr'], (0, 4), 1), g['out_0_4_1'], 1e-12, 1e-15)
+    assert_close(oracle.varYSizeGaussianFilter(g['arr'], 3, 0), g['out_3_0'], 1e-12, 1e-15)
+    assert_close(oracle.varYSizeGaussianFilter(g['arr_nan'], (0, 4), 1), g['out_nan_0_4_1'],
+                 1e-12, 1e-15)
+    assert_close(oracle.varYSizeGaussianFilter(g['arr'], (1, 3), 2, modex='reflect'),
+                 g['out_1_3_2_reflect'], 1e-12, 1e-15)
+
+
+def test_std2d(oracle):
+    g = load_golden('std2d.npz')
+    for k in (5, 11):
+        assert_close(oracle.standardDeviation2d(g['img'], k), g['std_k%d' % k], 1e-11, 1e-14)
+    assert_close(oracle.standardDeviation2d(g['img32'], 5), g['std32_k5'], 2e-6, 1e-7)
+
+
+def test_idw(oracle):
+    g = load_golden('idw.npz')
+    grid = g['grid']
+    n = 0
+    for k, want in g.items():
+        if k.startswith('idw_k'):
+            p = k.split('_')
+            kern, power = int(p[1][1:]), int(p[2][1:])
+            fx, fy = (2, 0.5) if len(p) > 3 else (1, 1)
+            got = oracle.interpolate2dStructuredIDW(grid.copy(), g['mask_k%d' % kern], kern,
+                                                    power, fx, fy)
+        elif k.startswith('fidw_k'):
+            p = k.split('_')
+            kern, power, minn = int(p[1][1:]), int(p[2][1:]), int(p[3][1:])
+            got = oracle.interpolate2dStructuredFastIDW(grid.copy(), g['mask_k%d' % kern], kern,
+                                                        power, minn)
+        else:
+            continue
+        assert_close(got, want, 1e-12, 1e-15, what=k)
+        n += 1
+    assert n == 21
+    assert_close(oracle.interpolate2dStructuredIDW(grid.astype(np.float32), g['mask_k5'], 5, 2),
+                 g['idw32_k5_p2'], F32, 0, 'idw32')
+    assert_close(oracle.interpolate2dStructuredIDW(grid.copy(), g['mask_block'], 3, 2),
+                 g['idw_block_k3'], 1e-12)
+    assert_close(oracle.interpolate2dStructuredFastIDW(grid.copy(), g['mask_block'], 3, 2, 5),
+                 g['fidw_block_k3'], 1e-12)
+    pos, dist = oracle.growPositions(4)
+    assert np.array_equal(pos, g['grow4_pos']) and np.array_equal(dist, g['grow4_dist'])
+
+
+CASES = ('zero', 'radial', 'synthdefault', 'strong')
+
+
+def test_undistort_map(oracle):
+    g = load_golden('remap_scipy.npz')
+    H, W = g['img'].shape
+    for c in CASES:
+        mx, my = oracle.build_undistort_map(g['K_' + c], g['dist_' + c], g['newK_' + c], H, W)
+        # independent numpy float64 evaluation of the documented formula; allow 1 ulp of f32
+        assert_close(mx, g['mapx_' + c], 1.2e-7, 1e-6, 'mapx ' + c)
+        assert_close(my, g['mapy_' + c], 1.2e-7, 1e-6, 'mapy ' + c)
+    mx, my = oracle.build_undistort_map(g['K_zero'], g['dist_zero'], g['newK_zero'], H, W)
+    yy, xx = np.mgrid[0:H, 0:W]
+    assert np.abs(mx - xx).max() < 1e-4 and np.abs(my - yy).max() < 1e-4
+
+
+def test_remap_linear_scipy(oracle):
+    g = load_golden('remap_scipy.npz')
+    img, img16 = g['img'], g['img16']
+    n = 0
+    for c in CASES:
+        mx, my = g['mapx_' + c], g['mapy_' + c]
+        for cname, cv in (('c0', 0.0), ('cnan', np.nan), ('c037', 0.37)):
+            key = 'lin_%s_%s' % (c, cname)
+            if key not in g:
+                continue
+            got = oracle.remap(img, mx, my, oracle.LINEAR, oracle.CONSTANT, cv)
+            assert_close(got, g[key], F32, 1e-7, key)
+            n += 1
+        got = oracle.remap(img16, mx, my, oracle.LINEAR, oracle.CONSTANT, 0, out_dtype=np.float32)
+        assert_close(got, g['lin16_' + c], F32, 1e-4, 'lin16 ' + c)
+        # analytic undistort == map-based remap (same float32 coordinates)
+        an = oracle.undistort(img, g['K_' + c], g['dist_' + c], g['newK_' + c])
+        assert_close(an, g['lin_%s_c0' % c], 2e-6, 2e-6, 'analytic ' + c)
+    assert n == 8
+    mx, my = g['mapx_strong'], g['mapy_strong']
+    for smode, b in (('nearest', oracle.REPLICATE), ('reflect', oracle.REFLECT),
+                     ('mirror', oracle.REFLECT101), ('grid-wrap', oracle.WRAP)):
+        got = oracle.remap(img, mx, my, oracle.LINEAR, b)
+        assert_close(got, g['lin_strong_' + smode], F32, 1e-7, smode)
+
+
+def test_filters_scipy(oracle):
+    g = load_golden('remap_scipy.npz')
+    img = g['img']
+    assert_close(oracle.conv2d(img, np.ones((3, 3)) / 9), g['corr_box3'], F32, 0, 'box3')
+    assert_close(oracle.conv2d(img, g['k7']), g['corr_k7'], F32, 0, 'k7')
+    assert_close(oracle.conv2d(img, g['k11']), g['corr_k11'], F32, 0, 'k11')
+    assert_close(oracle.conv2d(img, g['k7'][:3, :]), g['corr_k3x7'], F32, 0, 'k3x7')
+    assert_close(oracle.conv2d(img, g['k7'][:6, :4]), g['corr_k6x4'], F32, 0, 'k6x4')
+    for smode in ('nearest', 'mirror', 'wrap', 'constant'):
+        assert_close(oracle.conv2d(img, g['k7'], smode, cval=0.25), g['corr_k7_' + smode], F32, 0,
+                     smode)
+    for s in (0.5, 1.0, 1.25, 2.0):
+        assert_close(oracle.gaussian_filter(img, s), g['gauss_s%s' % str(s).replace('.', 'p')],
+                     F32, 0, 'gauss %s' % s)
+    assert_close(oracle.gaussian_filter(img, (1.0, 2.5)), g['gauss_s1_2p5'], F32, 0)
+    assert_close(oracle.gaussian_filter(img.astype(np.float64), 1.0), g['gauss64_s1'], 1e-13, 0)
+    # kernel radius rule of scipy: 5 taps <-> sigma 0.5, 9 taps <-> sigma 1.0
+    assert oracle.gaussian_kernel1d(0.5).size == 5 and oracle.gaussian_kernel1d(1.0).size == 9
+    # headline chain
+    und = oracle.remap(img, g['mapx_radial'], g['mapy_radial'])
+    assert_close(oracle.conv2d(und, g['k5']), g['chain_radial_k5'], 4e-7, 0, 'chain')
+    assert_close(oracle.remap_conv2d(img, g['mapx_radial'], g['mapy_radial'], g['k5']),
+                 g['chain_radial_k5'], 4e-7, 0, 'chain fused entry')
+
+
+def test_warp_skimage(oracle):
+    g = load_golden('warp_skimage.npz')
+    img = g['img'].astype(np.float64)
+    n = 0
+    for name in ('quad', 'quadb', 'rot7'):
+        M = g['M_' + name]
+        shp = tuple(int(v) for v in g['shape_' + name])
+        for order, interp in ((1, oracle.LINEAR), (3, oracle.CUBIC_KEYS)):
+            for cname, cv in (('c0', 0.0), ('c05', 0.5)):
+                want = g['warp_%s_o%d_%s' % (name, order, cname)]
+                got = oracle.warp_perspective(img, M, shp, interp, oracle.CONSTANT, cv)
+                assert_close(got, want, 1e-11, 1e-12, '%s o%d %s' % (name, order, cname))
+                n += 1
+        got = oracle.warp_perspective(img, M, shp, oracle.LINEAR, oracle.REPLICATE)
+        assert_close(got, g['warp_%s_o1_edge' % name], 1e-11, 1e-12, name + ' edge')
+        # H maps the quad onto the destination rectangle (getPerspectiveTransform semantics)
+    assert n == 12
+    quad = np.array([(8, 2), (120, 6), (122, 90), (5, 93)], float)
+    dst = np.array([[0, 0], [128, 0], [128, 96], [0, 96]], float)
+    H = oracle.get_perspective_transform(quad, dst)
+    assert_close(H, g['H_quad'], 1e-10, 1e-12)
+    p = H @ np.c_[quad, np.ones(4)].T
+    assert_close((p[:2] / p[2]).T, dst, 0, 1e-9)
+
+
+def test_known_answers(oracle):
+    rng = np.random.default_rng(5)
+    img = rng.random((33, 47)).astype(np.float32)
+    yy, xx = np.mgrid[0:33, 0:47].astype(np.float32)
+    for interp in (oracle.NEAREST, oracle.LINEAR, oracle.CUBIC_CV, oracle.CUBIC_KEYS,
+                   oracle.LANCZOS4, oracle.LINEAR | oracle.Q5, oracle.CUBIC_CV | oracle.Q5):
+        got = oracle.remap(img, xx, yy, interp)
+        assert np.array_equal(got, img), interp  # identity map -> bit-exact copy
+    # integer translation with constant border
+    got = oracle.remap(img, xx + 3, yy - 2, oracle.LINEAR, oracle.CONSTANT, 7.0)
+    want = np.full_like(img, 7.0)
+    want[2:, :-3] = img[:-2, 3:]
+    assert np.array_equal(got, want)
+    # uint8 fixed-point path: identity and half-pixel average with rounding
+    u8 = rng.integers(0, 256, (33, 47), dtype=np.uint8)
+    assert np.array_equal(oracle.remap(u8, xx, yy), u8)
+    got = oracle.remap(u8, xx + 0.5, yy)
+    a = u8.astype(np.int64)
+    want = np.zeros_like(a)
+    want[:, :-1] = (a[:, :-1] * 16384 + a[:, 1:] * 16384 + 16384) >> 15
+    want[:, -1] = (a[:, -1] * 16384 + 16384) >> 15
+    assert np.array_equal(got, want.astype(np.uint8))
+    # Lanczos4 weights sum to 1 and reproduce constants
+    c = np.full((20, 20), 3.25, np.float32)
+    yy2, xx2 = np.mgrid[0:20, 0:20].astype(np.float32)
+    got = oracle.remap(c, xx2 * 0.5 + 5.3, yy2 * 0.5 + 5.1, oracle.LANCZOS4)
+    assert_close(got, c, 1e-6)
+    # rotate +14 then -14 deg (transform/rotate.py:26-32 bound: mean|a-c| < 0.005 on a smooth image)
+    H_, W_ = 120, 160
+    y, x = np.mgrid[0:H_, 0:W_]
+    smooth = (0.5 + 0.5 * np.sin(x / 19.0) * np.cos(y / 23.0)).astype(np.float32)
+
+    def rot(a, deg):
+        t = np.deg2rad(deg)
+        cx, cy = (W_ - 1) / 2, (H_ - 1) / 2
+        R = np.array([[np.cos(t), np.sin(t), 0], [-np.sin(t), np.cos(t), 0], [0, 0, 1.]])
+        T = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.]])
+        M = T @ R @ np.linalg.inv(T)
+        return oracle.warp_perspective(a, M, a.shape, oracle.CUBIC_CV, oracle.REFLECT)
+    back = rot(rot(smooth, 14), -14)
+    assert np.abs(back - smooth)[20:-20, 20:-20].mean() < 0.005
