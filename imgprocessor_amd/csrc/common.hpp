@@ -1,0 +1,142 @@
+// common.hpp — context, error plumbing and device helpers shared by the gfx950 kernels.
+// Written for MI355X (CDNA4, wave64) only; no portability layer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/imgproc_hip.h"
+
+struct ipa_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int cu_count = 0;
+  std::string last_error;
+  // grow-only device workspace used by the host-pointer entry points
+  void* ws = nullptr;
+  size_t ws_bytes = 0;
+  // small device scratch for per-call tables (IDW weights, Lanczos table, ...)
+  void* tab = nullptr;
+  size_t tab_bytes = 0;
+  void* tab_pinned = nullptr;  // pinned staging so the H2D is truly stream-ordered
+  std::mutex mu;
+};
+
+struct ipa_event {
+  hipEvent_t ev;
+};
+
+void ipa_set_error(ipa_ctx* ctx, const char* fmt, ...);
+int ipa_ws_reserve(ipa_ctx* ctx, size_t bytes);                         // ctx->ws >= bytes
+int ipa_tab_upload(ipa_ctx* ctx, const void* host, size_t bytes, void** d);  // stream-ordered
+
+#define IPA_HIP(ctx, call)                                                            \
+  do {                                                                                \
+    hipError_t e__ = (call);                                                          \
+    if (e__ != hipSuccess) {                                                          \
+      ipa_set_error(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),      \
+                    __FILE__, __LINE__);                                              \
+      return e__ == hipErrorOutOfMemory ? IPA_ERR_OOM : IPA_ERR_HIP;                  \
+    }                                                                                 \
+  } while (0)
+
+#define IPA_REQUIRE(ctx, cond, ...)          \
+  do {                                       \
+    if (!(cond)) {                           \
+      ipa_set_error(ctx, __VA_ARGS__);       \
+      return IPA_ERR_BAD_ARG;                \
+    }                                        \
+  } while (0)
+
+#define IPA_UNSUPPORTED(ctx, ...)            \
+  do {                                       \
+    ipa_set_error(ctx, __VA_ARGS__);         \
+    return IPA_ERR_UNSUPPORTED;              \
+  } while (0)
+
+static inline size_t ipa_dtype_size(int dt) {
+  switch (dt) {
+    case IPA_U8: return 1;
+    case IPA_U16: return 2;
+    case IPA_F32: return 4;
+    case IPA_F64: return 8;
+  }
+  return 0;
+}
+
+// -------------------------------------------------------------------------
+// device helpers
+// -------------------------------------------------------------------------
+namespace ipa {
+
+constexpr int kWave = 64;
+constexpr int kXcds = 8;  // MI355X: 8 XCDs, blocks are dealt round-robin over them
+
+// Bijective XCD-aware remap of a linear workgroup id: workgroups that land on
+// the same XCD (id % 8) get a CONTIGUOUS range of tiles, so tiles that share
+// halo / source rows share that XCD's L2.  Speed only, never correctness.
+__device__ __forceinline__ unsigned xcd_swizzle(unsigned bid, unsigned nwg) {
+  unsigned q = nwg / kXcds, r = nwg % kXcds;
+  unsigned k = bid % kXcds, j = bid / kXcds;
+  unsigned start = k * q + (k < r ? k : r);
+  return start + j;
+}
+
+// index resolution shared by every border-aware load; returns -1 for "cval"
+__device__ __forceinline__ int resolve_idx(int i, int n, int mode) {
+  if ((unsigned)i < (unsigned)n) return i;
+  switch (mode) {
+    case IPA_BORDER_REPLICATE: return i < 0 ? 0 : n - 1;
+    case IPA_BORDER_REFLECT: {
+      if (n == 1) return 0;
+      int p = 2 * n;
+      int m = i % p;
+      if (m < 0) m += p;
+      return m < n ? m : p - 1 - m;
+    }
+    case IPA_BORDER_REFLECT101: {
+      if (n == 1) return 0;
+      int p = 2 * n - 2;
+      int m = i % p;
+      if (m < 0) m += p;
+      return m < n ? m : p - m;
+    }
+    case IPA_BORDER_WRAP: {
+      int m = i % n;
+      if (m < 0) m += n;
+      return m;
+    }
+    default: return -1;
+  }
+}
+
+__device__ __forceinline__ float ipa_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double ipa_fma(double a, double b, double c) { return fma(a, b, c); }
+
+template <typename T> struct compute_of { using type = float; };
+template <> struct compute_of<double> { using type = double; };
+
+// cv::saturate_cast semantics for integer outputs: round-half-even then clamp
+template <typename DT, typename CT> __device__ __forceinline__ DT store_cast(CT v);
+template <> __device__ __forceinline__ float store_cast<float, float>(float v) { return v; }
+template <> __device__ __forceinline__ double store_cast<double, double>(double v) { return v; }
+template <> __device__ __forceinline__ float store_cast<float, double>(double v) { return (float)v; }
+template <> __device__ __forceinline__ uint8_t store_cast<uint8_t, float>(float v) {
+  float r = rintf(v);
+  r = r > 0.f ? r : 0.f;  // NaN -> 0
+  r = r < 255.f ? r : 255.f;
+  return (uint8_t)r;
+}
+template <> __device__ __forceinline__ uint16_t store_cast<uint16_t, float>(float v) {
+  float r = rintf(v);
+  r = r > 0.f ? r : 0.f;
+  r = r < 65535.f ? r : 65535.f;
+  return (uint16_t)r;
+}
+
+}  // namespace ipa

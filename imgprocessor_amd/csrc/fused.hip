@@ -1,0 +1,133 @@
+// fused.hip — C-ABI entry points of the fused remap -> K x K filter chain
+// (kernels: fused_impl.hpp, one translation unit per K).
+#include "fused_impl.hpp"
+
+using namespace ipa;
+
+int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
+int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
+int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
+int ipa_fused_launch_k9(ipa_ctx*, const FusedCall&);
+int ipa_fused_launch_k11(ipa_ctx*, const FusedCall&);
+int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
+
+static int inv3f(const double* m, double* o) {
+  double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  if (det == 0 || det != det) return -1;
+  double id = 1.0 / det;
+  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+  o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+  o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+  return 0;
+}
+
+static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
+                        int sw, long src_pitch, const double* kernel, int kh, int kw, void* d_dst,
+                        int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                        double border_value, int cbx, int cby) {
+  IPA_REQUIRE(ctx, d_src && d_dst && kernel, "null pointer");
+  IPA_REQUIRE(ctx, sh > 0 && sw > 0 && dh > 0 && dw > 0, "empty image");
+  IPA_REQUIRE(ctx, src_pitch >= sw && dst_pitch >= dw, "pitch smaller than width");
+  IPA_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535, "n_frames must be in [1,65535]");
+  int rc = ipa_check_interp_border(ctx, interp, border_mode);
+  if (rc) return rc;
+  IPA_REQUIRE(ctx, cbx >= 0 && cbx <= IPA_BORDER_REFLECT101 && cby >= 0 && cby <= IPA_BORDER_REFLECT101,
+              "unknown filter border mode");
+  if (kh != kw || !(kh == 3 || kh == 5 || kh == 7 || kh == 9 || kh == 11))
+    IPA_UNSUPPORTED(ctx, "fused remap+filter is built for square 3/5/7/9/11 kernels (got %dx%d); "
+                         "use ipa_remap_dev + ipa_conv2d_dev", kh, kw);
+  size_t ss = ipa_dtype_size(src_dtype), ds = ipa_dtype_size(dst_dtype);
+  IPA_REQUIRE(ctx, ss && ds, "unknown dtype");
+  size_t frame_bytes = ((size_t)(sh - 1) * src_pitch + sw) * ss;
+  IPA_REQUIRE(ctx, frame_bytes < (1ull << 31), "source frame too large for 32-bit offsets");
+  int base = interp & 0xff;
+  FusedParams& p = f.p;
+  p.src = (const char*)d_src; p.dst = (char*)d_dst;
+  p.src_frame_bytes = src_frame_stride * (long)ss;
+  p.dst_frame_elems = dst_frame_stride;
+  p.src_bytes = (unsigned)frame_bytes;
+  p.sh = sh; p.sw = sw; p.spitch = (int)src_pitch;
+  p.dh = dh; p.dw = dw; p.dpitch = dst_pitch;
+  p.border = border_mode; p.q5 = (interp & IPA_INTER_Q5) ? 1 : 0;
+  p.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
+  p.lanczos = nullptr;
+  p.cval = border_value;
+  p.cbx = cbx; p.cby = cby; p.conv_cval = 0.0;
+  p.tiles_x = (unsigned)((dw + kTileW - 1) / kTileW);
+  p.tiles = p.tiles_x * (unsigned)((dh + kTileH - 1) / kTileH);
+  p.vec_out = (((uintptr_t)d_dst) % 16 == 0) && ((dst_pitch * (long)ds) % 16 == 0) &&
+              (n_frames == 1 || (dst_frame_stride * (long)ds) % 16 == 0);
+  f.src_dt = src_dtype; f.dst_dt = dst_dtype; f.interp_base = base; f.n_frames = n_frames;
+  f.kernel = kernel;
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  switch (kh) {
+    case 3: rc = ipa_fused_launch_k3(ctx, f); break;
+    case 5: rc = ipa_fused_launch_k5(ctx, f); break;
+    case 7: rc = ipa_fused_launch_k7(ctx, f); break;
+    case 9: rc = ipa_fused_launch_k9(ctx, f); break;
+    default: rc = ipa_fused_launch_k11(ctx, f); break;
+  }
+  if (rc) return rc;
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+extern "C" {
+
+int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                         long src_pitch, const float* d_mapx, const float* d_mapy, long map_pitch,
+                         const double* kernel, int kh, int kw, void* d_dst, int dst_dtype, int dh,
+                         int dw, long dst_pitch, int n_frames, long src_frame_stride,
+                         long dst_frame_stride, int interp, int border_mode, double border_value,
+                         int conv_border_x, int conv_border_y) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  FusedCall f;
+  f.coord_kind = 0;
+  f.map = MapCoord{d_mapx, d_mapy, map_pitch};
+  return fused_common(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst, dst_dtype,
+                      dh, dw, dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
+                      border_mode, border_value, conv_border_x, conv_border_y);
+}
+
+int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                             long src_pitch, const double* K, const double* dist5,
+                             const double* newK, const double* kernel, int kh, int kw, void* d_dst,
+                             int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                             long src_frame_stride, long dst_frame_stride, int interp,
+                             int border_mode, double border_value, int conv_border_x,
+                             int conv_border_y) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  FusedCall f;
+  f.coord_kind = 1;
+  UndistortCoord& c = f.und;
+  IPA_REQUIRE(ctx, inv3f(newK, c.ir) == 0, "newK is singular");
+  c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+  c.k1 = dist5[0]; c.k2 = dist5[1]; c.p1 = dist5[2]; c.p2 = dist5[3]; c.k3 = dist5[4];
+  c.affine = (c.ir[6] == 0.0 && c.ir[7] == 0.0 && c.ir[8] == 1.0) ? 1 : 0;
+  return fused_common(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst, dst_dtype,
+                      dh, dw, dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
+                      border_mode, border_value, conv_border_x, conv_border_y);
+}
+
+int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                                    long src_pitch, const double* M, const double* kernel, int kh,
+                                    int kw, void* d_dst, int dst_dtype, int dh, int dw,
+                                    long dst_pitch, int n_frames, long src_frame_stride,
+                                    long dst_frame_stride, int interp, int border_mode,
+                                    double border_value, int conv_border_x, int conv_border_y) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, M, "null matrix");
+  FusedCall f;
+  f.coord_kind = 2;
+  for (int i = 0; i < 9; i++) f.hom.m[i] = M[i];
+  return fused_common(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst, dst_dtype,
+                      dh, dw, dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
+                      border_mode, border_value, conv_border_x, conv_border_y);
+}
+
+}  // extern "C"

@@ -1,0 +1,252 @@
+// remap.hip — C-ABI entry points of the gather half of the hot path
+// (kernels + dispatch: remap_impl.hpp, one translation unit per coordinate source).
+#include <math.h>
+
+#define IPA_REMAP_API_TU
+#include "remap_impl.hpp"
+
+int ipa_remap_launch_map(ipa_ctx*, const RemapCall&, const MapCoord&, int map_vec);
+int ipa_remap_launch_undistort(ipa_ctx*, const RemapCall&, const UndistortCoord&);
+int ipa_remap_launch_homography(ipa_ctx*, const RemapCall&, const HomographyCoord&);
+
+// ---------------------------------------------------------------- host side --
+static int inv3(const double* m, double* o) {
+  double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  double A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  double det = a * A + b * B + c * C;
+  if (det == 0 || det != det) return -1;
+  double id = 1.0 / det;
+  o[0] = A * id; o[1] = -(b * i - c * h) * id; o[2] = (b * f - c * e) * id;
+  o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
+  o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
+  return 0;
+}
+
+static int make_undistort_coord(ipa_ctx* ctx, const double* K, const double* d, const double* newK,
+                                UndistortCoord* c) {
+  IPA_REQUIRE(ctx, K && d && newK, "K, dist5 and newK must be given");
+  IPA_REQUIRE(ctx, inv3(newK, c->ir) == 0, "newK is singular");
+  c->fx = K[0]; c->fy = K[4]; c->cx = K[2]; c->cy = K[5];
+  c->k1 = d[0]; c->k2 = d[1]; c->p1 = d[2]; c->p2 = d[3]; c->k3 = d[4];
+  c->affine = (c->ir[6] == 0.0 && c->ir[7] == 0.0 && c->ir[8] == 1.0) ? 1 : 0;
+  return IPA_OK;
+}
+
+// OpenCV interpolateLanczos4 evaluated at k/32, k = 0..31 (the rows of cv2's
+// Lanczos4 interpolation table)
+static void lanczos4_row(float x, float* coeffs) {
+  static const double s45 = 0.70710678118654752440084436210485;
+  static const double cs[][2] = {{1, 0},  {-s45, -s45}, {0, 1},  {s45, -s45},
+                                 {-1, 0}, {s45, s45},   {0, -1}, {-s45, s45}};
+  if (x < 1.1920929e-07f) {
+    for (int i = 0; i < 8; i++) coeffs[i] = 0;
+    coeffs[3] = 1;
+    return;
+  }
+  float sum = 0;
+  double y0 = -(x + 3) * M_PI * 0.25, s0 = sin(y0), c0 = cos(y0);
+  for (int i = 0; i < 8; i++) {
+    double y = -(x + 3 - i) * M_PI * 0.25;
+    coeffs[i] = (float)((cs[i][0] * s0 + cs[i][1] * c0) / (y * y));
+    sum += coeffs[i];
+  }
+  sum = 1.f / sum;
+  for (int i = 0; i < 8; i++) coeffs[i] *= sum;
+}
+
+static std::mutex g_lz_mu;
+static float* g_lanczos_dev[64] = {nullptr};
+
+int ipa_lanczos_table(ipa_ctx* ctx, const float** out) {
+  std::lock_guard<std::mutex> lk(g_lz_mu);
+  int dev = ctx->device;
+  IPA_REQUIRE(ctx, dev >= 0 && dev < 64, "device id out of range");
+  if (!g_lanczos_dev[dev]) {
+    float tab[32 * 8];
+    for (int k = 0; k < 32; k++) lanczos4_row((float)k / 32.f, tab + k * 8);
+    float* d = nullptr;
+    IPA_HIP(ctx, hipSetDevice(dev));
+    IPA_HIP(ctx, hipMalloc((void**)&d, sizeof(tab)));
+    IPA_HIP(ctx, hipMemcpy(d, tab, sizeof(tab), hipMemcpyHostToDevice));
+    g_lanczos_dev[dev] = d;
+  }
+  *out = g_lanczos_dev[dev];
+  return IPA_OK;
+}
+
+int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border) {
+  int base = interp & 0xff;
+  IPA_REQUIRE(ctx, (interp & ~(0xff | IPA_INTER_Q5)) == 0, "unknown interpolation flags 0x%x",
+              interp);
+  IPA_REQUIRE(ctx,
+              base == IPA_INTER_NEAREST || base == IPA_INTER_LINEAR ||
+                  base == IPA_INTER_CUBIC_CV || base == IPA_INTER_LANCZOS4 ||
+                  base == IPA_INTER_CUBIC_KEYS,
+              "unknown interpolation %d", base);
+  IPA_REQUIRE(ctx, border >= IPA_BORDER_CONSTANT && border <= IPA_BORDER_REFLECT101,
+              "unknown border mode %d", border);
+  return IPA_OK;
+}
+
+// host-pointer staging shared by the three remap flavours
+struct Staged {
+  char* d_src; char* d_dst; float* d_mx; float* d_my;
+  size_t src_bytes, dst_bytes, map_bytes;
+};
+
+static int stage_in(ipa_ctx* ctx, const void* src, int src_dt, int sh, int sw, int dst_dt, int dh,
+                    int dw, int n_frames, const float* mapx, const float* mapy, Staged* st) {
+  IPA_REQUIRE(ctx, src, "null source");
+  IPA_REQUIRE(ctx, sh > 0 && sw > 0 && dh > 0 && dw > 0 && n_frames >= 1, "bad shape");
+  size_t ss = ipa_dtype_size(src_dt), ds = ipa_dtype_size(dst_dt);
+  IPA_REQUIRE(ctx, ss && ds, "unknown dtype");
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  st->src_bytes = (size_t)sh * sw * ss * n_frames;
+  st->dst_bytes = (size_t)dh * dw * ds * n_frames;
+  st->map_bytes = mapx ? (size_t)dh * dw * 4 : 0;
+  size_t total = up(st->src_bytes) + up(st->dst_bytes) + 2 * up(st->map_bytes);
+  int rc = ipa_ws_reserve(ctx, total);
+  if (rc) return rc;
+  char* b = (char*)ctx->ws;
+  st->d_src = b; b += up(st->src_bytes);
+  st->d_dst = b; b += up(st->dst_bytes);
+  st->d_mx = (float*)b; b += up(st->map_bytes);
+  st->d_my = (float*)b;
+  IPA_HIP(ctx, hipMemcpyAsync(st->d_src, src, st->src_bytes, hipMemcpyHostToDevice, ctx->stream));
+  if (mapx) {
+    IPA_HIP(ctx, hipMemcpyAsync(st->d_mx, mapx, st->map_bytes, hipMemcpyHostToDevice, ctx->stream));
+    IPA_HIP(ctx, hipMemcpyAsync(st->d_my, mapy, st->map_bytes, hipMemcpyHostToDevice, ctx->stream));
+  }
+  return IPA_OK;
+}
+
+static int stage_out(ipa_ctx* ctx, void* dst, const Staged& st) {
+  IPA_HIP(ctx, hipMemcpyAsync(dst, st.d_dst, st.dst_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return IPA_OK;
+}
+
+extern "C" {
+
+int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dist5,
+                                const double* newK, int h, int w, float* d_mapx, float* d_mapy,
+                                long map_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_mapx && d_mapy && h > 0 && w > 0 && map_pitch >= w, "bad map arguments");
+  UndistortCoord c;
+  int rc = make_undistort_coord(ctx, K, dist5, newK, &c);
+  if (rc) return rc;
+  int vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, 16) && aligned_rows(d_mapy, map_pitch, 0, 1, 4, 16);
+  dim3 grid((w + 255) / 256, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(build_map_kernel, grid, block, 0, ctx->stream, c, h, w, d_mapx, d_mapy,
+                     map_pitch, vec);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_build_undistort_map(ipa_ctx* ctx, const double* K, const double* dist5,
+                            const double* newK, int h, int w, float* mapx, float* mapy) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, mapx && mapy && h > 0 && w > 0, "bad map arguments");
+  size_t mb = ((size_t)h * w * 4 + 255) & ~(size_t)255;
+  int rc = ipa_ws_reserve(ctx, 2 * mb);
+  if (rc) return rc;
+  float* dx = (float*)ctx->ws;
+  float* dy = (float*)((char*)ctx->ws + mb);
+  rc = ipa_build_undistort_map_dev(ctx, K, dist5, newK, h, w, dx, dy, w);
+  if (rc) return rc;
+  IPA_HIP(ctx, hipMemcpyAsync(mapx, dx, (size_t)h * w * 4, hipMemcpyDeviceToHost, ctx->stream));
+  IPA_HIP(ctx, hipMemcpyAsync(mapy, dy, (size_t)h * w * 4, hipMemcpyDeviceToHost, ctx->stream));
+  IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return IPA_OK;
+}
+
+int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw, long src_pitch,
+                  const float* d_mapx, const float* d_mapy, long map_pitch, void* d_dst,
+                  int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                  long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                  double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  MapCoord c{d_mapx, d_mapy, map_pitch};
+  int map_vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, 16) && aligned_rows(d_mapy, map_pitch, 0, 1, 4, 16);
+  RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
+              n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
+  return ipa_remap_launch_map(ctx, a, c, map_vec);
+}
+
+int ipa_undistort_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                      long src_pitch, const double* K, const double* dist5, const double* newK,
+                      void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                      long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                      double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  UndistortCoord c;
+  int rc = make_undistort_coord(ctx, K, dist5, newK, &c);
+  if (rc) return rc;
+  RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
+              n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
+  return ipa_remap_launch_undistort(ctx, a, c);
+}
+
+int ipa_warp_perspective_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                             long src_pitch, const double* M, void* d_dst, int dst_dtype, int dh,
+                             int dw, long dst_pitch, int n_frames, long src_frame_stride,
+                             long dst_frame_stride, int interp, int border_mode,
+                             double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, M, "null matrix");
+  HomographyCoord c;
+  for (int i = 0; i < 9; i++) c.m[i] = M[i];
+  RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
+              n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
+  return ipa_remap_launch_homography(ctx, a, c);
+}
+
+int ipa_remap(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw, const float* mapx,
+              const float* mapy, void* dst, int dst_dtype, int dh, int dw, int n_frames,
+              int interp, int border_mode, double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, mapx && mapy && dst, "null pointer");
+  Staged st;
+  int rc = stage_in(ctx, src, src_dtype, sh, sw, dst_dtype, dh, dw, n_frames, mapx, mapy, &st);
+  if (rc) return rc;
+  rc = ipa_remap_dev(ctx, st.d_src, src_dtype, sh, sw, sw, st.d_mx, st.d_my, dw, st.d_dst,
+                     dst_dtype, dh, dw, dw, n_frames, (long)sh * sw, (long)dh * dw, interp,
+                     border_mode, border_value);
+  if (rc) return rc;
+  return stage_out(ctx, dst, st);
+}
+
+int ipa_undistort(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw, const double* K,
+                  const double* dist5, const double* newK, void* dst, int dst_dtype, int dh,
+                  int dw, int n_frames, int interp, int border_mode, double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, dst, "null pointer");
+  Staged st;
+  int rc = stage_in(ctx, src, src_dtype, sh, sw, dst_dtype, dh, dw, n_frames, nullptr, nullptr, &st);
+  if (rc) return rc;
+  rc = ipa_undistort_dev(ctx, st.d_src, src_dtype, sh, sw, sw, K, dist5, newK, st.d_dst, dst_dtype,
+                         dh, dw, dw, n_frames, (long)sh * sw, (long)dh * dw, interp, border_mode,
+                         border_value);
+  if (rc) return rc;
+  return stage_out(ctx, dst, st);
+}
+
+int ipa_warp_perspective(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw,
+                         const double* M, void* dst, int dst_dtype, int dh, int dw, int n_frames,
+                         int interp, int border_mode, double border_value) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, dst, "null pointer");
+  Staged st;
+  int rc = stage_in(ctx, src, src_dtype, sh, sw, dst_dtype, dh, dw, n_frames, nullptr, nullptr, &st);
+  if (rc) return rc;
+  rc = ipa_warp_perspective_dev(ctx, st.d_src, src_dtype, sh, sw, sw, M, st.d_dst, dst_dtype, dh,
+                                dw, dw, n_frames, (long)sh * sw, (long)dh * dw, interp,
+                                border_mode, border_value);
+  if (rc) return rc;
+  return stage_out(ctx, dst, st);
+}
+
+}  // extern "C"

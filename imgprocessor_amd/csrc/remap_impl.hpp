@@ -1,0 +1,257 @@
+// remap_impl.hpp — the gather half of the hot path on gfx950:
+//   ipa_build_undistort_map*   (cv2.initUndistortRectifyMap, LensDistortion.py:355-357)
+//   ipa_remap*                 (cv2.remap,               LensDistortion.py:323-326)
+//   ipa_undistort*             (the two above fused: no map arrays in HBM)
+//   ipa_warp_perspective*      (cv2.warpPerspective,     PerspectiveCorrection.py:377-378,401-405)
+//
+// Kernel shape: one wave64 owns 256 consecutive output pixels of one row
+// (4 px per lane -> 16-byte map loads and 16-byte stores, fully coalesced);
+// a 256-thread workgroup owns a 256 x 4 output tile; tile ids are remapped so
+// every XCD walks a contiguous band of the image (its L2 then holds the
+// source rows neighbouring tiles share).  Source taps are gathered through a
+// raw buffer descriptor per frame.  HBM-bound: 16 B/px map-based, 8 B/px
+// analytic (f32).
+#pragma once
+
+#include <math.h>
+
+#include "common.hpp"
+#include "sampler.hpp"
+
+namespace ipa {
+
+struct RemapParams {
+  const char* src;
+  char* dst;
+  long src_frame_bytes;  // byte distance between consecutive source frames
+  long dst_frame_elems;
+  unsigned src_bytes;    // bytes of one source frame (descriptor range)
+  int sh, sw, spitch;
+  int dh, dw;
+  long dpitch;
+  int border, q5;
+  float cubic_a;
+  const float* lanczos;
+  double cval;
+  unsigned tiles_x, tiles;
+  int dst_vec, map_vec;
+};
+
+template <typename Coord>
+__device__ __forceinline__ void coords4(const Coord& c, int u0, int v, int n, int /*vec*/,
+                                        typename Coord::coord_t (&sx)[4],
+                                        typename Coord::coord_t (&sy)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    sx[k] = 0;
+    sy[k] = 0;
+    if (k < n) c.get(u0 + k, v, sx[k], sy[k]);
+  }
+}
+
+template <>
+__device__ __forceinline__ void coords4<MapCoord>(const MapCoord& c, int u0, int v, int n, int vec,
+                                                  float (&sx)[4], float (&sy)[4]) {
+  long o = (long)v * c.pitch + u0;
+  if (vec && n == 4) {
+    float4 a = *reinterpret_cast<const float4*>(c.mx + o);
+    float4 b = *reinterpret_cast<const float4*>(c.my + o);
+    sx[0] = a.x; sx[1] = a.y; sx[2] = a.z; sx[3] = a.w;
+    sy[0] = b.x; sy[1] = b.y; sy[2] = b.z; sy[3] = b.w;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      sx[k] = 0;
+      sy[k] = 0;
+      if (k < n) {
+        sx[k] = c.mx[o + k];
+        sy[k] = c.my[o + k];
+      }
+    }
+  }
+}
+
+template <typename DT>
+__device__ __forceinline__ void store4(DT* row, int x0, const DT (&v)[4], int n, int vec) {
+  if (vec && n == 4) {
+    if constexpr (sizeof(DT) == 4) {
+      *reinterpret_cast<float4*>(row + x0) = *reinterpret_cast<const float4*>(v);
+    } else if constexpr (sizeof(DT) == 8) {
+      reinterpret_cast<double2*>(row + x0)[0] = reinterpret_cast<const double2*>(v)[0];
+      reinterpret_cast<double2*>(row + x0)[1] = reinterpret_cast<const double2*>(v)[1];
+    } else if constexpr (sizeof(DT) == 2) {
+      *reinterpret_cast<uint2*>(row + x0) = *reinterpret_cast<const uint2*>(v);
+    } else {
+      *reinterpret_cast<unsigned*>(row + x0) = *reinterpret_cast<const unsigned*>(v);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (k < n) row[x0 + k] = v[k];
+  }
+}
+
+template <typename ST, typename DT, int INTERP, typename Coord, bool FIXED>
+__global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) {
+  using CT = typename compute_of<ST>::type;
+  unsigned t = xcd_swizzle(blockIdx.x, p.tiles);
+  unsigned tyi = t / p.tiles_x, txi = t - tyi * p.tiles_x;
+  int x0 = (int)((txi * 64 + threadIdx.x) * 4);
+  int y = (int)(tyi * 4 + threadIdx.y);
+  if (y >= p.dh || x0 >= p.dw) return;
+  int n = p.dw - x0 < 4 ? p.dw - x0 : 4;
+  unsigned frame = blockIdx.y;
+
+  SrcView s;
+  s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
+  s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
+  s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a; s.lanczos = p.lanczos;
+
+  typename Coord::coord_t sx[4], sy[4];
+  coords4<Coord>(coord, x0, y, n, p.map_vec, sx, sy);
+
+  alignas(16) DT out[4];
+  if constexpr (FIXED) {
+    double r = rint(p.cval);
+    uint8_t cv8 = (uint8_t)(r > 0 ? (r < 255 ? r : 255) : 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = k < n ? sample_u8_fixed(s, sx[k], sy[k], cv8) : 0;
+  } else {
+    CT cval = (CT)p.cval;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      out[k] = k < n ? store_cast<DT, CT>(sample<ST, INTERP>(s, sx[k], sy[k], cval)) : (DT)0;
+  }
+  DT* row = reinterpret_cast<DT*>(p.dst) + (long)frame * p.dst_frame_elems + (long)y * p.dpitch;
+  store4<DT>(row, x0, out, n, p.dst_vec);
+}
+
+#ifdef IPA_REMAP_API_TU  // only remap.hip carries the map builder
+__global__ void __launch_bounds__(256)
+build_map_kernel(UndistortCoord c, int h, int w, float* mapx, float* mapy, long pitch, int vec) {
+  int x0 = (int)((blockIdx.x * 64 + threadIdx.x) * 4);
+  int y = (int)(blockIdx.y * 4 + threadIdx.y);
+  if (y >= h || x0 >= w) return;
+  int n = w - x0 < 4 ? w - x0 : 4;
+  alignas(16) float sx[4], sy[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    sx[k] = 0;
+    sy[k] = 0;
+    if (k < n) c.get(x0 + k, y, sx[k], sy[k]);
+  }
+  store4<float>(mapx + (long)y * pitch, x0, sx, n, vec);
+  store4<float>(mapy + (long)y * pitch, x0, sy, n, vec);
+}
+
+#endif
+
+}  // namespace ipa
+
+
+
+using namespace ipa;
+
+int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
+int ipa_lanczos_table(ipa_ctx* ctx, const float** out);               // remap.hip
+
+struct RemapCall {
+  const void* src; int src_dt; int sh, sw; long spitch;
+  void* dst; int dst_dt; int dh, dw; long dpitch;
+  int n_frames; long src_fs, dst_fs;
+  int interp, border; double cval;
+};
+
+template <typename ST, typename DT, typename Coord, bool FIXED>
+static void launch_interp(ipa_ctx* ctx, const RemapParams& p, const Coord& c, int base, dim3 grid) {
+  dim3 block(64, 4);
+  switch (base) {
+    case IPA_INTER_NEAREST:
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kNearest, Coord, false>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+    case IPA_INTER_LINEAR:
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kLinear, Coord, FIXED>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+    case IPA_INTER_CUBIC_CV:
+    case IPA_INTER_CUBIC_KEYS:
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kCubic, Coord, false>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+    default:
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kLanczos4, Coord, false>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+  }
+}
+
+static inline bool aligned_rows(const void* base, long pitch_elems, long frame_elems, int n_frames,
+                         size_t elem, size_t vec_bytes) {
+  if (((uintptr_t)base) % vec_bytes) return false;
+  if ((pitch_elems * (long)elem) % (long)vec_bytes) return false;
+  if (n_frames > 1 && (frame_elems * (long)elem) % (long)vec_bytes) return false;
+  return true;
+}
+
+template <typename Coord>
+static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, int map_vec) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, a.src && a.dst, "null image pointer");
+  IPA_REQUIRE(ctx, a.sh > 0 && a.sw > 0 && a.dh > 0 && a.dw > 0, "empty image (%dx%d -> %dx%d)",
+              a.sh, a.sw, a.dh, a.dw);
+  IPA_REQUIRE(ctx, a.spitch >= a.sw && a.dpitch >= a.dw, "pitch smaller than width");
+  IPA_REQUIRE(ctx, a.n_frames >= 1 && a.n_frames <= 65535, "n_frames must be in [1,65535]");
+  int rc = ipa_check_interp_border(ctx, a.interp, a.border);
+  if (rc) return rc;
+  size_t ss = ipa_dtype_size(a.src_dt), ds = ipa_dtype_size(a.dst_dt);
+  IPA_REQUIRE(ctx, ss && ds, "unknown dtype");
+  size_t frame_bytes = ((size_t)(a.sh - 1) * a.spitch + a.sw) * ss;
+  IPA_REQUIRE(ctx, frame_bytes < (1ull << 31), "source frame too large for 32-bit offsets");
+  int base = a.interp & 0xff;
+
+  RemapParams p;
+  p.src = (const char*)a.src;
+  p.dst = (char*)a.dst;
+  p.src_frame_bytes = a.src_fs * (long)ss;
+  p.dst_frame_elems = a.dst_fs;
+  p.src_bytes = (unsigned)frame_bytes;
+  p.sh = a.sh; p.sw = a.sw; p.spitch = (int)a.spitch;
+  p.dh = a.dh; p.dw = a.dw; p.dpitch = a.dpitch;
+  p.border = a.border;
+  p.q5 = (a.interp & IPA_INTER_Q5) ? 1 : 0;
+  p.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
+  p.lanczos = nullptr;
+  if (base == IPA_INTER_LANCZOS4) {
+    rc = ipa_lanczos_table(ctx, &p.lanczos);
+    if (rc) return rc;
+  }
+  p.cval = a.cval;
+  p.tiles_x = (unsigned)((a.dw + 255) / 256);
+  unsigned tiles_y = (unsigned)((a.dh + 3) / 4);
+  p.tiles = p.tiles_x * tiles_y;
+  p.dst_vec = aligned_rows(a.dst, a.dpitch, a.dst_fs, a.n_frames, ds, 4 * ds > 16 ? 16 : 4 * ds);
+  p.map_vec = map_vec;
+  dim3 grid(p.tiles, (unsigned)a.n_frames);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+
+  int s = a.src_dt, d = a.dst_dt;
+  if (s == IPA_F32 && d == IPA_F32) {
+    launch_interp<float, float, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_F64 && d == IPA_F64) {
+    launch_interp<double, double, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_U16 && d == IPA_F32) {
+    launch_interp<uint16_t, float, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_U16 && d == IPA_U16) {
+    launch_interp<uint16_t, uint16_t, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_U8 && d == IPA_F32) {
+    launch_interp<uint8_t, float, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_U8 && d == IPA_U8) {
+    launch_interp<uint8_t, uint8_t, Coord, true>(ctx, p, coord, base, grid);
+  } else {
+    IPA_UNSUPPORTED(ctx, "remap: src dtype %d -> dst dtype %d not supported", s, d);
+  }
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+

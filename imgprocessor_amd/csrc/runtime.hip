@@ -1,0 +1,258 @@
+// runtime.hip — context / memory / event half of the C ABI (include/imgproc_hip.h).
+// One context per device: a dedicated non-blocking HIP stream, a grow-only
+// staging workspace for the host-pointer entry points and a small table arena.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+static thread_local std::string g_tls_error;
+
+void ipa_set_error(ipa_ctx* ctx, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->last_error = buf;
+  g_tls_error = buf;
+}
+
+extern "C" {
+
+int ipa_version(void) { return IPA_VERSION; }
+
+const char* ipa_status_string(int s) {
+  switch (s) {
+    case IPA_OK: return "ok";
+    case IPA_ERR_BAD_ARG: return "bad argument";
+    case IPA_ERR_UNSUPPORTED: return "unsupported dtype/mode";
+    case IPA_ERR_HIP: return "HIP runtime error";
+    case IPA_ERR_OOM: return "out of device memory";
+    case IPA_ERR_NO_DEVICE: return "no usable gfx950 device";
+  }
+  return "unknown status";
+}
+
+const char* ipa_last_error(const ipa_ctx* ctx) {
+  return ctx ? ctx->last_error.c_str() : g_tls_error.c_str();
+}
+
+int ipa_device_count(int* count) {
+  if (!count) return IPA_ERR_BAD_ARG;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    *count = 0;
+    ipa_set_error(nullptr, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    return IPA_ERR_NO_DEVICE;
+  }
+  *count = n;
+  return IPA_OK;
+}
+
+int ipa_ctx_create(int device_id, ipa_ctx** out) {
+  if (!out) return IPA_ERR_BAD_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+    ipa_set_error(nullptr, "no HIP device visible (this library has no CPU fallback)");
+    return IPA_ERR_NO_DEVICE;
+  }
+  if (device_id < 0 || device_id >= n) {
+    ipa_set_error(nullptr, "device_id %d out of range [0,%d)", device_id, n);
+    return IPA_ERR_BAD_ARG;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) {
+    ipa_set_error(nullptr, "hipGetDeviceProperties failed");
+    return IPA_ERR_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    ipa_set_error(nullptr, "device %d is %s; this library carries gfx950 code objects only",
+                  device_id, prop.gcnArchName);
+    return IPA_ERR_NO_DEVICE;
+  }
+  ipa_ctx* c = new ipa_ctx();
+  c->device = device_id;
+  c->cu_count = prop.multiProcessorCount;
+  if (hipSetDevice(device_id) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    ipa_set_error(nullptr, "stream creation failed on device %d", device_id);
+    delete c;
+    return IPA_ERR_HIP;
+  }
+  *out = c;
+  return IPA_OK;
+}
+
+int ipa_ctx_destroy(ipa_ctx* c) {
+  if (!c) return IPA_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  if (c->ws) (void)hipFree(c->ws);
+  if (c->tab) (void)hipFree(c->tab);
+  if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return IPA_OK;
+}
+
+int ipa_ctx_synchronize(ipa_ctx* c) {
+  if (!c) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  return IPA_OK;
+}
+
+int ipa_ctx_device_info(ipa_ctx* c, char* name, size_t name_len, int* cu_count,
+                        size_t* total_mem) {
+  if (!c) return IPA_ERR_BAD_ARG;
+  hipDeviceProp_t prop;
+  IPA_HIP(c, hipGetDeviceProperties(&prop, c->device));
+  if (name && name_len) {
+    snprintf(name, name_len, "%s (%s)", prop.name, prop.gcnArchName);
+  }
+  if (cu_count) *cu_count = prop.multiProcessorCount;
+  if (total_mem) *total_mem = prop.totalGlobalMem;
+  return IPA_OK;
+}
+
+int ipa_malloc(ipa_ctx* c, size_t bytes, void** dptr) {
+  if (!c || !dptr) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMalloc(dptr, bytes ? bytes : 1));
+  return IPA_OK;
+}
+
+int ipa_free(ipa_ctx* c, void* dptr) {
+  if (!c) return IPA_ERR_BAD_ARG;
+  if (!dptr) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  IPA_HIP(c, hipFree(dptr));
+  return IPA_OK;
+}
+
+int ipa_host_alloc(ipa_ctx* c, size_t bytes, void** hptr) {
+  if (!c || !hptr) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return IPA_OK;
+}
+
+int ipa_host_free(ipa_ctx* c, void* hptr) {
+  if (!c) return IPA_ERR_BAD_ARG;
+  if (!hptr) return IPA_OK;
+  IPA_HIP(c, hipHostFree(hptr));
+  return IPA_OK;
+}
+
+int ipa_memcpy_h2d(ipa_ctx* c, void* d, const void* h, size_t bytes) {
+  if (!c || (bytes && (!d || !h))) return IPA_ERR_BAD_ARG;
+  if (!bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, c->stream));
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  return IPA_OK;
+}
+
+int ipa_memcpy_d2h(ipa_ctx* c, void* h, const void* d, size_t bytes) {
+  if (!c || (bytes && (!d || !h))) return IPA_ERR_BAD_ARG;
+  if (!bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  return IPA_OK;
+}
+
+int ipa_memcpy_d2d(ipa_ctx* c, void* dst, const void* src, size_t bytes) {
+  if (!c || (bytes && (!dst || !src))) return IPA_ERR_BAD_ARG;
+  if (!bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return IPA_OK;
+}
+
+int ipa_memset(ipa_ctx* c, void* d, int value, size_t bytes) {
+  if (!c || (bytes && !d)) return IPA_ERR_BAD_ARG;
+  if (!bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMemsetAsync(d, value, bytes, c->stream));
+  return IPA_OK;
+}
+
+int ipa_event_create(ipa_ctx* c, ipa_event** ev) {
+  if (!c || !ev) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipSetDevice(c->device));
+  ipa_event* e = new ipa_event();
+  hipError_t r = hipEventCreate(&e->ev);
+  if (r != hipSuccess) {
+    delete e;
+    ipa_set_error(c, "hipEventCreate: %s", hipGetErrorString(r));
+    return IPA_ERR_HIP;
+  }
+  *ev = e;
+  return IPA_OK;
+}
+
+int ipa_event_destroy(ipa_ctx* c, ipa_event* ev) {
+  if (!c) return IPA_ERR_BAD_ARG;
+  if (!ev) return IPA_OK;
+  (void)hipEventDestroy(ev->ev);
+  delete ev;
+  return IPA_OK;
+}
+
+int ipa_event_record(ipa_ctx* c, ipa_event* ev) {
+  if (!c || !ev) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipEventRecord(ev->ev, c->stream));
+  return IPA_OK;
+}
+
+int ipa_event_elapsed_ms(ipa_ctx* c, ipa_event* a, ipa_event* b, float* ms) {
+  if (!c || !a || !b || !ms) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipEventSynchronize(b->ev));
+  IPA_HIP(c, hipEventElapsedTime(ms, a->ev, b->ev));
+  return IPA_OK;
+}
+
+}  // extern "C"
+
+int ipa_ws_reserve(ipa_ctx* c, size_t bytes) {
+  if (c->ws_bytes >= bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->ws) {
+    IPA_HIP(c, hipFree(c->ws));
+    c->ws = nullptr;
+    c->ws_bytes = 0;
+  }
+  size_t want = bytes + (bytes >> 2) + (1u << 20);
+  IPA_HIP(c, hipMalloc(&c->ws, want));
+  c->ws_bytes = want;
+  return IPA_OK;
+}
+
+// Upload a small host table through pinned staging.  The previous user of the
+// arena may still be running, and the pinned buffer may still be read by an
+// earlier async copy, so drain the stream first: tables are only used by the
+// secondary entry points (IDW, Lanczos), never by the per-frame hot loop.
+int ipa_tab_upload(ipa_ctx* c, const void* host, size_t bytes, void** d) {
+  IPA_HIP(c, hipSetDevice(c->device));
+  if (c->tab_bytes < bytes) {
+    IPA_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->tab) IPA_HIP(c, hipFree(c->tab));
+    if (c->tab_pinned) IPA_HIP(c, hipHostFree(c->tab_pinned));
+    c->tab = nullptr;
+    c->tab_pinned = nullptr;
+    c->tab_bytes = 0;
+    size_t want = bytes < (64u << 10) ? (64u << 10) : bytes * 2;
+    IPA_HIP(c, hipMalloc(&c->tab, want));
+    IPA_HIP(c, hipHostMalloc(&c->tab_pinned, want, hipHostMallocDefault));
+    c->tab_bytes = want;
+  }
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  memcpy(c->tab_pinned, host, bytes);
+  IPA_HIP(c, hipMemcpyAsync(c->tab, c->tab_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+  *d = c->tab;
+  return IPA_OK;
+}

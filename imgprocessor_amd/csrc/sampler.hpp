@@ -1,0 +1,321 @@
+// sampler.hpp — device-side source sampling for the remap family.
+//
+// A sample is:  coordinate -> (first tap index, per-axis weights) -> NT x NT
+// taps fetched through a raw buffer descriptor (hardware range check on the
+// frame, 32-bit byte offsets) -> separable weighted sum with fma chains.
+// Interior footprints use one wide buffer load per tap row (dwordx2 for
+// bilinear f32, dwordx4 for bicubic f32 ...); footprints that touch the image
+// edge resolve every tap through the border mode.
+//
+// Semantics restated from (reference = /root/reference):
+//   camera/LensDistortion.py:323-326   cv2.remap INTER_LINEAR, BORDER_CONSTANT
+//   camera/PerspectiveCorrection.py:377-378, 401-405  INTER_CUBIC / INTER_LANCZOS4
+// with cv2's interpolation kernels as published in OpenCV imgwarp.cpp
+// (interpolateCubic, interpolateLanczos4, INTER_BITS = 5) and the exact-
+// coordinate forms that scipy.ndimage.map_coordinates(order=1) and
+// skimage.transform.warp(order=1/3) implement.
+#pragma once
+
+#include "common.hpp"
+
+namespace ipa {
+
+enum : int { kNearest = 0, kLinear = 1, kCubic = 2, kLanczos4 = 4 };
+
+template <int INTERP> struct ntaps { static constexpr int value = 4; };
+template <> struct ntaps<kNearest> { static constexpr int value = 1; };
+template <> struct ntaps<kLinear> { static constexpr int value = 2; };
+template <> struct ntaps<kLanczos4> { static constexpr int value = 8; };
+
+// read-only view of one source frame
+struct SrcView {
+  __amdgpu_buffer_rsrc_t rsrc;
+  int h, w, pitch;        // pitch in elements
+  int border;             // ipa_border
+  int q5;                 // 1: cv2-style 1/32-px coordinate rounding
+  float cubic_a;          // Keys parameter (-0.75 cv2, -0.5 skimage)
+  const float* lanczos;   // [32][8] table (device), only for kLanczos4
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  // 0x00020000: raw buffer, DST_SEL identity / 32-bit data format for gfx9-family MUBUF
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// ------------------------------------------------------------- tap loads --
+// NOTE: never __builtin_bit_cast a vector ELEMENT expression (r[1]): clang 22
+// (ROCm 7.2) reads element 0 for every index.  Pass the element by value.
+__device__ __forceinline__ float u2f(unsigned u) { return __uint_as_float(u); }
+__device__ __forceinline__ double u2d(unsigned lo, unsigned hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+template <typename ST, typename CT> struct TapLoad;
+
+template <> struct TapLoad<float, float> {
+  static __device__ __forceinline__ float one(const SrcView& s, int e) {
+    return u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, e << 2, 0, 0));
+  }
+  template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, float (&v)[N]) {
+    if constexpr (N == 1) {
+      v[0] = one(s, e);
+    } else if constexpr (N == 2) {
+      auto r = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, e << 2, 0, 0);
+      v[0] = u2f(r[0]);
+      v[1] = u2f(r[1]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k += 4) {
+        auto r = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (e + k) << 2, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[k + j] = u2f(r[j]);
+      }
+    }
+  }
+};
+
+template <> struct TapLoad<double, double> {
+  static __device__ __forceinline__ double one(const SrcView& s, int e) {
+    auto r = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, e << 3, 0, 0);
+    return u2d(r[0], r[1]);
+  }
+  template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, double (&v)[N]) {
+    if constexpr (N == 1) {
+      v[0] = one(s, e);
+    } else {
+#pragma unroll
+      for (int k = 0; k < N; k += 2) {
+        auto r = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (e + k) << 3, 0, 0);
+        v[k] = u2d(r[0], r[1]);
+        v[k + 1] = u2d(r[2], r[3]);
+      }
+    }
+  }
+};
+
+template <> struct TapLoad<uint8_t, float> {
+  static __device__ __forceinline__ float one(const SrcView& s, int e) {
+    return (float)__builtin_amdgcn_raw_buffer_load_b8(s.rsrc, e, 0, 0);
+  }
+  template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = one(s, e + k);
+  }
+};
+
+template <> struct TapLoad<uint16_t, float> {
+  static __device__ __forceinline__ float one(const SrcView& s, int e) {
+    return (float)__builtin_amdgcn_raw_buffer_load_b16(s.rsrc, e << 1, 0, 0);
+  }
+  template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, float (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = one(s, e + k);
+  }
+};
+
+// --------------------------------------------------------------- weights --
+__device__ __forceinline__ float ipa_floor(float x) { return floorf(x); }
+__device__ __forceinline__ double ipa_floor(double x) { return floor(x); }
+__device__ __forceinline__ float ipa_rint(float x) { return rintf(x); }
+__device__ __forceinline__ double ipa_rint(double x) { return rint(x); }
+
+// OpenCV interpolateCubic generalised over A
+template <typename CT> __device__ __forceinline__ void cubic_weights(CT t, CT A, CT (&w)[4]) {
+  CT t1 = t + (CT)1, u = (CT)1 - t;
+  w[0] = ((A * t1 - (CT)5 * A) * t1 + (CT)8 * A) * t1 - (CT)4 * A;
+  w[1] = ((A + (CT)2) * t - (A + (CT)3)) * t * t + (CT)1;
+  w[2] = ((A + (CT)2) * u - (A + (CT)3)) * u * u + (CT)1;
+  w[3] = (CT)1 - w[0] - w[1] - w[2];
+}
+
+// coordinate (float: map / undistort; double: homography) -> first tap + weights
+template <int INTERP, typename CT, typename C>
+__device__ __forceinline__ void axis_split(const SrcView& s, C c, int& i0,
+                                           CT (&w)[ntaps<INTERP>::value]) {
+  int ip;
+  CT t;
+  int k = 0;
+  if (INTERP == kLanczos4 || s.q5) {
+    int qi = (int)ipa_rint(c * (C)32);  // cvRound(coordinate * INTER_TAB_SIZE)
+    ip = qi >> 5;
+    k = qi & 31;
+    t = (CT)k * (CT)0.03125;
+  } else {
+    C fl = ipa_floor(c);
+    ip = (int)fl;
+    // fraction in the wider of (coordinate, compute) types: c - floor(c) is not
+    // exact in float for c in (-1, 0)
+    if constexpr (sizeof(CT) > sizeof(C)) t = (CT)c - (CT)fl;
+    else t = (CT)(c - fl);
+  }
+  if constexpr (INTERP == kNearest) {
+    i0 = (int)ipa_rint(c);
+    w[0] = (CT)1;
+  } else if constexpr (INTERP == kLinear) {
+    i0 = ip;
+    w[0] = (CT)1 - t;
+    w[1] = t;
+  } else if constexpr (INTERP == kCubic) {
+    i0 = ip - 1;
+    cubic_weights<CT>(t, (CT)s.cubic_a, w);
+  } else {
+    i0 = ip - 3;
+    const float4* row = reinterpret_cast<const float4*>(s.lanczos + k * 8);
+    float4 a = row[0], b = row[1];
+    w[0] = (CT)a.x; w[1] = (CT)a.y; w[2] = (CT)a.z; w[3] = (CT)a.w;
+    w[4] = (CT)b.x; w[5] = (CT)b.y; w[6] = (CT)b.z; w[7] = (CT)b.w;
+  }
+}
+
+constexpr float kCoordLimit = 1.0e6f;  // beyond this a coordinate is "far outside"
+
+// One interpolated sample in the compute type CT (float, or double for f64 images)
+template <typename ST, int INTERP, typename C>
+__device__ __forceinline__ typename compute_of<ST>::type sample(const SrcView& s, C sx, C sy,
+                                                                typename compute_of<ST>::type cval) {
+  using CT = typename compute_of<ST>::type;
+  constexpr int NT = ntaps<INTERP>::value;
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cval;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  int ix0, iy0;
+  CT wx[NT], wy[NT];
+  axis_split<INTERP, CT, C>(s, sx, ix0, wx);
+  axis_split<INTERP, CT, C>(s, sy, iy0, wy);
+
+  CT out = (CT)0;
+  if (ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h) {
+    // interior: one wide load per tap row
+    int e = iy0 * s.pitch + ix0;
+#pragma unroll
+    for (int r = 0; r < NT; r++) {
+      CT v[NT];
+      TapLoad<ST, CT>::template row<NT>(s, e + r * s.pitch, v);
+      CT rs = wx[0] * v[0];
+#pragma unroll
+      for (int c = 1; c < NT; c++) rs = ipa_fma(wx[c], v[c], rs);
+      out = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, out);
+    }
+    return out;
+  }
+  if (s.border == IPA_BORDER_CONSTANT &&
+      (ix0 >= s.w || ix0 + NT <= 0 || iy0 >= s.h || iy0 + NT <= 0))
+    return cval;  // whole footprint outside
+#pragma unroll
+  for (int r = 0; r < NT; r++) {
+    int yy = resolve_idx(iy0 + r, s.h, s.border);
+    CT rs = (CT)0;
+#pragma unroll
+    for (int c = 0; c < NT; c++) {
+      int xx = resolve_idx(ix0 + c, s.w, s.border);
+      CT v = (yy < 0 || xx < 0) ? cval : TapLoad<ST, CT>::one(s, yy * s.pitch + xx);
+      rs = c == 0 ? wx[0] * v : ipa_fma(wx[c], v, rs);
+    }
+    out = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, out);
+  }
+  return out;
+}
+
+// cv2's uint8 bilinear: q5 coordinates, exact 15-bit integer weights
+// ((32-fx)(32-fy)*32 ...), rounded shift.  Integer arithmetic: bit-exact.
+template <typename C>
+__device__ __forceinline__ uint8_t sample_u8_fixed(const SrcView& s, C sx, C sy, uint8_t cv8) {
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cv8;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
+  int ix = qx >> 5, iy = qy >> 5, fx = qx & 31, fy = qy & 31;
+  int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
+  int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  int v[4];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    int yy = resolve_idx(iy + r, s.h, s.border);
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+      int xx = resolve_idx(ix + c, s.w, s.border);
+      v[r * 2 + c] = (yy < 0 || xx < 0)
+                         ? (int)cv8
+                         : (int)__builtin_amdgcn_raw_buffer_load_b8(s.rsrc, yy * s.pitch + xx, 0, 0);
+    }
+  }
+  int acc = v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11;
+  int o = (acc + (1 << 14)) >> 15;
+  return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
+// ------------------------------------------------------- coordinate sources --
+// Each provides  coord_t  and  get(u, v, sx, sy)  for destination pixel (u,v).
+
+struct MapCoord {
+  using coord_t = float;
+  const float* mx;
+  const float* my;
+  long pitch;
+  __device__ __forceinline__ void get(int u, int v, float& sx, float& sy) const {
+    long o = (long)v * pitch + u;
+    sx = mx[o];
+    sy = my[o];
+  }
+};
+
+// cv2.initUndistortRectifyMap with R = I evaluated per pixel in double and
+// rounded to the float32 a CV_32FC1 map stores (camera/LensDistortion.py:355-357).
+// No fp contraction here: the map builder, the analytic kernels and the CPU
+// oracle must produce the same float32 coordinate bit for bit.
+struct UndistortCoord {
+  using coord_t = float;
+  double ir[9];  // inv(newK)
+  double fx, fy, cx, cy;
+  double k1, k2, p1, p2, k3;
+  int affine;  // ir[6]==ir[7]==0 && ir[8]==1  ->  _w == 1 exactly
+  __device__ __forceinline__ void get(int u, int v, float& sx, float& sy) const {
+#pragma clang fp contract(off)
+    double du = (double)u, dv = (double)v;
+    double _x = ir[0] * du + ir[1] * dv + ir[2];
+    double _y = ir[3] * du + ir[4] * dv + ir[5];
+    double x = _x, y = _y;
+    if (!affine) {
+      double _w = ir[6] * du + ir[7] * dv + ir[8];
+      double iw = 1.0 / _w;
+      x = _x * iw;
+      y = _y * iw;
+    }
+    double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+    double kr = 1 + ((k3 * r2 + k2) * r2 + k1) * r2;
+    double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2);
+    double yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+    sx = (float)(fx * xd + cx);
+    sy = (float)(fy * yd + cy);
+  }
+};
+
+// cv2.warpPerspective: source = M * (u, v, 1), M = dst->src matrix, double
+// coordinates (skimage _warp_fast keeps them in double too).
+struct HomographyCoord {
+  using coord_t = double;
+  double m[9];
+  __device__ __forceinline__ void get(int u, int v, double& sx, double& sy) const {
+#pragma clang fp contract(off)
+    double du = (double)u, dv = (double)v;
+    double X = m[0] * du + m[1] * dv + m[2];
+    double Y = m[3] * du + m[4] * dv + m[5];
+    double W = m[6] * du + m[7] * dv + m[8];
+    if (W != 0.0) {
+      double iw = 1.0 / W;
+      sx = X * iw;
+      sy = Y * iw;
+    } else {
+      sx = 0.0;
+      sy = 0.0;
+    }
+  }
+};
+
+}  // namespace ipa

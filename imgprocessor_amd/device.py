@@ -1,0 +1,193 @@
+"""Device context and device-resident arrays on top of the C ABI.
+
+``Context`` wraps one ``ipa_ctx`` (one per GPU: a HIP stream + staging
+workspace).  ``DeviceArray`` is a thin owner of a device allocation with a
+numpy-like shape/dtype, so frames can stay in HBM between calls
+(`lens.correct(d_img)` -> `filter(d_img, k)` never touches the host).
+"""
+import ctypes as C
+import threading
+
+import numpy as np
+
+from . import _lib as L
+
+_DT = {np.dtype(np.uint8): L.U8, np.dtype(np.uint16): L.U16,
+       np.dtype(np.float32): L.F32, np.dtype(np.float64): L.F64}
+
+
+def dtype_id(dt):
+    try:
+        return _DT[np.dtype(dt)]
+    except KeyError:
+        raise TypeError('imgprocessor_amd: unsupported dtype %s (uint8, uint16, float32, '
+                        'float64 are)' % np.dtype(dt))
+
+
+class Context(object):
+    """one per GPU; create with Context(device_id) or use default_context()"""
+
+    def __init__(self, device_id=0):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        L.check(self._lib.ipa_ctx_create(int(device_id), C.byref(h)), None, 'ipa_ctx_create')
+        self.handle = h
+        self.device_id = int(device_id)
+
+    # -- info -------------------------------------------------------------
+    def device_info(self):
+        name = C.create_string_buffer(256)
+        cu = C.c_int()
+        mem = C.c_size_t()
+        self._check(self._lib.ipa_ctx_device_info(self.handle, name, 256, C.byref(cu),
+                                                  C.byref(mem)), 'device_info')
+        return {'name': name.value.decode(), 'cu_count': cu.value, 'total_mem': mem.value}
+
+    def _check(self, status, what=''):
+        L.check(status, self.handle, what)
+
+    def synchronize(self):
+        self._check(self._lib.ipa_ctx_synchronize(self.handle), 'synchronize')
+
+    # -- memory -----------------------------------------------------------
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, arr):
+        arr = np.ascontiguousarray(arr)
+        d = DeviceArray(self, arr.shape, arr.dtype)
+        d.set(arr)
+        return d
+
+    # -- events (HIP events on the stream the kernels run on) --------------
+    def event(self):
+        return Event(self)
+
+    def close(self):
+        if self.handle is not None:
+            self._lib.ipa_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Event(object):
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx._check(ctx._lib.ipa_event_create(ctx.handle, C.byref(h)), 'event_create')
+        self.handle = h
+
+    def record(self):
+        self.ctx._check(self.ctx._lib.ipa_event_record(self.ctx.handle, self.handle), 'event_record')
+        return self
+
+    def elapsed_ms(self, later):
+        """milliseconds from this event to `later` (synchronises on `later`)"""
+        ms = C.c_float()
+        self.ctx._check(self.ctx._lib.ipa_event_elapsed_ms(self.ctx.handle, self.handle,
+                                                           later.handle, C.byref(ms)), 'elapsed')
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.ctx.handle is not None:
+                self.ctx._lib.ipa_event_destroy(self.ctx.handle, self.handle)
+        except Exception:
+            pass
+
+
+class DeviceArray(object):
+    """C-contiguous array in HBM ([frame,] y, x)"""
+
+    def __init__(self, ctx, shape, dtype):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        dtype_id(self.dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        ctx._check(ctx._lib.ipa_malloc(ctx.handle, self.nbytes, C.byref(p)), 'ipa_malloc')
+        self.ptr = p
+        self._owner = True
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def set(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=self.dtype)
+        if arr.shape != self.shape:
+            raise ValueError('shape mismatch %s vs %s' % (arr.shape, self.shape))
+        self.ctx._check(self.ctx._lib.ipa_memcpy_h2d(self.ctx.handle, self.ptr,
+                                                     arr.ctypes.data_as(C.c_void_p), self.nbytes),
+                        'memcpy_h2d')
+        return self
+
+    def get(self, out=None):
+        if out is None:
+            out = np.empty(self.shape, self.dtype)
+        assert out.flags.c_contiguous and out.nbytes == self.nbytes
+        self.ctx._check(self.ctx._lib.ipa_memcpy_d2h(self.ctx.handle,
+                                                     out.ctypes.data_as(C.c_void_p), self.ptr,
+                                                     self.nbytes), 'memcpy_d2h')
+        return out
+
+    def frame(self, i):
+        """view of frame i of a (n, h, w) batch (no copy, not owning)"""
+        if self.ndim != 3:
+            raise ValueError('frame() needs a (n,h,w) batch')
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.shape, v.dtype = self.ctx, self.shape[1:], self.dtype
+        v.nbytes = self.nbytes // self.shape[0]
+        v.ptr = C.c_void_p(self.ptr.value + i * v.nbytes)
+        v._owner = False
+        v._base = self
+        return v
+
+    def free(self):
+        if getattr(self, '_owner', False) and self.ptr is not None and self.ctx.handle is not None:
+            self.ctx._lib.ipa_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+_default = {}
+_lock = threading.Lock()
+
+
+def default_context(device_id=0):
+    """process-wide context of a device (created on first use)"""
+    with _lock:
+        c = _default.get(device_id)
+        if c is None or c.handle is None:
+            c = _default[device_id] = Context(device_id)
+        return c
+
+
+def device_count():
+    n = C.c_int()
+    rc = L.lib().ipa_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def as_frames(a):
+    """(shape-normalised) -> n_frames, h, w for a 2-D image or 3-D batch"""
+    if len(a.shape) == 2:
+        return 1, a.shape[0], a.shape[1]
+    if len(a.shape) == 3:
+        return a.shape
+    raise ValueError('expected a (h,w) image or (n,h,w) batch, got shape %s' % (a.shape,))

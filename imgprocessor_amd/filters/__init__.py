@@ -1,0 +1,4 @@
+"""K x K filters of the hot path (reference: imgProcessor/filters/)."""
+from .filter import filter, gaussian_filter, box_filter  # noqa: F401,A001
+from .maskedConvolve import maskedConvolve  # noqa: F401
+from ._extendArrayForConvolution import extendArrayForConvolution  # noqa: F401

@@ -1,0 +1,423 @@
+"""Functional layer over the C ABI: every function takes either host numpy
+arrays (staged through the context workspace, result returned as numpy) or
+``DeviceArray``s (enqueued on the context stream, result stays in HBM).
+
+Shapes: (h, w) image or (n, h, w) batch of independent frames.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from .device import DeviceArray, default_context, dtype_id, as_frames
+
+INTERPOLATIONS = {
+    # exact-coordinate forms (scipy / scikit-image semantics)
+    'nearest': L.INTER_NEAREST,
+    'linear': L.INTER_LINEAR,                 # == map_coordinates(order=1), skimage order=1
+    'cubic': L.INTER_CUBIC_KEYS,              # Keys a=-0.5 == skimage order=3
+    'cubic_cv': L.INTER_CUBIC_CV,             # Keys a=-0.75, exact coordinates
+    # cv2-style: coordinates rounded to 1/32 px (INTER_BITS=5)
+    'linear_cv_q5': L.INTER_LINEAR | L.INTER_Q5,
+    'cubic_cv_q5': L.INTER_CUBIC_CV | L.INTER_Q5,
+    'lanczos4': L.INTER_LANCZOS4,
+}
+BORDERS = {
+    'constant': L.BORDER_CONSTANT, 'replicate': L.BORDER_REPLICATE, 'nearest': L.BORDER_REPLICATE,
+    'edge': L.BORDER_REPLICATE, 'reflect': L.BORDER_REFLECT, 'symmetric': L.BORDER_REFLECT,
+    'wrap': L.BORDER_WRAP, 'grid-wrap': L.BORDER_WRAP, 'mirror': L.BORDER_REFLECT101,
+    'reflect101': L.BORDER_REFLECT101,
+}
+
+
+def interp_id(v):
+    if isinstance(v, str):
+        try:
+            return INTERPOLATIONS[v]
+        except KeyError:
+            raise ValueError('unknown interpolation %r (one of %s)' % (v, sorted(INTERPOLATIONS)))
+    return int(v)
+
+
+def border_id(v):
+    if isinstance(v, str):
+        try:
+            return BORDERS[v]
+        except KeyError:
+            raise ValueError('unknown border mode %r (one of %s)' % (v, sorted(BORDERS)))
+    return int(v)
+
+
+def _is_dev(a):
+    return isinstance(a, DeviceArray)
+
+
+def _ctx_of(*arrs, **kw):
+    ctx = kw.get('ctx')
+    for a in arrs:
+        if _is_dev(a):
+            if ctx is not None and a.ctx is not ctx:
+                raise ValueError('arrays live on different contexts')
+            ctx = a.ctx
+    return ctx or default_context()
+
+
+def _host(a, dtype=None):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    dtype_id(a.dtype)
+    return a
+
+
+def _p(a):
+    return a.ptr if _is_dev(a) else a.ctypes.data_as(C.c_void_p)
+
+
+def _out_dtype(src_dtype, out_dtype):
+    return np.dtype(src_dtype if out_dtype is None else out_dtype)
+
+
+def _dev_out(ctx, out, shape, dtype):
+    if out is None:
+        return DeviceArray(ctx, shape, dtype)
+    if not _is_dev(out) or out.shape != tuple(shape) or out.dtype != np.dtype(dtype):
+        raise ValueError('out must be a DeviceArray of shape %s dtype %s' % (shape, dtype))
+    return out
+
+
+# ------------------------------------------------------------------ maps --
+def build_undistort_map(K, dist5, newK, h, w, ctx=None, device=False):
+    """cv2.initUndistortRectifyMap(K, d, None, newK, (w,h), CV_32FC1)"""
+    ctx = ctx or default_context()
+    lib = ctx._lib
+    K, d, nK = L.dbl(np.ravel(K), 9), L.dbl(np.ravel(dist5)[:5], 5), L.dbl(np.ravel(newK), 9)
+    if device:
+        mx, my = DeviceArray(ctx, (h, w), np.float32), DeviceArray(ctx, (h, w), np.float32)
+        ctx._check(lib.ipa_build_undistort_map_dev(ctx.handle, K, d, nK, h, w, mx.ptr, my.ptr, w),
+                   'build_undistort_map')
+        return mx, my
+    mx, my = np.empty((h, w), np.float32), np.empty((h, w), np.float32)
+    ctx._check(lib.ipa_build_undistort_map(ctx.handle, K, d, nK, h, w, _p(mx), _p(my)),
+               'build_undistort_map')
+    return mx, my
+
+
+# ----------------------------------------------------------------- remap --
+def remap(src, mapx, mapy, interpolation='linear', border_mode='constant', border_value=0.0,
+          out_dtype=None, out=None, ctx=None, map_roi=None):
+    """cv2.remap(src, mapx, mapy, ...).  map_roi=(x, y, w, h) (device maps only)
+    evaluates just that window of the maps — the keepSize=False crop of
+    LensDistortion.correct without computing the discarded border."""
+    interp, border = interp_id(interpolation), border_id(border_mode)
+    if _is_dev(src):
+        ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
+        if not (_is_dev(mapx) and _is_dev(mapy)):
+            raise TypeError('device source needs device maps')
+        n, sh, sw = as_frames(src)
+        mh, mw = mapx.shape
+        dh, dw, moff = mh, mw, 0
+        if map_roi is not None:
+            rx, ry, rw, rh = [int(v) for v in map_roi]
+            if not (0 <= rx and 0 <= ry and rw > 0 and rh > 0 and rx + rw <= mw and ry + rh <= mh):
+                raise ValueError('map_roi %s outside the %dx%d maps' % (map_roi, mh, mw))
+            dh, dw, moff = rh, rw, (ry * mw + rx) * 4
+        odt = _out_dtype(src.dtype, out_dtype)
+        oshape = (dh, dw) if src.ndim == 2 else (n, dh, dw)
+        dst = _dev_out(ctx, out, oshape, odt)
+        ctx._check(ctx._lib.ipa_remap_dev(ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw,
+                                          C.c_void_p(mapx.ptr.value + moff),
+                                          C.c_void_p(mapy.ptr.value + moff), mw, dst.ptr,
+                                          dtype_id(odt), dh, dw, dw, n, sh * sw, dh * dw, interp,
+                                          border, float(border_value)), 'remap')
+        return dst
+    if map_roi is not None:
+        raise ValueError('map_roi needs device arrays')
+    ctx = ctx or default_context()
+    src = _host(src)
+    mapx, mapy = _host(mapx, np.float32), _host(mapy, np.float32)
+    if mapx.shape != mapy.shape or mapx.ndim != 2:
+        raise ValueError('mapx/mapy must be 2-D and of equal shape')
+    n, sh, sw = as_frames(src)
+    dh, dw = mapx.shape
+    odt = _out_dtype(src.dtype, out_dtype)
+    dst = np.empty((dh, dw) if src.ndim == 2 else (n, dh, dw), odt)
+    ctx._check(ctx._lib.ipa_remap(ctx.handle, _p(src), dtype_id(src.dtype), sh, sw, _p(mapx),
+                                  _p(mapy), _p(dst), dtype_id(odt), dh, dw, n, interp, border,
+                                  float(border_value)), 'remap')
+    return dst
+
+
+def undistort(src, K, dist5, newK=None, interpolation='linear', border_mode='constant',
+              border_value=0.0, out_dtype=None, out_shape=None, out=None, ctx=None):
+    """LensDistortion.correct without map arrays (analytic coordinates)"""
+    interp, border = interp_id(interpolation), border_id(border_mode)
+    if newK is None:
+        newK = K
+    Kc, dc, nKc = L.dbl(np.ravel(K), 9), L.dbl(np.ravel(dist5)[:5], 5), L.dbl(np.ravel(newK), 9)
+    dev = _is_dev(src)
+    ctx = _ctx_of(src, ctx=ctx)
+    if not dev:
+        src = _host(src)
+    n, sh, sw = as_frames(src)
+    dh, dw = out_shape or (sh, sw)
+    odt = _out_dtype(src.dtype, out_dtype)
+    oshape = (dh, dw) if len(src.shape) == 2 else (n, dh, dw)
+    if dev:
+        dst = _dev_out(ctx, out, oshape, odt)
+        ctx._check(ctx._lib.ipa_undistort_dev(ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw,
+                                              Kc, dc, nKc, dst.ptr, dtype_id(odt), dh, dw, dw, n,
+                                              sh * sw, dh * dw, interp, border,
+                                              float(border_value)), 'undistort')
+        return dst
+    dst = np.empty(oshape, odt)
+    ctx._check(ctx._lib.ipa_undistort(ctx.handle, _p(src), dtype_id(src.dtype), sh, sw, Kc, dc,
+                                      nKc, _p(dst), dtype_id(odt), dh, dw, n, interp, border,
+                                      float(border_value)), 'undistort')
+    return dst
+
+
+def warp_perspective(src, M_dst2src, out_shape, interpolation='linear', border_mode='constant',
+                     border_value=0.0, out_dtype=None, out=None, ctx=None):
+    """cv2.warpPerspective with M the DESTINATION->SOURCE matrix (pass inv(H)
+    for a plain call, H for WARP_INVERSE_MAP)"""
+    interp, border = interp_id(interpolation), border_id(border_mode)
+    M = L.dbl(np.ravel(np.asarray(M_dst2src, dtype=np.float64)), 9)
+    dev = _is_dev(src)
+    ctx = _ctx_of(src, ctx=ctx)
+    if not dev:
+        src = _host(src)
+    n, sh, sw = as_frames(src)
+    dh, dw = int(out_shape[0]), int(out_shape[1])
+    odt = _out_dtype(src.dtype, out_dtype)
+    oshape = (dh, dw) if len(src.shape) == 2 else (n, dh, dw)
+    if dev:
+        dst = _dev_out(ctx, out, oshape, odt)
+        ctx._check(ctx._lib.ipa_warp_perspective_dev(ctx.handle, src.ptr, dtype_id(src.dtype), sh,
+                                                     sw, sw, M, dst.ptr, dtype_id(odt), dh, dw, dw,
+                                                     n, sh * sw, dh * dw, interp, border,
+                                                     float(border_value)), 'warp_perspective')
+        return dst
+    dst = np.empty(oshape, odt)
+    ctx._check(ctx._lib.ipa_warp_perspective(ctx.handle, _p(src), dtype_id(src.dtype), sh, sw, M,
+                                             _p(dst), dtype_id(odt), dh, dw, n, interp, border,
+                                             float(border_value)), 'warp_perspective')
+    return dst
+
+
+# --------------------------------------------------------------- filters --
+def _float_img(img):
+    """filters run on float32/float64 (the reference's toFloatArray rule for ints)"""
+    if _is_dev(img):
+        if img.dtype not in (np.float32, np.float64):
+            raise TypeError('device filters need float32/float64 arrays')
+        return img
+    img = np.asarray(img)
+    if img.dtype not in (np.float32, np.float64):
+        img = img.astype(np.float32 if img.dtype.itemsize <= 2 else np.float64)
+    return np.ascontiguousarray(img)
+
+
+def conv2d(img, kernel, mode='reflect', cval=0.0, mask=None, mode_y=None, out=None, ctx=None):
+    """centred correlation == scipy.ndimage.correlate(img, kernel, mode=mode, cval=cval);
+    mode applies to x (columns), mode_y (default: same) to y (rows)"""
+    bx = border_id(mode)
+    by = border_id(mode_y) if mode_y is not None else bx
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    if k.ndim != 2:
+        raise ValueError('kernel must be 2-D')
+    kp = k.ctypes.data_as(C.POINTER(C.c_double))
+    img = _float_img(img)
+    ctx = _ctx_of(img, mask, ctx=ctx)
+    n, h, w = as_frames(img)
+    if _is_dev(img):
+        if mask is not None and not _is_dev(mask):
+            raise TypeError('device image needs a device mask')
+        dst = _dev_out(ctx, out, img.shape, img.dtype)
+        ctx._check(ctx._lib.ipa_conv2d_dev(ctx.handle, img.ptr, dtype_id(img.dtype), h, w, w, kp,
+                                           k.shape[0], k.shape[1],
+                                           mask.ptr if mask is not None else None, w, dst.ptr, w,
+                                           n, h * w, h * w, bx, by, float(cval)), 'conv2d')
+        return dst
+    m = None
+    if mask is not None:
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape != (h, w):
+            raise ValueError('mask shape %s != image shape %s' % (m.shape, (h, w)))
+    dst = np.empty_like(img)
+    ctx._check(ctx._lib.ipa_conv2d(ctx.handle, _p(img), dtype_id(img.dtype), h, w, kp, k.shape[0],
+                                   k.shape[1], _p(m) if m is not None else None, _p(dst), n, bx,
+                                   by, float(cval)), 'conv2d')
+    return dst
+
+
+def sepconv2d(img, ky, kx, mode='reflect', cval=0.0, out=None, ctx=None):
+    """separable correlation, axis 0 (ky) then axis 1 (kx); None skips an axis"""
+    b = border_id(mode)
+    ky = np.zeros(0) if ky is None else np.ascontiguousarray(ky, dtype=np.float64).ravel()
+    kx = np.zeros(0) if kx is None else np.ascontiguousarray(kx, dtype=np.float64).ravel()
+    dp = C.POINTER(C.c_double)
+    img = _float_img(img)
+    ctx = _ctx_of(img, ctx=ctx)
+    n, h, w = as_frames(img)
+    if _is_dev(img):
+        dst = _dev_out(ctx, out, img.shape, img.dtype)
+        ctx._check(ctx._lib.ipa_sepconv2d_dev(ctx.handle, img.ptr, dtype_id(img.dtype), h, w, w,
+                                              ky.ctypes.data_as(dp), ky.size, kx.ctypes.data_as(dp),
+                                              kx.size, dst.ptr, w, n, h * w, h * w, b, b,
+                                              float(cval)), 'sepconv2d')
+        return dst
+    dst = np.empty_like(img)
+    ctx._check(ctx._lib.ipa_sepconv2d(ctx.handle, _p(img), dtype_id(img.dtype), h, w,
+                                      ky.ctypes.data_as(dp), ky.size, kx.ctypes.data_as(dp),
+                                      kx.size, _p(dst), n, b, b, float(cval)), 'sepconv2d')
+    return dst
+
+
+def gaussian_kernel1d(sigma, radius=None, truncate=4.0):
+    """the taps scipy.ndimage.gaussian_filter uses: radius=int(truncate*sigma+0.5)"""
+    sigma = float(sigma)
+    if radius is None:
+        radius = int(truncate * sigma + 0.5)
+    x = np.arange(-radius, radius + 1, dtype=np.float64)
+    k = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return k / k.sum()
+
+
+def gaussian_filter(img, sigma, mode='reflect', cval=0.0, truncate=4.0, out=None, ctx=None):
+    """scipy.ndimage.gaussian_filter(img, sigma, mode=..., truncate=...) for 2-D frames"""
+    if np.isscalar(sigma):
+        sigma = (sigma, sigma)
+    ks = [gaussian_kernel1d(s, truncate=truncate) if s > 1e-15 else None for s in sigma]
+    return sepconv2d(img, ks[0], ks[1], mode, cval, out=out, ctx=ctx)
+
+
+def extend_array(arr, kernelXY, modex='reflect', modey='reflect', ctx=None):
+    """filters/_extendArrayForConvolution.py:5-97 on the device"""
+    kx, ky = int(kernelXY[0]), int(kernelXY[1])
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, ctx=ctx)
+    d_in = arr if dev else ctx.to_device(_host(arr))
+    if d_in.ndim != 2:
+        raise ValueError('extend_array works on 2-D arrays')
+    h, w = d_in.shape
+    oshape = (h + 2 * (ky // 2), w + 2 * (kx // 2))
+    d_out = DeviceArray(ctx, oshape, d_in.dtype)
+    ctx._check(ctx._lib.ipa_extend_array_dev(ctx.handle, d_in.ptr, dtype_id(d_in.dtype), h, w, w,
+                                             kx, ky, border_id(modex), border_id(modey), d_out.ptr,
+                                             oshape[1]), 'extend_array')
+    return d_out if dev else d_out.get()
+
+
+# ------------------------------------------------- fused remap -> filter --
+def _fused_out(ctx, src, out, dh, dw, n):
+    odt = np.float64 if src.dtype == np.float64 else np.float32
+    return _dev_out(ctx, out, (dh, dw) if src.ndim == 2 else (n, dh, dw), odt), odt
+
+
+def remap_conv2d(src, mapx, mapy, kernel, interpolation='linear', border_mode='constant',
+                 border_value=0.0, conv_mode='reflect', out=None, ctx=None):
+    """remap followed by a K x K centred correlation, one kernel, device arrays only"""
+    ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
+    if not (_is_dev(src) and _is_dev(mapx) and _is_dev(mapy)):
+        raise TypeError('remap_conv2d works on DeviceArrays (use Context.to_device)')
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    n, sh, sw = as_frames(src)
+    dh, dw = mapx.shape
+    dst, odt = _fused_out(ctx, src, out, dh, dw, n)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_remap_conv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw, mapx.ptr, mapy.ptr, dw,
+        k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], dst.ptr, dtype_id(odt),
+        dh, dw, dw, n, sh * sw, dh * dw, interp_id(interpolation), border_id(border_mode),
+        float(border_value), cb, cb), 'remap_conv2d')
+    return dst
+
+
+def undistort_conv2d(src, K, dist5, newK, kernel, interpolation='linear', border_mode='constant',
+                     border_value=0.0, conv_mode='reflect', out_shape=None, out=None, ctx=None):
+    ctx = _ctx_of(src, ctx=ctx)
+    if not _is_dev(src):
+        raise TypeError('undistort_conv2d works on DeviceArrays (use Context.to_device)')
+    if newK is None:
+        newK = K
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    n, sh, sw = as_frames(src)
+    dh, dw = out_shape or (sh, sw)
+    dst, odt = _fused_out(ctx, src, out, dh, dw, n)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_undistort_conv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw, L.dbl(np.ravel(K), 9),
+        L.dbl(np.ravel(dist5)[:5], 5), L.dbl(np.ravel(newK), 9),
+        k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], dst.ptr, dtype_id(odt),
+        dh, dw, dw, n, sh * sw, dh * dw, interp_id(interpolation), border_id(border_mode),
+        float(border_value), cb, cb), 'undistort_conv2d')
+    return dst
+
+
+def warp_perspective_conv2d(src, M_dst2src, out_shape, kernel, interpolation='linear',
+                            border_mode='constant', border_value=0.0, conv_mode='reflect',
+                            out=None, ctx=None):
+    ctx = _ctx_of(src, ctx=ctx)
+    if not _is_dev(src):
+        raise TypeError('warp_perspective_conv2d works on DeviceArrays (use Context.to_device)')
+    k = np.ascontiguousarray(kernel, dtype=np.float64)
+    n, sh, sw = as_frames(src)
+    dh, dw = int(out_shape[0]), int(out_shape[1])
+    dst, odt = _fused_out(ctx, src, out, dh, dw, n)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_warp_perspective_conv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw,
+        L.dbl(np.ravel(np.asarray(M_dst2src, dtype=np.float64)), 9),
+        k.ctypes.data_as(C.POINTER(C.c_double)), k.shape[0], k.shape[1], dst.ptr, dtype_id(odt),
+        dh, dw, dw, n, sh * sw, dh * dw, interp_id(interpolation), border_id(border_mode),
+        float(border_value), cb, cb), 'warp_perspective_conv2d')
+    return dst
+
+
+# ------------------------------------------------------------------- IDW --
+def idw_fill(grid, mask, ksize, weights, ctx=None):
+    """in-place IDW hole filling (interpolate2dStructuredIDW._calc)"""
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if w.shape != (2 * ksize + 1, 2 * ksize + 1):
+        raise ValueError('weights must be (2*ksize+1)^2')
+    wp = w.ctypes.data_as(C.POINTER(C.c_double))
+    ctx = _ctx_of(grid, mask, ctx=ctx)
+    if _is_dev(grid):
+        if not _is_dev(mask):
+            raise TypeError('device grid needs a device mask')
+        h, wd = grid.shape
+        ctx._check(ctx._lib.ipa_idw_fill_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype), mask.ptr,
+                                             h, wd, wd, int(ksize), wp), 'idw_fill')
+        return grid
+    if not (isinstance(grid, np.ndarray) and grid.flags.c_contiguous and grid.ndim == 2):
+        raise ValueError('grid must be a C-contiguous 2-D ndarray (it is modified in place)')
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, wd = grid.shape
+    ctx._check(ctx._lib.ipa_idw_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h, wd,
+                                     int(ksize), wp), 'idw_fill')
+    return grid
+
+
+def fast_idw_fill(grid, mask, offsets, weights, minnvals, ctx=None):
+    """in-place growing-distance IDW (interpolate2dStructuredFastIDW._calc)"""
+    offs = np.ascontiguousarray(offsets, dtype=np.int32)
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    n = int(w.size)
+    if offs.shape != (n, 2):
+        raise ValueError('offsets must be (n,2) matching weights')
+    wp = w.ctypes.data_as(C.POINTER(C.c_double))
+    ctx = _ctx_of(grid, mask, ctx=ctx)
+    if _is_dev(grid):
+        if not _is_dev(mask):
+            raise TypeError('device grid needs a device mask')
+        h, wd = grid.shape
+        ctx._check(ctx._lib.ipa_fast_idw_fill_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype),
+                                                  mask.ptr, h, wd, wd, _p(offs), wp, n,
+                                                  int(minnvals)), 'fast_idw_fill')
+        return grid
+    if not (isinstance(grid, np.ndarray) and grid.flags.c_contiguous and grid.ndim == 2):
+        raise ValueError('grid must be a C-contiguous 2-D ndarray (it is modified in place)')
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    h, wd = grid.shape
+    ctx._check(ctx._lib.ipa_fast_idw_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h,
+                                          wd, _p(offs), wp, n, int(minnvals)), 'fast_idw_fill')
+    return grid

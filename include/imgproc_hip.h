@@ -1,0 +1,236 @@
+/*
+ * imgproc_hip.h — C ABI of libimgproc_hip.so, the MI355X (gfx950) implementation
+ * of imgProcessor's per-pixel hot path (undistort / perspective remap, K x K
+ * filters, IDW stencils).
+ *
+ * The reference (radjkarl/imgProcessor, pure Python) has no FFI layer; its
+ * boundary for this path is a set of Python call sites into cv2 / numba /
+ * scipy.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; every function returns an ipa_status (0 = ok).
+ *   - images are row-major [y][x], single channel; pitches are in ELEMENTS.
+ *   - `*_dev` functions take DEVICE pointers and enqueue on the context's
+ *     stream without synchronising (use ipa_ctx_synchronize / events).
+ *     The un-suffixed variants take HOST pointers, stage H2D/D2H through the
+ *     context's workspace and return after the result is in host memory.
+ *   - batches: n_frames images, consecutive frames `*_frame_stride` ELEMENTS
+ *     apart; maps / kernels / matrices are shared by all frames.
+ *   - there is NO CPU fallback in this library.  Without a usable gfx950
+ *     device ipa_ctx_create fails with IPA_ERR_NO_DEVICE.
+ */
+#ifndef IMGPROC_HIP_H
+#define IMGPROC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPA_VERSION 100 /* 0.1.0 */
+
+typedef enum {
+  IPA_OK = 0,
+  IPA_ERR_BAD_ARG = -1,
+  IPA_ERR_UNSUPPORTED = -2, /* dtype / mode combination not implemented */
+  IPA_ERR_HIP = -3,         /* a HIP runtime call failed; see ipa_last_error */
+  IPA_ERR_OOM = -4,
+  IPA_ERR_NO_DEVICE = -5
+} ipa_status;
+
+/* pixel types (transformations.py:78-87 toFloatArray: u8,u16 -> f32) */
+typedef enum { IPA_U8 = 0, IPA_U16 = 1, IPA_F32 = 2, IPA_F64 = 3 } ipa_dtype;
+
+/* interpolation; numbering follows cv2.INTER_* where one exists */
+typedef enum {
+  IPA_INTER_NEAREST = 0,
+  IPA_INTER_LINEAR = 1,     /* cv2.INTER_LINEAR   — LensDistortion.py:323 */
+  IPA_INTER_CUBIC_CV = 2,   /* cv2.INTER_CUBIC (Keys a=-0.75) — PerspectiveCorrection.py:378 */
+  IPA_INTER_LANCZOS4 = 4,   /* cv2.INTER_LANCZOS4 — PerspectiveCorrection.py:404 (always q5) */
+  IPA_INTER_CUBIC_KEYS = 5, /* Keys a=-0.5 == skimage.transform.warp(order=3) */
+  IPA_INTER_Q5 = 0x100      /* OR-able flag: round coordinates to 1/32 px like cv2 (INTER_BITS=5) */
+} ipa_interp;
+
+/* border modes; numbering follows cv2.BORDER_* */
+typedef enum {
+  IPA_BORDER_CONSTANT = 0,  /* cv2.BORDER_CONSTANT / scipy 'constant' (per-tap blend) */
+  IPA_BORDER_REPLICATE = 1, /* scipy 'nearest' */
+  IPA_BORDER_REFLECT = 2,   /* fedcba|abcdef: scipy 'reflect', numpy 'symmetric',
+                               extendArrayForConvolution 'reflect' */
+  IPA_BORDER_WRAP = 3,      /* scipy 'wrap' / 'grid-wrap', extendArray modex='wrap' */
+  IPA_BORDER_REFLECT101 = 4 /* scipy 'mirror' */
+} ipa_border;
+
+typedef struct ipa_ctx ipa_ctx;     /* one per device; owns a stream + workspace */
+typedef struct ipa_event ipa_event; /* HIP event on the context's stream */
+
+/* ---------------------------------------------------------------- runtime */
+int ipa_version(void);
+const char* ipa_status_string(int status);
+/* last error text of this context (or of the calling thread when ctx==NULL) */
+const char* ipa_last_error(const ipa_ctx* ctx);
+int ipa_device_count(int* count);
+int ipa_ctx_create(int device_id, ipa_ctx** ctx);
+int ipa_ctx_destroy(ipa_ctx* ctx);
+int ipa_ctx_synchronize(ipa_ctx* ctx);
+/* name (e.g. "gfx950...") and compute-unit count of the context's device */
+int ipa_ctx_device_info(ipa_ctx* ctx, char* name, size_t name_len, int* cu_count,
+                        size_t* total_mem_bytes);
+
+/* device / pinned-host memory owned by the caller until freed */
+int ipa_malloc(ipa_ctx* ctx, size_t bytes, void** dptr);
+int ipa_free(ipa_ctx* ctx, void* dptr);
+int ipa_host_alloc(ipa_ctx* ctx, size_t bytes, void** hptr);
+int ipa_host_free(ipa_ctx* ctx, void* hptr);
+int ipa_memcpy_h2d(ipa_ctx* ctx, void* dptr, const void* hptr, size_t bytes); /* synchronous */
+int ipa_memcpy_d2h(ipa_ctx* ctx, void* hptr, const void* dptr, size_t bytes); /* synchronous */
+int ipa_memcpy_d2d(ipa_ctx* ctx, void* dst, const void* src, size_t bytes);   /* stream-ordered */
+int ipa_memset(ipa_ctx* ctx, void* dptr, int value, size_t bytes);            /* stream-ordered */
+
+/* HIP events recorded on the stream the kernels run on (bench.py timing) */
+int ipa_event_create(ipa_ctx* ctx, ipa_event** ev);
+int ipa_event_destroy(ipa_ctx* ctx, ipa_event* ev);
+int ipa_event_record(ipa_ctx* ctx, ipa_event* ev);
+int ipa_event_elapsed_ms(ipa_ctx* ctx, ipa_event* start, ipa_event* stop, float* ms);
+
+/* ------------------------------------------------------------ map builder */
+/* replaces cv2.initUndistortRectifyMap(K, dist, None, newK, (w,h), CV_32FC1)
+ * at camera/LensDistortion.py:355-357.  K,newK: 3x3 row-major double;
+ * dist5 = [k1,k2,p1,p2,k3] (LensDistortion.py:370,380).  Maps are float32. */
+int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dist5,
+                                const double* newK, int h, int w, float* d_mapx, float* d_mapy,
+                                long map_pitch);
+int ipa_build_undistort_map(ipa_ctx* ctx, const double* K, const double* dist5,
+                            const double* newK, int h, int w, float* mapx, float* mapy);
+
+/* ------------------------------------------------------------------ remap */
+/* replaces cv2.remap(image, mapx, mapy, interp, borderMode, borderValue) at
+ * camera/LensDistortion.py:323-326,339-340 (and transform/polarTransform.py:66,105).
+ * dst dtype may equal the src dtype or be IPA_F32 (fused toFloatArray ingest).
+ * u8 -> u8 INTER_LINEAR uses cv2's exact fixed-point arithmetic. */
+int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw, long src_pitch,
+                  const float* d_mapx, const float* d_mapy, long map_pitch, void* d_dst,
+                  int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                  long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                  double border_value);
+int ipa_remap(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw, const float* mapx,
+              const float* mapy, void* dst, int dst_dtype, int dh, int dw, int n_frames,
+              int interp, int border_mode, double border_value);
+
+/* LensDistortion.correct without materialised maps: the distortion model of
+ * initUndistortRectifyMap is evaluated per pixel in double, rounded to the
+ * float32 a CV_32FC1 map would hold, then sampled exactly like ipa_remap.
+ * Bit-identical to ipa_build_undistort_map_dev + ipa_remap_dev. */
+int ipa_undistort_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                      long src_pitch, const double* K, const double* dist5, const double* newK,
+                      void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                      long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                      double border_value);
+int ipa_undistort(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw, const double* K,
+                  const double* dist5, const double* newK, void* dst, int dst_dtype, int dh,
+                  int dw, int n_frames, int interp, int border_mode, double border_value);
+
+/* replaces cv2.warpPerspective at camera/PerspectiveCorrection.py:241-242,
+ * 377-378,401-405 (and transform/simplePerspectiveTransform.py:27-31).
+ * M is the 3x3 row-major double matrix mapping DESTINATION (x,y,1) to source
+ * coordinates: pass inv(H) for a plain call, H itself for WARP_INVERSE_MAP. */
+int ipa_warp_perspective_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                             long src_pitch, const double* M, void* d_dst, int dst_dtype, int dh,
+                             int dw, long dst_pitch, int n_frames, long src_frame_stride,
+                             long dst_frame_stride, int interp, int border_mode,
+                             double border_value);
+int ipa_warp_perspective(ipa_ctx* ctx, const void* src, int src_dtype, int sh, int sw,
+                         const double* M, void* dst, int dst_dtype, int dh, int dw, int n_frames,
+                         int interp, int border_mode, double border_value);
+
+/* ---------------------------------------------------------------- filters */
+/* dense kh x kw centred correlation (== scipy.ndimage.correlate, origin 0):
+ *   dst[y,x] = sum_{i,j} kernel[i,j] * src[y+i-kh/2, x+j-kw/2]
+ * replaces filters/maskedConvolve.py:24-43 (_calc) + the padding of
+ * filters/_extendArrayForConvolution.py:5-97 (border_x / border_y per axis),
+ * and the cv2.blur / scipy.ndimage.convolve call sites
+ * (camera/lens/estimateSystematicErrorLensCorrection.py:206-207, features/hog.py:62-63).
+ * kernel: HOST pointer, kh*kw doubles.  d_mask: optional uint8 (H,W) device
+ * array; where it is 0 the output is 0 (maskedConvolve), NULL = everywhere.
+ * dtype: IPA_F32 or IPA_F64 (src and dst). */
+int ipa_conv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
+                   const double* kernel, int kh, int kw, const uint8_t* d_mask, long mask_pitch,
+                   void* d_dst, long dst_pitch, int n_frames, long src_frame_stride,
+                   long dst_frame_stride, int border_x, int border_y, double border_value);
+int ipa_conv2d(ipa_ctx* ctx, const void* src, int dtype, int h, int w, const double* kernel,
+               int kh, int kw, const uint8_t* mask, void* dst, int n_frames, int border_x,
+               int border_y, double border_value);
+
+/* separable correlation, scipy.ndimage.gaussian_filter order: axis 0 (y) with
+ * ky[nky] first, intermediate rounded to the image dtype, then axis 1 (x) with
+ * kx[nkx].  nky==0 / nkx==0 skips that axis.  Replaces the gaussian_filter call
+ * sites filters/standardDeviation.py:23, filters/fastFilter.py:42,
+ * camera/flatField/flatField.py:47.  Single pass over HBM. */
+int ipa_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
+                      const double* ky, int nky, const double* kx, int nkx, void* d_dst,
+                      long dst_pitch, int n_frames, long src_frame_stride, long dst_frame_stride,
+                      int border_y, int border_x, double border_value);
+int ipa_sepconv2d(ipa_ctx* ctx, const void* src, int dtype, int h, int w, const double* ky,
+                  int nky, const double* kx, int nkx, void* dst, int n_frames, int border_y,
+                  int border_x, double border_value);
+
+/* replaces filters/_extendArrayForConvolution.py:5-97 for callers that want the
+ * padded array itself (the filters above resolve borders while staging and do
+ * not need it): dst is (h + 2*(ky/2)) x (w + 2*(kx/2)), kx/ky = kernel size
+ * along x/y.  Any dtype (pure copy). */
+int ipa_extend_array_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
+                         int kx, int ky, int modex, int modey, void* d_dst, long dst_pitch);
+
+/* --------------------------------------------- fused remap -> K x K filter */
+/* the headline chain (LensDistortion.correct followed by a K x K filter, the
+ * in-tree archetype being estimateSystematicErrorLensCorrection.py:199-207):
+ * remapped pixels (incl. the filter halo, resolved with conv_border_*) are
+ * produced into LDS and filtered there; the intermediate image never touches
+ * HBM.  dst dtype is IPA_F32 (src may be u8/u16/f32) or IPA_F64 (src f64). */
+int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                         long src_pitch, const float* d_mapx, const float* d_mapy, long map_pitch,
+                         const double* kernel, int kh, int kw, void* d_dst, int dst_dtype, int dh,
+                         int dw, long dst_pitch, int n_frames, long src_frame_stride,
+                         long dst_frame_stride, int interp, int border_mode, double border_value,
+                         int conv_border_x, int conv_border_y);
+int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                             long src_pitch, const double* K, const double* dist5,
+                             const double* newK, const double* kernel, int kh, int kw, void* d_dst,
+                             int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                             long src_frame_stride, long dst_frame_stride, int interp,
+                             int border_mode, double border_value, int conv_border_x,
+                             int conv_border_y);
+int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                                    long src_pitch, const double* M, const double* kernel, int kh,
+                                    int kw, void* d_dst, int dst_dtype, int dh, int dw,
+                                    long dst_pitch, int n_frames, long src_frame_stride,
+                                    long dst_frame_stride, int interp, int border_mode,
+                                    double border_value, int conv_border_x, int conv_border_y);
+
+/* ------------------------------------------------------------ interpolate */
+/* replaces interpolate/interpolate2dStructuredIDW.py:26-65 (_calc): every
+ * pixel with mask!=0 becomes the weighted mean of the unmasked pixels in the
+ * (2*ksize+1)^2 window; weights: HOST (2*ksize+1)^2 doubles (table built by the
+ * caller exactly as :16-21).  In place on d_grid (F32 or F64). */
+int ipa_idw_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* d_mask, int h, int w,
+                     long pitch, int ksize, const double* weights);
+int ipa_idw_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
+                 int ksize, const double* weights);
+
+/* replaces interpolate/interpolate2dStructuredFastIDW.py:29-63: neighbours are
+ * visited in the order of offsets[n][2] (int32 dy,dx pairs, HOST), stopping
+ * after `minnvals`+1 hits exactly as the reference loop does. */
+int ipa_fast_idw_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* d_mask, int h,
+                          int w, long pitch, const int32_t* offsets, const double* weights, int n,
+                          int minnvals);
+int ipa_fast_idw_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
+                      const int32_t* offsets, const double* weights, int n, int minnvals);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMGPROC_HIP_H */

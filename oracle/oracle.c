@@ -255,10 +255,10 @@ static inline void axis_weights(const sampler_t* s, double c, long* i0, double* 
 
 static double sample(const sampler_t* s, double sx, double sy) {
   /* NaN / absurd coordinates behave like "far outside" */
-  if (!(sx > -1e9 && sx < 1e9 && sy > -1e9 && sy < 1e9)) {
+  if (!(sx > -1e6 && sx < 1e6 && sy > -1e6 && sy < 1e6)) {
     if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return s->cval;
-    sx = sx < -1e9 ? -1e9 : (sx > 1e9 ? 1e9 : sx);
-    sy = sy < -1e9 ? -1e9 : (sy > 1e9 ? 1e9 : sy);
+    sx = sx < -1e6 ? -1e6 : (sx > 1e6 ? 1e6 : sx);
+    sy = sy < -1e6 ? -1e6 : (sy > 1e6 ? 1e6 : sy);
   }
   int n = ntaps_of(s->interp);
   long ix0 = 0, iy0 = 0;
@@ -285,10 +285,10 @@ static double sample(const sampler_t* s, double sx, double sy) {
 /* OpenCV's uint8 bilinear: q5 coordinates, 15-bit integer weights
  * (BilinearTab_i = (32-fx)(32-fy)*32 etc., exact), rounded shift. */
 static uint8_t sample_u8_fixed(const sampler_t* s, double sx, double sy, uint8_t cv8) {
-  if (!(sx > -1e9 && sx < 1e9 && sy > -1e9 && sy < 1e9)) {
+  if (!(sx > -1e6 && sx < 1e6 && sy > -1e6 && sy < 1e6)) {
     if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return cv8;
-    sx = sx < -1e9 ? -1e9 : (sx > 1e9 ? 1e9 : sx);
-    sy = sy < -1e9 ? -1e9 : (sy > 1e9 ? 1e9 : sy);
+    sx = sx < -1e6 ? -1e6 : (sx > 1e6 ? 1e6 : sx);
+    sy = sy < -1e6 ? -1e6 : (sy > 1e6 ? 1e6 : sy);
   }
   long qx = (long)nearbyint(sx * 32.0), qy = (long)nearbyint(sy * 32.0);
   long ix = qx >> 5, iy = qy >> 5;

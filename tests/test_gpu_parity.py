@@ -1,0 +1,509 @@
+"""GPU: the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Tolerances: float32 images within 1e-5 relative (BASELINE.json north_star;
+`rtol` on each element plus an `atol` of 1e-5 x the image's value range so
+that cancelling sums are judged against the data scale); float64 images
+within 1e-12; uint8 fixed-point and pure index work bit-exact.
+"""
+import io
+import contextlib
+
+import numpy as np
+import pytest
+
+from .conftest import load_golden, assert_close, synth
+
+pytestmark = pytest.mark.gpu
+
+RT = 1e-5
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)  # raises without a gfx950 device: no fallback
+    return imgprocessor_amd
+
+
+def close32(got, want, what='', scale=None):
+    want = np.asarray(want, dtype=np.float64)
+    s = np.nanmax(np.abs(want)) if scale is None else scale
+    assert_close(got, want, RT, RT * s, what)
+
+
+# ---------------------------------------------------------------- remap ----
+CASES = ('zero', 'radial', 'synthdefault', 'strong')
+
+
+def test_undistort_map_bit_exact(ia, oracle):
+    g = load_golden('remap_scipy.npz')
+    H, W = g['img'].shape
+    for c in CASES:
+        mx, my = ia.ops.build_undistort_map(g['K_' + c], g['dist_' + c], g['newK_' + c], H, W)
+        omx, omy = oracle.build_undistort_map(g['K_' + c], g['dist_' + c], g['newK_' + c], H, W)
+        assert np.array_equal(mx, omx) and np.array_equal(my, omy), c
+        assert_close(mx, g['mapx_' + c], 1.2e-7, 1e-6, 'golden mapx ' + c)
+    # non-affine newK (perspective row) exercises the 1/w branch
+    nK = np.array([[100., 2, 60], [1, 105., 50], [1e-4, -2e-4, 1.0]])
+    mx, my = ia.ops.build_undistort_map(g['K_strong'], g['dist_strong'], nK, 50, 70)
+    omx, omy = oracle.build_undistort_map(g['K_strong'], g['dist_strong'], nK, 50, 70)
+    assert np.array_equal(mx, omx) and np.array_equal(my, omy)
+
+
+def test_remap_linear_golden(ia, oracle):
+    g = load_golden('remap_scipy.npz')
+    img, img16 = g['img'], g['img16']
+    for c in CASES:
+        mx, my = g['mapx_' + c], g['mapy_' + c]
+        for cname, cv in (('c0', 0.0), ('cnan', np.nan), ('c037', 0.37)):
+            key = 'lin_%s_%s' % (c, cname)
+            if key not in g:
+                continue
+            got = ia.ops.remap(img, mx, my, 'linear', 'constant', cv)
+            close32(got, g[key], key, scale=1.0)
+            close32(got, oracle.remap(img, mx, my, oracle.LINEAR, oracle.CONSTANT, cv), key + ' orc',
+                    scale=1.0)
+        got = ia.ops.remap(img16, mx, my, 'linear', out_dtype=np.float32)
+        close32(got, g['lin16_' + c], 'lin16 ' + c)
+        # analytic kernel: same float32 coordinates -> identical to the map-based kernel
+        an = ia.ops.undistort(img, g['K_' + c], g['dist_' + c], g['newK_' + c])
+        mb = ia.ops.remap(img, *ia.ops.build_undistort_map(g['K_' + c], g['dist_' + c],
+                                                           g['newK_' + c], *img.shape))
+        assert np.array_equal(an, mb), 'analytic != map-based ' + c
+    mx, my = g['mapx_strong'], g['mapy_strong']
+    for smode, b in (('nearest', 'replicate'), ('reflect', 'reflect'), ('mirror', 'reflect101'),
+                     ('grid-wrap', 'wrap')):
+        close32(ia.ops.remap(img, mx, my, 'linear', b), g['lin_strong_' + smode], smode)
+
+
+def test_remap_all_modes_vs_oracle(ia, oracle):
+    rng = np.random.default_rng(3)
+    H, W = 61, 83  # odd sizes: scalar tails, unaligned rows
+    img = synth((H, W), 9)
+    yy, xx = np.mgrid[0:70, 0:90].astype(np.float32)
+    mx = (xx * 0.93 - 2.2 + 3 * np.sin(yy / 9)).astype(np.float32)
+    my = (yy * 0.9 - 3.1 + 2 * np.cos(xx / 7)).astype(np.float32)
+    mx[5, 7] = np.nan
+    my[9, 3] = np.inf
+    mx[11, 11] = 1e7
+    interps = {'nearest': oracle.NEAREST, 'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS,
+               'cubic_cv': oracle.CUBIC_CV, 'linear_cv_q5': oracle.LINEAR | oracle.Q5,
+               'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5, 'lanczos4': oracle.LANCZOS4}
+    borders = {'constant': oracle.CONSTANT, 'replicate': oracle.REPLICATE,
+               'reflect': oracle.REFLECT, 'wrap': oracle.WRAP, 'reflect101': oracle.REFLECT101}
+    for iname, iid in interps.items():
+        for bname, bid in borders.items():
+            got = ia.ops.remap(img, mx, my, iname, bname, 0.25)
+            want = oracle.remap(img, mx, my, iid, bid, 0.25)
+            close32(got, want, '%s/%s' % (iname, bname), scale=1.0)
+    # float64 images compute in double
+    img64 = img.astype(np.float64)
+    for iname in ('linear', 'cubic', 'lanczos4'):
+        got = ia.ops.remap(img64, mx, my, iname, 'reflect')
+        assert got.dtype == np.float64
+        assert_close(got, oracle.remap(img64, mx, my, interps[iname], oracle.REFLECT), 1e-12, 1e-12,
+                     'f64 ' + iname)
+    # uint16 -> uint16 (round half even) may differ by 1 LSB at exact ties only
+    u16 = rng.integers(0, 4096, (H, W), dtype=np.uint16)
+    got = ia.ops.remap(u16, mx, my, 'linear')
+    want = oracle.remap(u16, mx, my)
+    assert got.dtype == np.uint16
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert (got != want).mean() < 1e-3
+    # uint8 -> float32 ingest
+    u8 = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    close32(ia.ops.remap(u8, mx, my, 'cubic', out_dtype=np.float32),
+            oracle.remap(u8, mx, my, oracle.CUBIC_KEYS, out_dtype=np.float32), 'u8->f32')
+
+
+def test_remap_uint8_bit_exact(ia, oracle):
+    rng = np.random.default_rng(4)
+    H, W = 97, 131
+    u8 = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    mx = (xx + 4 * np.sin(yy / 11) - 1.3).astype(np.float32)
+    my = (yy * 1.02 - 2.7).astype(np.float32)
+    for bname, bid in (('constant', oracle.CONSTANT), ('reflect', oracle.REFLECT),
+                       ('replicate', oracle.REPLICATE)):
+        for cv in (0, 17.6):
+            got = ia.ops.remap(u8, mx, my, 'linear', bname, cv)
+            want = oracle.remap(u8, mx, my, oracle.LINEAR, bid, cv)
+            assert got.dtype == np.uint8 and np.array_equal(got, want), (bname, cv)
+    assert np.array_equal(ia.ops.remap(u8, xx, yy), u8)
+    # "uint8 after rounding" of a float32 result: only exact-tie neighbours may differ
+    f = u8.astype(np.float32)
+    got = np.rint(ia.ops.remap(f, mx, my, 'linear'))
+    want = np.rint(oracle.remap(f, mx, my))
+    assert (got != want).mean() < 2e-3 and np.abs(got - want).max() <= 1
+
+
+def test_known_answers(ia):
+    rng = np.random.default_rng(5)
+    img = rng.random((33, 47)).astype(np.float32)
+    yy, xx = np.mgrid[0:33, 0:47].astype(np.float32)
+    for interp in ('nearest', 'linear', 'cubic', 'cubic_cv', 'lanczos4', 'linear_cv_q5'):
+        assert np.array_equal(ia.ops.remap(img, xx, yy, interp), img), interp
+    got = ia.ops.remap(img, xx + 3, yy - 2, 'linear', 'constant', 7.0)
+    want = np.full_like(img, 7.0)
+    want[2:, :-3] = img[:-2, 3:]
+    assert np.array_equal(got, want)
+    K = np.array([[50., 0, 23], [0, 50., 16], [0, 0, 1]])
+    assert np.array_equal(ia.ops.undistort(img, K, np.zeros(5), K), img)
+    assert np.array_equal(ia.ops.warp_perspective(img, np.eye(3), img.shape), img)
+
+
+def test_warp_perspective_golden(ia, oracle):
+    g = load_golden('warp_skimage.npz')
+    img = g['img']
+    for name in ('quad', 'quadb', 'rot7'):
+        M = g['M_' + name]
+        shp = tuple(int(v) for v in g['shape_' + name])
+        for order, interp in ((1, 'linear'), (3, 'cubic')):
+            for cname, cv in (('c0', 0.0), ('c05', 0.5)):
+                want = g['warp_%s_o%d_%s' % (name, order, cname)]
+                got = ia.ops.warp_perspective(img, M, shp, interp, 'constant', cv)
+                close32(got, want, '%s o%d %s' % (name, order, cname), scale=1.0)
+        got = ia.ops.warp_perspective(img, M, shp, 'linear', 'replicate')
+        close32(got, g['warp_%s_o1_edge' % name], name + ' edge')
+        got64 = ia.ops.warp_perspective(img.astype(np.float64), M, shp, 'cubic', 'constant', 0.5)
+        assert_close(got64, g['warp_%s_o3_c05' % name], 1e-11, 1e-12, name + ' f64')
+        for interp, iid in (('lanczos4', oracle.LANCZOS4), ('cubic_cv_q5', oracle.CUBIC_CV | oracle.Q5)):
+            close32(ia.ops.warp_perspective(img, M, shp, interp),
+                    oracle.warp_perspective(img, M, shp, iid), name + interp, scale=1.0)
+
+
+def test_batch_and_device_arrays(ia, oracle):
+    ctx = ia.default_context(0)
+    n, H, W = 5, 72, 100
+    frames = np.stack([synth((H, W), s) for s in range(n)])
+    K = np.array([[100., 0, 49.5], [0, 100., 35.5], [0, 0, 1]])
+    d = np.array([-0.2, 0.05, 1e-3, 2e-3, 0.01])
+    mx, my = oracle.build_undistort_map(K, d, K, H, W)
+    want = np.stack([oracle.remap(f, mx, my) for f in frames])
+    d_fr = ctx.to_device(frames)
+    dmx, dmy = ia.ops.build_undistort_map(K, d, K, H, W, device=True)
+    got = ia.ops.remap(d_fr, dmx, dmy).get()
+    close32(got, want, 'batch remap', scale=1.0)
+    got = ia.ops.undistort(d_fr, K, d, K).get()
+    close32(got, want, 'batch undistort', scale=1.0)
+    assert np.array_equal(ia.ops.remap(frames, mx, my), ia.ops.remap(d_fr, dmx, dmy).get())
+    # roi window of the maps == crop of the full result
+    full = ia.ops.remap(d_fr, dmx, dmy).get()
+    part = ia.ops.remap(d_fr, dmx, dmy, map_roi=(7, 5, 61, 40)).get()
+    assert np.array_equal(part, full[:, 5:45, 7:68])
+    # uint16 batch -> float32 (C4-style ingest)
+    f16 = np.round(frames * 4095).astype(np.uint16)
+    got = ia.ops.remap(ctx.to_device(f16), dmx, dmy, out_dtype=np.float32).get()
+    want = np.stack([oracle.remap(f, mx, my, out_dtype=np.float32) for f in f16])
+    close32(got, want, 'u16 batch')
+
+
+# -------------------------------------------------------------- filters ----
+def test_conv2d_golden(ia, oracle):
+    g = load_golden('remap_scipy.npz')
+    img = g['img']
+    close32(ia.ops.conv2d(img, np.ones((3, 3)) / 9), g['corr_box3'], 'box3')
+    close32(ia.ops.conv2d(img, g['k7']), g['corr_k7'], 'k7')
+    close32(ia.ops.conv2d(img, g['k11']), g['corr_k11'], 'k11')
+    close32(ia.ops.conv2d(img, g['k5']), oracle.conv2d(img, g['k5']), 'k5')
+    close32(ia.ops.conv2d(img, g['k7'][:3, :]), g['corr_k3x7'], 'k3x7 (generic path)')
+    close32(ia.ops.conv2d(img, g['k7'][:6, :4]), g['corr_k6x4'], 'k6x4 (generic path)')
+    for smode in ('nearest', 'mirror', 'wrap', 'constant'):
+        close32(ia.ops.conv2d(img, g['k7'], smode, cval=0.25), g['corr_k7_' + smode], smode)
+    # 9x9 and per-axis borders against the oracle
+    k9 = np.random.default_rng(9).random((9, 9))
+    k9 /= k9.sum()
+    close32(ia.ops.conv2d(img, k9, 'wrap', mode_y='reflect'),
+            oracle.conv2d(img, k9, 'wrap', mode_y='reflect'), 'k9 wrap-x/reflect-y')
+    # float64
+    i64 = img.astype(np.float64)
+    for k in (g['k5'], g['k7'], g['k11']):
+        assert_close(ia.ops.conv2d(i64, k), oracle.conv2d(i64, k), 1e-12, 1e-13, 'f64 conv')
+
+
+def test_conv2d_shapes_and_masks(ia, oracle):
+    rng = np.random.default_rng(10)
+    for (H, W) in ((1, 1), (3, 5), (31, 33), (32, 128), (33, 129), (130, 70)):
+        img = rng.random((H, W)).astype(np.float32)
+        for K in (3, 5):
+            if K // 2 >= min(H, W) and (H, W) != (1, 1):
+                continue
+            k = rng.random((K, K))
+            got = ia.ops.conv2d(img, k, 'reflect')
+            close32(got, oracle.conv2d(img, k, 'reflect'), 'shape %s k%d' % ((H, W), K))
+    img = synth((70, 90), 1)
+    mask = rng.random((70, 90)) < 0.3
+    k = rng.random((5, 5))
+    got = ia.ops.conv2d(img, k, mask=mask)
+    want = oracle.conv2d(img, k, mask=mask)
+    close32(got, want, 'masked')
+    assert np.all(got[~mask] == 0)
+    # batch
+    fr = np.stack([synth((40, 52), s) for s in range(3)])
+    got = ia.ops.conv2d(fr, k)
+    for i in range(3):
+        close32(got[i], oracle.conv2d(fr[i], k), 'batch %d' % i)
+
+
+def test_masked_convolve_golden(ia):
+    from imgprocessor_amd.filters import maskedConvolve, filter as ipa_filter
+    g = load_golden('masked_convolve.npz')
+    n = 0
+    for key, want in g.items():
+        if not key.startswith('out_'):
+            continue
+        _, im, kn, mk = key.split('_')
+        img = g['img_' + im]
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            got = maskedConvolve(img, g['kernel_' + kn], g['mask_' + mk])
+        h = g['kernel_' + kn].shape[0] // 2
+        assert buf.getvalue().strip() == str((img.shape[0] + 2 * h, img.shape[1] + 2 * h))
+        assert got.dtype == want.dtype
+        if img.dtype == np.float32:
+            close32(got, want, key)
+        else:
+            assert_close(got, want, 1e-12, 1e-13, key)
+        # the identity of SURVEY §8(b)
+        f = ipa_filter(img, np.fft.fftshift(g['kernel_' + kn]))
+        assert np.array_equal(np.where(g['mask_' + mk], f, 0), got)
+        n += 1
+    assert n == 13
+    with contextlib.redirect_stdout(io.StringIO()):
+        got = maskedConvolve(g['selftest_arr'], np.eye(5), g['selftest_mask'])
+    assert_close(got, g['selftest_out'], 1e-12, 1e-13, 'reference selftest (maskedConvolve.py:56-73)')
+    with pytest.raises(Exception):
+        maskedConvolve(g['selftest_arr'], np.eye(5), g['selftest_mask'], mode='wrap')
+
+
+def test_extend_array_golden(ia):
+    from imgprocessor_amd.filters import extendArrayForConvolution
+    g = load_golden('extend_array.npz')
+    arr = g['arr']
+    for key, want in g.items():
+        if not key.startswith('ext_'):
+            continue
+        _, kx, ky, modex = key.split('_')
+        got = extendArrayForConvolution(arr, (int(kx[2:]), int(ky[2:])), modex=modex)
+        assert np.array_equal(got, want), key
+    with pytest.raises(Exception):
+        extendArrayForConvolution(arr, (3, 3), modey='wrap')
+
+
+def test_gaussian_golden(ia, oracle):
+    from imgprocessor_amd.filters import gaussian_filter, box_filter
+    g = load_golden('remap_scipy.npz')
+    img = g['img']
+    for s in (0.5, 1.0, 1.25, 2.0):
+        close32(gaussian_filter(img, s), g['gauss_s%s' % str(s).replace('.', 'p')], 'gauss %s' % s)
+    close32(gaussian_filter(img, (1.0, 2.5)), g['gauss_s1_2p5'], 'gauss (1,2.5)')
+    assert_close(gaussian_filter(img.astype(np.float64), 1.0), g['gauss64_s1'], 1e-12, 1e-13)
+    for mode in ('constant', 'nearest', 'mirror', 'wrap'):
+        k = oracle.gaussian_kernel1d(1.5)
+        close32(ia.ops.sepconv2d(img, k, k, mode, 0.3), oracle.sepconv2d(img, k, k, mode, 0.3),
+                'sep ' + mode)
+    close32(ia.ops.sepconv2d(img, None, oracle.gaussian_kernel1d(2.0)),
+            oracle.sepconv2d(img, None, oracle.gaussian_kernel1d(2.0)), 'x only')
+    close32(box_filter(img, 3), oracle.conv2d(img, np.ones((3, 3)) / 9, 'mirror'), 'cv2.blur 3x3')
+    big = synth((200, 300), 2)
+    close32(gaussian_filter(big, 3.0), oracle.gaussian_filter(big, 3.0), 'sigma 3 (25 taps)')
+
+
+# ---------------------------------------------------------------- fused ----
+def test_fused_chain(ia, oracle):
+    ctx = ia.default_context(0)
+    g = load_golden('remap_scipy.npz')
+    img = g['img']
+    d_img = ctx.to_device(img)
+    mx, my = g['mapx_radial'], g['mapy_radial']
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    got = ia.ops.remap_conv2d(d_img, dmx, dmy, g['k5']).get()
+    close32(got, g['chain_radial_k5'], 'fused vs scipy chain')
+    rng = np.random.default_rng(2)
+    K, d, nK = g['K_strong'], g['dist_strong'], g['newK_strong']
+    M = load_golden('warp_skimage.npz')['M_rot7']
+    for ksz in (3, 5, 7, 9, 11):
+        k = rng.random((ksz, ksz))
+        k /= k.sum()
+        for interp, iid in (('linear', oracle.LINEAR), ('cubic', oracle.CUBIC_KEYS)):
+            for cmode in ('reflect', 'wrap', 'constant'):
+                want = oracle.conv2d(oracle.remap(img, mx, my, iid, oracle.CONSTANT, 0.1), k, cmode)
+                got = ia.ops.remap_conv2d(d_img, dmx, dmy, k, interp, 'constant', 0.1, cmode).get()
+                close32(got, want, 'fused map k%d %s %s' % (ksz, interp, cmode))
+        want = oracle.conv2d(oracle.undistort(img, K, d, nK), k)
+        close32(ia.ops.undistort_conv2d(d_img, K, d, nK, k).get(), want, 'fused undistort k%d' % ksz)
+        want = oracle.conv2d(oracle.warp_perspective(img, M, (80, 100), oracle.CUBIC_KEYS), k)
+        close32(ia.ops.warp_perspective_conv2d(d_img, M, (80, 100), k, 'cubic').get(), want,
+                'fused warp k%d' % ksz)
+    # two launches == one launch
+    two = ia.ops.conv2d(ia.ops.remap(d_img, dmx, dmy), g['k5']).get()
+    close32(ia.ops.remap_conv2d(d_img, dmx, dmy, g['k5']).get(), two, 'fused vs two launches')
+    # uint16 frames -> float32 (C4)
+    d16 = ctx.to_device(g['img16'])
+    k7 = g['k7']
+    want = oracle.conv2d(oracle.remap(g['img16'], mx, my, out_dtype=np.float32), k7)
+    close32(ia.ops.remap_conv2d(d16, dmx, dmy, k7).get(), want, 'fused u16')
+
+
+# ------------------------------------------------------------------ IDW ----
+def test_idw_golden(ia):
+    from imgprocessor_amd.interpolate import (interpolate2dStructuredIDW,
+                                               interpolate2dStructuredFastIDW)
+    from imgprocessor_amd.interpolate.interpolate2dStructuredFastIDW import growPositions
+    g = load_golden('idw.npz')
+    grid = g['grid']
+    n = 0
+    for key, want in g.items():
+        if key.startswith('idw_k'):
+            p = key.split('_')
+            kern, power = int(p[1][1:]), int(p[2][1:])
+            fx, fy = (2, 0.5) if len(p) > 3 else (1, 1)
+            gg = grid.copy()
+            got = interpolate2dStructuredIDW(gg, g['mask_k%d' % kern], kern, power, fx, fy)
+            assert got is gg  # in place, returns the grid
+        elif key.startswith('fidw_k'):
+            p = key.split('_')
+            kern, power, minn = int(p[1][1:]), int(p[2][1:]), int(p[3][1:])
+            got = interpolate2dStructuredFastIDW(grid.copy(), g['mask_k%d' % kern], kern, power, minn)
+        else:
+            continue
+        assert_close(got, want, 1e-12, 1e-14, key)
+        n += 1
+    assert n == 21
+    close32(interpolate2dStructuredIDW(grid.astype(np.float32), g['mask_k5'], 5, 2),
+            g['idw32_k5_p2'], 'idw32')
+    assert_close(interpolate2dStructuredIDW(grid.copy(), g['mask_block'], 3, 2), g['idw_block_k3'],
+                 1e-12)
+    assert_close(interpolate2dStructuredFastIDW(grid.copy(), g['mask_block'], 3, 2, 5),
+                 g['fidw_block_k3'], 1e-12)
+    pos, dist = growPositions(4)
+    assert np.array_equal(pos, g['grow4_pos']) and np.array_equal(dist, g['grow4_dist'])
+
+
+def test_idw_edges_vs_oracle(ia, oracle):
+    from imgprocessor_amd.interpolate import (interpolate2dStructuredIDW,
+                                               interpolate2dStructuredFastIDW)
+    rng = np.random.default_rng(8)
+    for (H, W) in ((40, 150), (65, 64), (7, 9)):
+        grid = rng.random((H, W))
+        mask = rng.random((H, W)) < 0.3  # masked pixels right up to every edge
+        k = 4
+        assert_close(interpolate2dStructuredIDW(grid.copy(), mask, k, 2),
+                     oracle.interpolate2dStructuredIDW(grid.copy(), mask, k, 2), 1e-12, 1e-14)
+        assert_close(interpolate2dStructuredFastIDW(grid.copy(), mask, k, 2, 5),
+                     oracle.interpolate2dStructuredFastIDW(grid.copy(), mask, k, 2, 5), 1e-12, 1e-14)
+
+
+# ------------------------------------------------------- drop-in surface ----
+def test_lens_distortion_class(ia, oracle):
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    H, W = 120, 160
+    img = synth((H, W), 3)
+    fx = fy = 160.0
+    ld = LensDistortion()
+    ld.setCameraParams(fx, fy, 79.5, 59.5, -0.12, 0.03, 0.0, 1e-3, -5e-4)
+    assert ld.getCameraParams() == (fx, fy, 79.5, 59.5, -0.12, 0.03, 0.0, 1e-3, -5e-4)
+    out = ld.correct(img)                      # keepSize=False: cropped to roi
+    xx, yy, ww, hh = ld.roi
+    assert out.shape == (hh, ww) and out is ld.img
+    full = ld.correct(img, keepSize=True)
+    assert full.shape == img.shape
+    assert np.array_equal(out, full[yy:yy + hh, xx:xx + ww])
+    mx, my = ld.getUndistortRectifyMap(W, H)
+    assert mx.dtype == np.float32 and mx.shape == (H, W)
+    assert ld.getUndistortRectifyMap(W, H)[0] is mx  # cached per shape
+    K = np.array([[fx, 0, 79.5], [0, fy, 59.5], [0, 0, 1]])
+    d = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+    omx, omy = oracle.build_undistort_map(K, d, ld.newCameraMatrix, H, W)
+    assert np.array_equal(mx, omx) and np.array_equal(my, omy)
+    close32(full, oracle.remap(img, omx, omy), 'correct', scale=1.0)
+    close32(ld.correct(img, keepSize=True, borderValue=0.5),
+            oracle.remap(img, omx, omy, cval=0.5), 'borderValue', scale=1.0)
+    # colour image = independent channels; uint8 stays uint8
+    rgb = (np.stack([synth((H, W), s) for s in (1, 2, 3)], axis=2) * 255).astype(np.uint8)
+    o = ld.correct(rgb, keepSize=True)
+    assert o.shape == rgb.shape and o.dtype == np.uint8
+    for c in range(3):
+        assert np.array_equal(o[..., c], oracle.remap(np.ascontiguousarray(rgb[..., c]), omx, omy))
+    # distortImage: first-order inverse map as written in the reference
+    posy, posx = np.mgrid[0:H, 0:W].astype(np.float32)
+    close32(ld.distortImage(img), oracle.remap(img, posx + (posx - omx), posy + (posy - omy)),
+            'distortImage', scale=1.0)
+    # undistort then re-distort is close to identity in the interior (approximate inverse)
+    rt = ld.distortImage(ld.correct(img, keepSize=True))
+    assert np.abs(rt - img)[30:-30, 30:-30].mean() < 0.04
+    # zero distortion, newK = K -> identity
+    ld0 = LensDistortion(newCameraMatrix='same')
+    ld0.setCameraParams(fx, fy, 79.5, 59.5, 0, 0, 0, 0, 0)
+    assert np.array_equal(ld0.correct(img, keepSize=True), img)
+    # device arrays stay on the device
+    ctx = ia.default_context(0)
+    d_out = ld.correct(ctx.to_device(img), keepSize=True)
+    assert isinstance(d_out, ia.DeviceArray) and np.array_equal(d_out.get(), full)
+
+
+def test_perspective_correction_class(ia, oracle, capsys):
+    from imgprocessor_amd.camera.PerspectiveCorrection import PerspectiveCorrection
+    g = load_golden('warp_skimage.npz')
+    img = g['img']
+    quad = np.array([(8, 2), (120, 6), (122, 90), (5, 93)], float)
+    pc = PerspectiveCorrection(img.shape, new_size=(96, 128))
+    pc.setReference(quad[[2, 0, 3, 1]])  # any order: corners are sorted
+    assert_close(pc.homography, g['H_quad'], 1e-9, 1e-9, 'homography')
+    out = pc.correct(img)
+    assert 'CORRECT PERSPECTIVE' in capsys.readouterr().out
+    assert out.shape == (96, 128)
+    Minv = np.linalg.inv(pc.homography)
+    close32(out, oracle.warp_perspective(img, Minv, (96, 128), oracle.LANCZOS4), 'lanczos4',
+            scale=1.0)
+    pcl = PerspectiveCorrection(img.shape, new_size=(96, 128), interpolation='linear')
+    pcl.setReference(quad)
+    close32(pcl.correct(img), g['warp_quad_o1_c0'], 'linear vs skimage', scale=1.0)
+    pcb = PerspectiveCorrection(img.shape, new_size=(80, 100), border=7, interpolation='cubic')
+    pcb.setReference(quad)
+    close32(pcb.correct(img), g['warp_quadb_o3_c0'], 'border=7 cubic vs skimage', scale=1.0)
+    # uncorrect: INTER_CUBIC | WARP_INVERSE_MAP
+    un = pc.uncorrect(out)
+    assert un.shape == out.shape
+    close32(un, oracle.warp_perspective(out, pc.homography, out.shape,
+                                        oracle.CUBIC_CV | oracle.Q5), 'uncorrect', scale=1.0)
+    # round trip correct -> uncorrect is close to the original inside the quad
+    assert np.abs(un - img)[20:-20, 20:-20].mean() < 0.03
+    pts = pc.correctPoints(quad)
+    assert_close(pts[0], [[0, 0], [128, 0], [128, 96], [0, 96]], 0, 1e-3)
+    pch = PerspectiveCorrection(img.shape, new_size=(96, 128), interpolation='linear')
+    pch.setReference(g['H_rot7'])
+    close32(pch.correct(img), g['warp_rot7_o1_c0'], 'explicit homography', scale=1.0)
+
+
+def test_rotate_roundtrip_bound(ia):
+    """the reference's own check, transform/rotate.py:26-32: a 50x50 ramp rotated by +14 deg
+    then -14 deg (INTER_CUBIC, BORDER_REFLECT, about the image centre) stays within 0.005"""
+    a = np.tile(np.linspace(0, 1, 50), (50, 1))
+
+    def rotate(img, angle):
+        s0, s1 = img.shape
+        cx, cy = (s0 - 1) / 2., (s1 - 1) / 2.
+        t = np.deg2rad(angle)
+        al, be = np.cos(t), np.sin(t)  # cv2.getRotationMatrix2D
+        M = np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy],
+                      [0, 0, 1.]])
+        return ia.ops.warp_perspective(img, np.linalg.inv(M), img.shape, 'cubic_cv_q5', 'reflect')
+    for dt in (np.float64, np.float32):
+        c = rotate(rotate(a.astype(dt), 14), -14)
+        assert np.abs(a - c).mean() < 0.005
+
+
+def test_errors(ia):
+    img = np.zeros((8, 8), np.float32)
+    with pytest.raises(ValueError):
+        ia.ops.remap(img, np.zeros((4, 4), np.float32), np.zeros((4, 5), np.float32))
+    with pytest.raises(ValueError):
+        ia.ops.remap(img, np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32), 'bogus')
+    with pytest.raises(TypeError):
+        ia.ops.remap(img.astype(np.int32), np.zeros((4, 4), np.float32), np.zeros((4, 4), np.float32))
+    with pytest.raises(NotImplementedError):
+        ia.ops.remap(img.astype(np.float64), np.zeros((4, 4), np.float32),
+                     np.zeros((4, 4), np.float32), out_dtype=np.float32)
+    with pytest.raises(ValueError):
+        ia.ops.undistort(img, np.eye(3), np.zeros(5), np.zeros((3, 3)))  # singular newK

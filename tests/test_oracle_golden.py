@@ -218,17 +218,17 @@ def test_known_answers(oracle):
     yy2, xx2 = np.mgrid[0:20, 0:20].astype(np.float32)
     got = oracle.remap(c, xx2 * 0.5 + 5.3, yy2 * 0.5 + 5.1, oracle.LANCZOS4)
     assert_close(got, c, 1e-6)
-    # rotate +14 then -14 deg (transform/rotate.py:26-32 bound: mean|a-c| < 0.005 on a smooth image)
-    H_, W_ = 120, 160
-    y, x = np.mgrid[0:H_, 0:W_]
-    smooth = (0.5 + 0.5 * np.sin(x / 19.0) * np.cos(y / 23.0)).astype(np.float32)
+    # the reference's own check (transform/rotate.py:26-32): 50x50 ramp, +14 deg then -14 deg,
+    # INTER_CUBIC + BORDER_REFLECT about the centre, mean |a-c| < 0.005
+    a = np.tile(np.linspace(0, 1, 50), (50, 1))
 
-    def rot(a, deg):
-        t = np.deg2rad(deg)
-        cx, cy = (W_ - 1) / 2, (H_ - 1) / 2
-        R = np.array([[np.cos(t), np.sin(t), 0], [-np.sin(t), np.cos(t), 0], [0, 0, 1.]])
-        T = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.]])
-        M = T @ R @ np.linalg.inv(T)
-        return oracle.warp_perspective(a, M, a.shape, oracle.CUBIC_CV, oracle.REFLECT)
-    back = rot(rot(smooth, 14), -14)
-    assert np.abs(back - smooth)[20:-20, 20:-20].mean() < 0.005
+    def rotate(img, angle):
+        s0, s1 = img.shape
+        cx, cy = (s0 - 1) / 2., (s1 - 1) / 2.
+        t = np.deg2rad(angle)
+        al, be = np.cos(t), np.sin(t)  # cv2.getRotationMatrix2D
+        M = np.array([[al, be, (1 - al) * cx - be * cy], [-be, al, be * cx + (1 - al) * cy],
+                      [0, 0, 1.]])
+        return oracle.warp_perspective(img, np.linalg.inv(M), img.shape,
+                                       oracle.CUBIC_CV | oracle.Q5, oracle.REFLECT)
+    assert np.abs(a - rotate(rotate(a, 14), -14)).mean() < 0.005
