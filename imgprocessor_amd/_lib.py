@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libimgproc_hip.so')
+# IMGPROC_HIP_LIB selects another build of the SAME library (tuning A/B variants)
+LIB_PATH = os.environ.get('IMGPROC_HIP_LIB') or os.path.join(_HERE, 'libimgproc_hip.so')
 
 # enums of include/imgproc_hip.h
 U8, U16, F32, F64 = 0, 1, 2, 3

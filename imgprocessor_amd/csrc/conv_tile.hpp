@@ -62,6 +62,27 @@ __device__ __forceinline__ void load_window(const CT* __restrict__ p, CT (&win)[
   }
 }
 
+// one input row (window `win`, tile-relative row r) feeds the up-to-4 output
+// rows oy with kernel row i = r - oy; r is wave-uniform -> scalar weight loads
+template <typename CT, int KH, int KW>
+__device__ __forceinline__ void conv_row(const CT (&win)[conv_geom<KW>::NW], int r,
+                                         const Weights<CT, KH * KW>& wts, CT (&acc)[4][4]) {
+  using G = conv_geom<KW>;
+#pragma unroll
+  for (int oy = 0; oy < 4; oy++) {
+    const int i = r - oy;
+    if (i >= 0 && i < KH) {
+#pragma unroll
+      for (int j = 0; j < KW; j++) {
+        CT w = wts.w[i * KW + j];
+#pragma unroll
+        for (int ox = 0; ox < 4; ox++)
+          acc[oy][ox] = ipa_fma(w, win[G::OFF + ox + j], acc[oy][ox]);
+      }
+    }
+  }
+}
+
 // Correlate the LDS tile; acc[oy][ox] for the thread's 4x4 micro-tile.
 template <typename CT, int KH, int KW>
 __device__ __forceinline__ void conv_from_lds(const CT* __restrict__ tile, int tx, int ty,
@@ -72,28 +93,18 @@ __device__ __forceinline__ void conv_from_lds(const CT* __restrict__ tile, int t
 #pragma unroll
     for (int ox = 0; ox < 4; ox++) acc[oy][ox] = (CT)0;
 
+  static_assert((4 + KH - 1) % 2 == 0, "odd KH only: the row loop is unrolled by two");
   const CT* base = tile + (ty * 4) * G::LW + tx * 4;
-  CT cur[G::NW], nxt[G::NW];
-  load_window<CT, G::NW>(base, cur);
+  CT wa[G::NW], wb[G::NW];  // ping-pong row windows: no register copies between rows
+  load_window<CT, G::NW>(base, wa);
 #pragma unroll 1
-  for (int r = 0; r < 4 + KH - 1; r++) {
-    // prefetch the next input row (the tile has one spare row of slack: see lds_rows)
-    load_window<CT, G::NW>(base + (r + 1) * G::LW, nxt);
-#pragma unroll
-    for (int oy = 0; oy < 4; oy++) {
-      const int i = r - oy;  // kernel row feeding output row oy from input row r (wave-uniform)
-      if (i >= 0 && i < KH) {
-#pragma unroll
-        for (int j = 0; j < KW; j++) {
-          CT w = wts.w[i * KW + j];
-#pragma unroll
-          for (int ox = 0; ox < 4; ox++)
-            acc[oy][ox] = ipa_fma(w, cur[G::OFF + ox + j], acc[oy][ox]);
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < G::NW; k++) cur[k] = nxt[k];
+  for (int r = 0; r < 4 + KH - 1; r += 2) {
+    // prefetch the next input row while the current one is consumed (the tile
+    // has one spare row of slack for the last prefetch: see lds_rows)
+    load_window<CT, G::NW>(base + (r + 1) * G::LW, wb);
+    conv_row<CT, KH, KW>(wa, r, wts, acc);
+    load_window<CT, G::NW>(base + (r + 2) * G::LW, wa);
+    conv_row<CT, KH, KW>(wb, r + 1, wts, acc);
   }
 }
 

@@ -7,8 +7,6 @@ using namespace ipa;
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
-int ipa_fused_launch_k9(ipa_ctx*, const FusedCall&);
-int ipa_fused_launch_k11(ipa_ctx*, const FusedCall&);
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
 static int inv3f(const double* m, double* o) {
@@ -21,6 +19,19 @@ static int inv3f(const double* m, double* o) {
   o[3] = B * id; o[4] = (a * i - c * g) * id;  o[5] = -(a * f - c * d) * id;
   o[6] = C * id; o[7] = -(a * h - b * g) * id; o[8] = (a * e - b * d) * id;
   return 0;
+}
+
+// K >= 9: the register-resident wave stencil does not fit (81 / 121 coefficients
+// + 9 / 11 running rows); run the chain as two launches through the context
+// workspace: remap kernel -> LDS-tiled filter.
+static int big_kernel_tmp(ipa_ctx* ctx, int kh, int kw, int dst_dtype, int dh, int dw, int n_frames,
+                          void** tmp) {
+  if (kh != kw || !(kh == 9 || kh == 11)) return 1;  // not the two-launch case
+  IPA_REQUIRE(ctx, dst_dtype == IPA_F32, "fused remap+filter writes float32");
+  int rc = ipa_ws_reserve(ctx, (size_t)n_frames * dh * dw * 4);
+  if (rc) return rc;
+  *tmp = ctx->ws;
+  return IPA_OK;
 }
 
 static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
@@ -44,22 +55,26 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   size_t frame_bytes = ((size_t)(sh - 1) * src_pitch + sw) * ss;
   IPA_REQUIRE(ctx, frame_bytes < (1ull << 31), "source frame too large for 32-bit offsets");
   int base = interp & 0xff;
-  FusedParams& p = f.p;
-  p.src = (const char*)d_src; p.dst = (char*)d_dst;
-  p.src_frame_bytes = src_frame_stride * (long)ss;
+  WaveParams& p = f.p;
+  p.dst = (char*)d_dst;
   p.dst_frame_elems = dst_frame_stride;
-  p.src_bytes = (unsigned)frame_bytes;
-  p.sh = sh; p.sw = sw; p.spitch = (int)src_pitch;
   p.dh = dh; p.dw = dw; p.dpitch = dst_pitch;
-  p.border = border_mode; p.q5 = (interp & IPA_INTER_Q5) ? 1 : 0;
-  p.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
-  p.lanczos = nullptr;
-  p.cval = border_value;
-  p.cbx = cbx; p.cby = cby; p.conv_cval = 0.0;
-  p.tiles_x = (unsigned)((dw + kTileW - 1) / kTileW);
-  p.tiles = p.tiles_x * (unsigned)((dh + kTileH - 1) / kTileH);
+  p.cbx = cbx; p.cby = cby;
   p.vec_out = (((uintptr_t)d_dst) % 16 == 0) && ((dst_pitch * (long)ds) % 16 == 0) &&
               (n_frames == 1 || (dst_frame_stride * (long)ds) % 16 == 0);
+  f.src = (const char*)d_src;
+  f.src_frame_bytes = src_frame_stride * (long)ss;
+  f.src_bytes = (unsigned)frame_bytes;
+  f.sh = sh; f.sw = sw; f.spitch = (int)src_pitch;
+  f.border = border_mode; f.q5 = (interp & IPA_INTER_Q5) ? 1 : 0;
+  f.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
+  f.cval = border_value;
+  f.conv_cval = 0.0;
+  if (f.coord_kind == 0)
+    f.map_vec = (((uintptr_t)f.map.mx) % 16 == 0) && (((uintptr_t)f.map.my) % 16 == 0) &&
+                ((f.map.pitch * 4) % 16 == 0);
+  else
+    f.map_vec = 0;
   f.src_dt = src_dtype; f.dst_dt = dst_dtype; f.interp_base = base; f.n_frames = n_frames;
   f.kernel = kernel;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
@@ -67,8 +82,7 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;
     case 5: rc = ipa_fused_launch_k5(ctx, f); break;
     case 7: rc = ipa_fused_launch_k7(ctx, f); break;
-    case 9: rc = ipa_fused_launch_k9(ctx, f); break;
-    default: rc = ipa_fused_launch_k11(ctx, f); break;
+    default: rc = ipa_fused_launch_k7(ctx, f); break;
   }
   if (rc) return rc;
   IPA_HIP(ctx, hipGetLastError());
@@ -85,6 +99,18 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
                          int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  void* tmp = nullptr;
+  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  if (big < 0) return big;
+  if (big == 0) {
+    int rc = ipa_remap_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, tmp,
+                           IPA_F32, dh, dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
+                           border_mode, border_value);
+    if (rc) return rc;
+    return ipa_conv2d_dev(ctx, tmp, IPA_F32, dh, dw, dw, kernel, kh, kw, nullptr, 0, d_dst,
+                          dst_pitch, n_frames, (long)dh * dw, dst_frame_stride, conv_border_x,
+                          conv_border_y, 0.0);
+  }
   FusedCall f;
   f.coord_kind = 0;
   f.map = MapCoord{d_mapx, d_mapy, map_pitch};
@@ -102,6 +128,18 @@ int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                              int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  void* tmp = nullptr;
+  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  if (big < 0) return big;
+  if (big == 0) {
+    int rc = ipa_undistort_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, tmp,
+                               IPA_F32, dh, dw, dw, n_frames, src_frame_stride, (long)dh * dw,
+                               interp, border_mode, border_value);
+    if (rc) return rc;
+    return ipa_conv2d_dev(ctx, tmp, IPA_F32, dh, dw, dw, kernel, kh, kw, nullptr, 0, d_dst,
+                          dst_pitch, n_frames, (long)dh * dw, dst_frame_stride, conv_border_x,
+                          conv_border_y, 0.0);
+  }
   FusedCall f;
   f.coord_kind = 1;
   UndistortCoord& c = f.und;
@@ -122,6 +160,18 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
                                     double border_value, int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, M, "null matrix");
+  void* tmp = nullptr;
+  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  if (big < 0) return big;
+  if (big == 0) {
+    int rc = ipa_warp_perspective_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, tmp, IPA_F32, dh,
+                                      dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
+                                      border_mode, border_value);
+    if (rc) return rc;
+    return ipa_conv2d_dev(ctx, tmp, IPA_F32, dh, dw, dw, kernel, kh, kw, nullptr, 0, d_dst,
+                          dst_pitch, n_frames, (long)dh * dw, dst_frame_stride, conv_border_x,
+                          conv_border_y, 0.0);
+  }
   FusedCall f;
   f.coord_kind = 2;
   for (int i = 0; i < 9; i++) f.hom.m[i] = M[i];

@@ -118,9 +118,20 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     for (int k = 0; k < 4; k++) out[k] = k < n ? sample_u8_fixed(s, sx[k], sy[k], cv8) : 0;
   } else {
     CT cval = (CT)p.cval;
+    constexpr int BN = batch_of<INTERP>::value;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      out[k] = k < n ? store_cast<DT, CT>(sample<ST, INTERP>(s, sx[k], sy[k], cval)) : (DT)0;
+    for (int b = 0; b < 4; b += BN) {
+      typename Coord::coord_t bx[BN], by[BN];
+      CT o[BN];
+#pragma unroll
+      for (int j = 0; j < BN; j++) {
+        bx[j] = sx[b + j];  // lanes past the row end carry (0,0): a harmless interior sample
+        by[j] = sy[b + j];
+      }
+      sample_batch<ST, INTERP, BN>(s, bx, by, cval, o);
+#pragma unroll
+      for (int j = 0; j < BN; j++) out[b + j] = store_cast<DT, CT>(o[j]);
+    }
   }
   DT* row = reinterpret_cast<DT*>(p.dst) + (long)frame * p.dst_frame_elems + (long)y * p.dpitch;
   store4<DT>(row, x0, out, n, p.dst_vec);

@@ -219,6 +219,143 @@ __device__ __forceinline__ typename compute_of<ST>::type sample(const SrcView& s
   return out;
 }
 
+// N samples at once, laid out for memory-level parallelism: the tap loads of
+// the WHOLE batch are issued back to back (range-checked buffer loads cannot
+// fault, so they are issued unconditionally at a clamped offset) before any
+// value is consumed; only then are they blended.  Footprints that touch the
+// image border (rare) are redone through sample().  Same arithmetic and
+// summation order as sample(): results are bit-identical.
+template <typename ST, int INTERP, int N, typename C>
+__device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N], const C (&sy)[N],
+                                             typename compute_of<ST>::type cval,
+                                             typename compute_of<ST>::type (&out)[N]) {
+  using CT = typename compute_of<ST>::type;
+  constexpr int NT = ntaps<INTERP>::value;
+  int e[N];
+  bool interior[N];
+  CT wx[N][NT], wy[N][NT];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    bool ok = sx[k] > (C)-kCoordLimit && sx[k] < (C)kCoordLimit && sy[k] > (C)-kCoordLimit &&
+              sy[k] < (C)kCoordLimit;
+    int ix0, iy0;
+    axis_split<INTERP, CT, C>(s, ok ? sx[k] : (C)0, ix0, wx[k]);
+    axis_split<INTERP, CT, C>(s, ok ? sy[k] : (C)0, iy0, wy[k]);
+    interior[k] = ok && ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
+    e[k] = interior[k] ? iy0 * s.pitch + ix0 : 0;
+  }
+  CT v[N][NT][NT];
+#pragma unroll
+  for (int k = 0; k < N; k++)
+#pragma unroll
+    for (int r = 0; r < NT; r++) TapLoad<ST, CT>::template row<NT>(s, e[k] + r * s.pitch, v[k][r]);
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    CT o = (CT)0;
+#pragma unroll
+    for (int r = 0; r < NT; r++) {
+      CT rs = wx[k][0] * v[k][r][0];
+#pragma unroll
+      for (int c = 1; c < NT; c++) rs = ipa_fma(wx[k][c], v[k][r][c], rs);
+      o = r == 0 ? wy[k][0] * rs : ipa_fma(wy[k][r], rs, o);
+    }
+    out[k] = o;
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++)
+    if (!interior[k]) out[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+}
+
+// ---- split form of sample_batch for software-pipelined callers (wave_stencil.hpp):
+// batch_issue() computes the footprints and ISSUES every tap load of the batch,
+// batch_blend() (called later, after more loads were queued) consumes them.
+// Only the fractions are kept between the two halves; bilinear / bicubic only.
+template <typename ST, int INTERP, int N> struct BatchTaps {
+  using CT = typename compute_of<ST>::type;
+  static constexpr int NT = ntaps<INTERP>::value;
+  CT v[N][NT][NT];
+  CT tx[N], ty[N];
+  unsigned interior;  // bit k: footprint k fully inside the source
+};
+
+template <int INTERP, typename CT, typename C>
+__device__ __forceinline__ void axis_frac(const SrcView& s, C c, int& i0, CT& t) {
+  int ip;
+  if (s.q5) {
+    int qi = (int)ipa_rint(c * (C)32);
+    ip = qi >> 5;
+    t = (CT)(qi & 31) * (CT)0.03125;
+  } else {
+    C fl = ipa_floor(c);
+    ip = (int)fl;
+    if constexpr (sizeof(CT) > sizeof(C)) t = (CT)c - (CT)fl;
+    else t = (CT)(c - fl);
+  }
+  i0 = INTERP == kLinear ? ip : ip - 1;
+}
+
+template <int INTERP, typename CT>
+__device__ __forceinline__ void weights_from_frac(const SrcView& s, CT t,
+                                                  CT (&w)[ntaps<INTERP>::value]) {
+  if constexpr (INTERP == kLinear) {
+    w[0] = (CT)1 - t;
+    w[1] = t;
+  } else {
+    cubic_weights<CT>(t, (CT)s.cubic_a, w);
+  }
+}
+
+template <typename ST, int INTERP, int N, typename C>
+__device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], const C (&sy)[N],
+                                            BatchTaps<ST, INTERP, N>& b) {
+  using CT = typename compute_of<ST>::type;
+  constexpr int NT = ntaps<INTERP>::value;
+  static_assert(INTERP == kLinear || INTERP == kCubic, "split sampling: bilinear/bicubic only");
+  b.interior = 0;
+  int e[N];
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    bool ok = sx[k] > (C)-kCoordLimit && sx[k] < (C)kCoordLimit && sy[k] > (C)-kCoordLimit &&
+              sy[k] < (C)kCoordLimit;
+    int ix0, iy0;
+    axis_frac<INTERP, CT, C>(s, ok ? sx[k] : (C)0, ix0, b.tx[k]);
+    axis_frac<INTERP, CT, C>(s, ok ? sy[k] : (C)0, iy0, b.ty[k]);
+    bool in = ok && ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
+    b.interior |= in ? (1u << k) : 0u;
+    e[k] = in ? iy0 * s.pitch + ix0 : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < N; k++)
+#pragma unroll
+    for (int r = 0; r < NT; r++)
+      TapLoad<ST, CT>::template row<NT>(s, e[k] + r * s.pitch, b.v[k][r]);
+}
+
+// blend footprint k of an issued batch (same arithmetic / order as sample())
+template <typename ST, int INTERP, int N>
+__device__ __forceinline__ typename compute_of<ST>::type batch_blend_one(
+    const SrcView& s, const BatchTaps<ST, INTERP, N>& b, int k) {
+  using CT = typename compute_of<ST>::type;
+  constexpr int NT = ntaps<INTERP>::value;
+  CT wx[NT], wy[NT];
+  weights_from_frac<INTERP, CT>(s, b.tx[k], wx);
+  weights_from_frac<INTERP, CT>(s, b.ty[k], wy);
+  CT o = (CT)0;
+#pragma unroll
+  for (int r = 0; r < NT; r++) {
+    CT rs = wx[0] * b.v[k][r][0];
+#pragma unroll
+    for (int c = 1; c < NT; c++) rs = ipa_fma(wx[c], b.v[k][r][c], rs);
+    o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+  }
+  return o;
+}
+
+// batch width per interpolation: bounded by the tap registers (N * NT^2)
+template <int INTERP> struct batch_of { static constexpr int value = 4; };
+template <> struct batch_of<kCubic> { static constexpr int value = 2; };
+template <> struct batch_of<kLanczos4> { static constexpr int value = 1; };
+
 // cv2's uint8 bilinear: q5 coordinates, exact 15-bit integer weights
 // ((32-fx)(32-fy)*32 ...), rounded shift.  Integer arithmetic: bit-exact.
 template <typename C>

@@ -1,0 +1,397 @@
+// wave_stencil.hpp — the K x K stencil skeleton tuned for CDNA4: a wave64
+// marches down a column strip, no LDS, no barriers.
+//
+//   * one wave owns a strip 256 px wide (64 lanes x 4 px: every global access
+//     is a coalesced 16-byte-per-lane vector) and `strip_h` output rows tall;
+//   * it walks the strip's strip_h + K - 1 input rows top to bottom in CHUNKS
+//     of D rows.  All memory traffic of a chunk is issued up front in straight-
+//     line code (D row loads; for the fused kernels D map-row loads, then the
+//     4 x D tap gathers), only then are the rows consumed one by one — so the
+//     waitcnt scoreboard sees counted waits and every wave keeps D KB (plus
+//     8 D gathers) in flight; 12-16 waves per CU cover the HBM latency without
+//     any workgroup-level staging phase;
+//   * horizontal neighbours come from the adjacent lanes with DPP wave shifts
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1) — a K/2-px exchange per row
+//     instead of an LDS round trip;
+//   * vertical reuse is in registers: an arriving input row is scattered into
+//     the K output rows it contributes to (K x 4 running sums per lane, shifted
+//     by one row per step inside the fma chain itself); the oldest row is
+//     complete after each step and is stored as one float4.
+//     Strips overlap by 8*HL px (HL = halo lanes per side) instead of loading
+//     ragged halos: lanes 0 and 63 (0,1,62,63 for K = 11) only supply
+//     neighbours.
+//
+// Input rows are produced by a row source: plain image rows (the filters/
+// convolution) or remapped rows sampled on the fly (undistort / perspective
+// warp fused with the filter: the intermediate image never exists in HBM).
+//
+// Two code paths per kernel, chosen per strip (wave-uniform):
+//   FAST  every column and row the strip touches lies inside the image and
+//         vector alignment holds: unconditional 16-byte accesses;
+//   rim   strips touching the image border: columns / rows are resolved
+//         through the FILTER's border mode (per lane once, per row on the
+//         scalar unit), element accesses with selects instead of branches.
+//
+// Summation order per output pixel is identical to conv_tile.hpp: kernel rows
+// i = 0..K-1, taps j = 0..K-1, one float fma chain -> bit-identical results.
+//
+// Reference semantics: filters/maskedConvolve.py:24-43 + scipy.ndimage.correlate
+// (filter), camera/LensDistortion.py:323-326 and
+// camera/PerspectiveCorrection.py:401-405 followed by a K x K filter (fused).
+#pragma once
+
+#include <type_traits>
+
+#include "common.hpp"
+#include "conv_tile.hpp"
+#include "sampler.hpp"
+
+namespace ipa {
+
+// lane i <- lane i-1 (lane 0 keeps its own value)
+__device__ __forceinline__ float from_lane_below(float v) {
+  int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x138 /*wave_shr:1*/, 0xf, 0xf, false));
+}
+// lane i <- lane i+1 (lane 63 keeps its own value)
+__device__ __forceinline__ float from_lane_above(float v) {
+  int i = __float_as_int(v);
+  return __int_as_float(__builtin_amdgcn_update_dpp(i, i, 0x130 /*wave_shl:1*/, 0xf, 0xf, false));
+}
+
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+template <int K> struct wave_geom {
+  static constexpr int H = K / 2;
+  static constexpr int HL = (H + 3) / 4;     // halo lanes per side
+  static constexpr int OW = 256 - 8 * HL;    // output pixels per strip row
+  static constexpr int NW = 4 + 2 * H;       // window a lane needs per row
+};
+
+struct WaveParams {
+  char* dst;
+  long dst_frame_elems;
+  int dh, dw;          // filter domain == output size
+  long dpitch;
+  int cbx, cby;        // filter border mode per axis
+  int strips_x, strip_h;
+  unsigned strips;     // per frame
+  int vec_out;
+};
+
+// columns of the filter domain a lane covers, resolved once per strip
+struct Cols {
+  int xo;       // first column (may be < 0 or >= dw for halo lanes at the rim)
+  int uu[4];    // border-resolved column per pixel, -1 = constant border
+};
+
+// ---------------------------------------------------------------- row sources --
+// load_chunk<FAST, D>() issues the memory traffic of D consecutive rows
+// (vv[d] = border-resolved row, -1 = constant border; never -1 when FAST);
+// row<FAST, D>(d) turns row d of the chunk into the lane's 4 pixels.
+
+// plain float32 image rows
+struct LoadRowSrc {
+#ifndef IPA_LOAD_DEPTH
+#define IPA_LOAD_DEPTH 8
+#endif
+  template <int K> struct depth { static constexpr int value = K >= 9 ? 4 : IPA_LOAD_DEPTH; };
+  template <int D> struct Chunk { float v[D][4]; };
+  const float* base;   // frame 0
+  long frame_elems, pitch;
+  int vec_in;
+  float cval;          // filter border value
+  __device__ __forceinline__ void set_frame(unsigned f) { base += (long)f * frame_elems; }
+  __device__ __forceinline__ bool vectors_ok() const { return vec_in != 0; }
+
+  template <bool FAST, int D>
+  __device__ __forceinline__ void load_chunk(const Cols& c, const int (&vv)[D],
+                                             Chunk<D>& ch) const {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      if constexpr (FAST) {
+        float4 q = *reinterpret_cast<const float4*>(base + (long)vv[d] * pitch + c.xo);
+        ch.v[d][0] = q.x; ch.v[d][1] = q.y; ch.v[d][2] = q.z; ch.v[d][3] = q.w;
+      } else {
+        const float* row = base + (long)(vv[d] < 0 ? 0 : vv[d]) * pitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          float v = row[c.uu[k] < 0 ? 0 : c.uu[k]];
+          ch.v[d][k] = (vv[d] < 0 || c.uu[k] < 0) ? cval : v;
+        }
+      }
+    }
+  }
+  template <bool FAST, int D>
+  __device__ __forceinline__ void row(const Cols&, const int (&)[D], const Chunk<D>& ch, int d,
+                                      float (&cur)[4]) const {
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = ch.v[d][k];
+  }
+};
+
+// rows of the remapped image, sampled on the fly
+template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
+  using C = typename Coord::coord_t;
+  static constexpr bool kMap = std::is_same<Coord, MapCoord>::value;
+#ifndef IPA_SAMPLE_DEPTH
+#define IPA_SAMPLE_DEPTH 2
+#endif
+  template <int K> struct depth {
+    static constexpr int value = INTERP == kLinear ? IPA_SAMPLE_DEPTH : 1;
+  };
+  template <int D> struct Chunk { BatchTaps<ST, INTERP, 4> t[D]; };
+
+  Coord coord;
+  const char* src;       // frame 0 of the remap source
+  long src_frame_bytes;
+  unsigned src_bytes;
+  int sh, sw, spitch;
+  int border, q5;
+  float cubic_a;
+  const float* lanczos;
+  float cval;            // remap border value
+  float ccval;           // filter border value
+  int map_vec;
+  SrcView s;             // built by set_frame
+
+  __device__ __forceinline__ void set_frame(unsigned f) {
+    s.rsrc = make_rsrc(src + (long)f * src_frame_bytes, src_bytes);
+    s.h = sh; s.w = sw; s.pitch = spitch;
+    s.border = border; s.q5 = q5; s.cubic_a = cubic_a; s.lanczos = lanczos;
+  }
+  __device__ __forceinline__ bool vectors_ok() const { return !kMap || map_vec != 0; }
+
+  template <bool FAST>
+  __device__ __forceinline__ void coords_of_row(const Cols& c, int vv, C (&sx)[4],
+                                                C (&sy)[4]) const {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if constexpr (FAST) coord.get(c.xo + k, vv, sx[k], sy[k]);
+      else coord.get(c.uu[k] < 0 ? 0 : c.uu[k], vv < 0 ? 0 : vv, sx[k], sy[k]);
+    }
+  }
+
+  template <bool FAST, int D>
+  __device__ __forceinline__ void load_chunk(const Cols& c, const int (&vv)[D],
+                                             Chunk<D>& ch) const {
+    C sx[D][4], sy[D][4];
+    if constexpr (kMap && FAST) {
+      float4 a[D], b[D];  // stage A: every map row of the chunk first
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        long o = (long)vv[d] * coord.pitch + c.xo;
+        a[d] = *reinterpret_cast<const float4*>(coord.mx + o);
+        b[d] = *reinterpret_cast<const float4*>(coord.my + o);
+      }
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        sx[d][0] = a[d].x; sx[d][1] = a[d].y; sx[d][2] = a[d].z; sx[d][3] = a[d].w;
+        sy[d][0] = b[d].x; sy[d][1] = b[d].y; sy[d][2] = b[d].z; sy[d][3] = b[d].w;
+      }
+    } else {
+#pragma unroll
+      for (int d = 0; d < D; d++) coords_of_row<FAST>(c, vv[d], sx[d], sy[d]);
+    }
+    // stage B: footprints + all tap gathers of the chunk
+#pragma unroll
+    for (int d = 0; d < D; d++) batch_issue<ST, INTERP, 4>(s, sx[d], sy[d], ch.t[d]);
+  }
+
+  template <bool FAST, int D>
+  __device__ __forceinline__ void row(const Cols& c, const int (&vv)[D], const Chunk<D>& ch,
+                                      int d, float (&cur)[4]) const {
+#pragma unroll
+    for (int k = 0; k < 4; k++) cur[k] = batch_blend_one<ST, INTERP, 4>(s, ch.t[d], k);
+    if (ch.t[d].interior != 0xfu) {
+      // footprints touching the source border (rare): redo them tap by tap
+      C sx[4], sy[4];
+      coords_of_row<FAST>(c, vv[d], sx, sy);
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (!((ch.t[d].interior >> k) & 1u)) cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+    }
+    if constexpr (!FAST) {
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (vv[d] < 0 || c.uu[k] < 0) cur[k] = ccval;
+    }
+  }
+};
+
+// -------------------------------------------------------------------- kernel --
+// a zero the optimiser cannot see through: added to the LDS index of a
+// coefficient it keeps the reads inside the row loop (big kernels: 81/121
+// coefficients fit neither the SGPR file nor, hoisted, the VGPR budget)
+__device__ __forceinline__ int opaque_zero_after(float dep) {
+  int z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(dep));
+  return z;
+}
+
+template <bool FAST, typename Src, int K>
+__device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
+                                               const Weights<float, K * K>& wts,
+                                               const float* wl, const Cols& c, int y0, int nrows,
+                                               bool writer, float* dst) {
+  using G = wave_geom<K>;
+  constexpr int D = Src::template depth<K>::value;
+  const int T = nrows + K - 1;  // input rows of this strip
+
+  // acc[i] = running sums of output row (t - i) after input row t was added
+  float acc[K][4];
+#pragma unroll 1
+  for (int tb = 0; tb < T; tb += D) {
+    int vv[D];  // wave-uniform row indices of the chunk (border-resolved on the rim path)
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      if constexpr (FAST) vv[d] = y0 - G::H + tb + d;
+      else vv[d] = resolve_idx(y0 - G::H + tb + d, p.dh, p.cby);
+    }
+    typename Src::template Chunk<D> ch;
+    src.template load_chunk<FAST, D>(c, vv, ch);
+
+    static_for<0, D>([&](auto Dd) {
+      constexpr int d = decltype(Dd)::value;
+      const int t = tb + d;
+      float cur[4];
+      src.template row<FAST, D>(c, vv, ch, d, cur);
+
+      // window = own 4 px + H px from each side (neighbouring lanes)
+      float win[G::NW];
+#pragma unroll
+      for (int k = 0; k < 4; k++) win[G::H + k] = cur[k];
+      {
+        float l1[4], r1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          l1[k] = from_lane_below(cur[k]);
+          r1[k] = from_lane_above(cur[k]);
+        }
+#pragma unroll
+        for (int m = 0; m < G::H && m < 4; m++) {
+          win[G::H - 1 - m] = l1[3 - m];
+          win[G::H + 4 + m] = r1[m];
+        }
+        if constexpr (G::H > 4) {
+#pragma unroll
+          for (int m = 4; m < G::H; m++) {
+            win[G::H - 1 - m] = from_lane_below(l1[3 - (m - 4)]);
+            win[G::H + 4 + m] = from_lane_above(r1[m - 4]);
+          }
+        }
+      }
+
+      // scatter this input row into the K output rows it feeds.  Going from
+      // the oldest output row down, the first fma of row i reads acc[i-1] and
+      // writes acc[i]: the running sums shift by one row per step for free.
+      static_for<0, K>([&](auto Ii) {
+        constexpr int i = K - 1 - decltype(Ii)::value;
+        // K >= 9: coefficients come from LDS (uniform address = broadcast read,
+        // re-read every row step); smaller kernels keep them in SGPRs.  The
+        // opaque zero is chained to the previous kernel row's result so only
+        // one row of K coefficients is live at a time.
+        int z = 0;
+        if constexpr (K >= 9) z = opaque_zero_after(i == K - 1 ? win[0] : acc[i + 1][3]);
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+          const float w = K >= 9 ? wl[i * K + j + z] : wts.w[i * K + j];
+#pragma unroll
+          for (int ox = 0; ox < 4; ox++) {
+            if constexpr (i == 0) {
+              acc[0][ox] = j == 0 ? w * win[ox] : fmaf(w, win[ox + j], acc[0][ox]);
+            } else {
+              acc[i][ox] = fmaf(w, win[ox + j], j == 0 ? acc[i - 1][ox] : acc[i][ox]);
+            }
+          }
+        }
+      });
+
+      // output row t - (K-1) is complete
+      const int o = t - (K - 1);
+      if (o >= 0 && o < nrows && writer) {
+        float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
+        const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
+        if constexpr (FAST) {  // FAST strips: whole 16-byte-aligned chunks inside the image
+          *reinterpret_cast<float4*>(row) =
+              float4{acc[K - 1][0], acc[K - 1][1], acc[K - 1][2], acc[K - 1][3]};
+        } else if (p.vec_out && n == 4) {
+          *reinterpret_cast<float4*>(row) =
+              float4{acc[K - 1][0], acc[K - 1][1], acc[K - 1][2], acc[K - 1][3]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (k < n) row[k] = acc[K - 1][k];
+        }
+      }
+    });
+  }
+}
+
+#ifndef IPA_WAVE_MIN_WAVES
+#define IPA_WAVE_MIN_WAVES 1
+#endif
+template <typename Src, int K>
+__global__ void __launch_bounds__(256, IPA_WAVE_MIN_WAVES)
+wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
+  using G = wave_geom<K>;
+  constexpr int D = Src::template depth<K>::value;
+  const int lane = threadIdx.x & 63;
+  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned sid = b * 4 + (threadIdx.x >> 6);
+  __shared__ float wl[K >= 9 ? K * K : 1];
+  if constexpr (K >= 9) {
+    for (int i = threadIdx.x; i < K * K; i += 256) wl[i] = wts.w[i];
+    __syncthreads();
+  }
+  if (sid >= p.strips) return;  // whole wave
+  const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
+  const unsigned frame = blockIdx.y;
+  src.set_frame(frame);
+
+  const int xs = sxi * G::OW - 4 * G::HL;  // first column of the strip (lane 0)
+  Cols c;
+  c.xo = xs + lane * 4;
+  const int y0 = syi * p.strip_h;
+  const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
+  const bool writer = lane >= G::HL && lane < 64 - G::HL && c.xo < p.dw;
+  float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
+
+  // rows touched incl. the overshoot of the last chunk
+  const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
+  const bool fast = src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
+                    y0 - G::H >= 0 &&
+                    y0 - G::H + rows_touched <= p.dh;
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
+    wave_run_strip<true, Src, K>(p, src, wts, wl, c, y0, nrows, writer, dst);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+    wave_run_strip<false, Src, K>(p, src, wts, wl, c, y0, nrows, writer, dst);
+  }
+}
+
+// strip height: tall strips amortise the K-1 halo rows, short ones give small
+// problems enough waves to fill 256 CUs
+static inline int wave_strip_height(int dh, int dw, int n_frames, int K) {
+  int ow = 256 - 8 * ((K / 2 + 3) / 4);
+  long sx = (dw + ow - 1) / ow;
+  // measured on 16 x 4K frames (MI355X): 16-32 rows best, 64 within 3 %, 128+ and 8 clearly
+  // slower -> 32 rows when that still gives >= 8192 waves, else shorter strips
+  int best = 8;
+  for (int sh : {32, 16, 8}) {
+    long waves = sx * ((dh + sh - 1) / sh) * n_frames;
+    best = sh;
+    if (waves >= 8192) break;
+  }
+  return best;
+}
+
+}  // namespace ipa
