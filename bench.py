@@ -63,7 +63,13 @@ def cpu_baseline(h, w, K, dist, k5, budget_s=12.0):
     frame = synth_frames(1, h, w, 1000)[0]
     mx, my = orc.build_undistort_map(K, dist, K, h, w)
     res = {}
-    for label, threads in (('1', 1), ('all', orc.max_threads())):
+    # cores this process may actually run on (cgroup/affinity), not the host's core count
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    avail = max(1, min(avail, orc.max_threads()))
+    for label, threads in (('1', 1), ('all', avail)):
         orc.set_threads(threads)
         orc.remap_conv2d(frame, mx, my, k5)  # warm
         n, t0 = 0, time.perf_counter()
@@ -80,6 +86,22 @@ def cpu_baseline(h, w, K, dist, k5, budget_s=12.0):
             'sample': '%d frame(s) of %dx%d float32, map-based undistort + 5x5, oracle/oracle.c '
                       'with OpenMP on %d threads; single-thread: %.2f Mpix/s'
                       % (n_all, w, h, cores, res['1'][0])}
+
+
+def pmc_traffic(variant, batch, h, w):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
+    passes of this same command (profiles/pmc_summary.json, written by
+    profiles/summarize.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE).  None if that
+    profile does not cover this variant/shape: counters cannot be read from inside the run."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')) as f:
+            s = json.load(f)
+        e = s.get(variant)
+        if e and e.get('batch') == batch and e.get('height') == h and e.get('width') == w:
+            return e['traffic_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -138,21 +160,21 @@ def main():
     if args.variant == 'fused_map':
         def step():
             ops.remap_conv2d(d_src, dmx, dmy, k5, out=d_dst)
-        bytes_per_px, launches, kname = 16, 1, 'fused_kernel<float,linear,MapCoord,5>'
+        bytes_per_px, launches, kname = 16, 1, 'wave_stencil_kernel<SampleRowSrc<float,linear,MapCoord>,5>'
     elif args.variant == 'fused_analytic':
         def step():
             ops.undistort_conv2d(d_src, K, dcoef, K, k5, out=d_dst)
-        bytes_per_px, launches, kname = 8, 1, 'fused_kernel<float,linear,UndistortCoord,5>'
+        bytes_per_px, launches, kname = 8, 1, 'wave_stencil_kernel<SampleRowSrc<float,linear,UndistortCoord>,5>'
     elif args.variant == 'two_kernel':
         def step():
             ops.remap(d_src, dmx, dmy, out=d_tmp)
             ops.conv2d(d_tmp, k5, out=d_dst)
-        bytes_per_px, launches, kname = 24, 2, 'remap_kernel + conv_kernel<float,5,5>'
+        bytes_per_px, launches, kname = 24, 2, 'remap_kernel<float,float,linear,MapCoord> + wave_stencil_kernel<LoadRowSrc,5>'
     else:
         def step():
             ops.undistort(d_src, K, dcoef, K, out=d_tmp)
             ops.conv2d(d_tmp, k5, out=d_dst)
-        bytes_per_px, launches, kname = 16, 2, 'remap_kernel(analytic) + conv_kernel<float,5,5>'
+        bytes_per_px, launches, kname = 16, 2, 'remap_kernel<float,float,linear,UndistortCoord> + wave_stencil_kernel<LoadRowSrc,5>'
 
     for _ in range(args.warmup):
         step()
@@ -185,7 +207,10 @@ def main():
                        'frames_per_step_per_gpu': B, 'variant': args.variant,
                        'sharding': 'independent frames, %d rank(s), no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                         'traffic': pmc_traffic(args.variant, B, h, w),
+                         'algorithmic_bytes_per_launch': bytes_per_px * px // launches
+                         if launches == 1 else None,
                          'kernel': kname, 'algorithmic_bytes_per_px': bytes_per_px,
                          'launches_per_step': launches,
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4)},

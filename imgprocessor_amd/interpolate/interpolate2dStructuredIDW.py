@@ -15,12 +15,15 @@ from .. import ops
 
 
 def idw_weights(kernel, power=2, fx=1, fy=1):
+    # scalar float arithmetic like the reference loop (:17-21): numpy's array pow may
+    # differ from libm pow in the last bit
     k = int(kernel)
-    xi = np.arange(-k, k + 1, dtype=np.float64)
-    dist = (fx * xi[:, None]) ** 2 + (fy * xi[None, :]) ** 2
-    w = np.zeros_like(dist)
-    nz = dist != 0
-    w[nz] = 1.0 / dist[nz] ** (0.5 * power)
+    w = np.zeros((2 * k + 1, 2 * k + 1))
+    for xi in range(-k, k + 1):
+        for yi in range(-k, k + 1):
+            dist = ((fx * xi) ** 2 + (fy * yi) ** 2)
+            if dist:
+                w[xi + k, yi + k] = 1 / dist ** (0.5 * power)
     return w
 
 

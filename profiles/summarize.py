@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (gpurun_out/...) into the small files committed here.
+
+    python profiles/summarize.py <round-tag> <stats_dir> <pmc_fetch_dir> <pmc_write_dir> \
+           [--variant fused_map --batch 16 --height 2160 --width 3840]
+
+Writes
+  profiles/<tag>_kernel_stats.csv   the `rocprofv3 --kernel-trace --stats` per-kernel summary
+  profiles/<tag>_pmc.csv            per-kernel mean FETCH_SIZE / WRITE_SIZE (raw counter units)
+  profiles/pmc_summary.json         bytes per launch of the dominant kernel, corrected as
+                                    MI355X_MICROARCH.md prescribes: FETCH_SIZE reports half the
+                                    bytes of wide coalesced reads on gfx950 (x2), WRITE_SIZE is
+                                    exact; both are in KiB.  Note that FETCH_SIZE counts L2-side
+                                    fabric requests, Infinity-Cache hits included.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def mean_counter(d, counter):
+    out = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
+        for r in csv.DictReader(open(f)):
+            if r['Counter_Name'] == counter:
+                out[r['Kernel_Name']].append(float(r['Counter_Value']))
+    return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('tag')
+    ap.add_argument('stats_dir')
+    ap.add_argument('fetch_dir')
+    ap.add_argument('write_dir')
+    ap.add_argument('--variant', default='fused_map')
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--height', type=int, default=2160)
+    ap.add_argument('--width', type=int, default=3840)
+    a = ap.parse_args()
+
+    stats = glob.glob(os.path.join(a.stats_dir, '*', '*kernel_stats.csv'))
+    if stats:
+        shutil.copy(stats[0], os.path.join(HERE, '%s_kernel_stats.csv' % a.tag))
+    fetch = mean_counter(a.fetch_dir, 'FETCH_SIZE')
+    write = mean_counter(a.write_dir, 'WRITE_SIZE')
+    with open(os.path.join(HERE, '%s_pmc.csv' % a.tag), 'w') as f:
+        w = csv.writer(f)
+        w.writerow(['kernel', 'launches', 'FETCH_SIZE_mean_KiB_raw', 'WRITE_SIZE_mean_KiB'])
+        for k in sorted(set(fetch) | set(write)):
+            w.writerow([k, fetch.get(k, (0, 0))[1], '%.1f' % fetch.get(k, (0, 0))[0],
+                        '%.1f' % write.get(k, (0, 0))[0]])
+    # dominant kernel = largest fetch
+    dom = max(fetch, key=lambda k: fetch[k][0])
+    traffic = (2 * fetch[dom][0] + write.get(dom, (0, 0))[0]) * 1024
+    path = os.path.join(HERE, 'pmc_summary.json')
+    summ = json.load(open(path)) if os.path.exists(path) else {}
+    summ[a.variant] = {'kernel': dom, 'batch': a.batch, 'height': a.height, 'width': a.width,
+                       'fetch_size_kib_raw': fetch[dom][0], 'write_size_kib': write[dom][0],
+                       'traffic_bytes_per_launch': int(traffic), 'round': a.tag,
+                       'correction': 'FETCH_SIZE x2 (gfx950 wide coalesced reads) + WRITE_SIZE, KiB'}
+    json.dump(summ, open(path, 'w'), indent=1, sort_keys=True)
+    print(json.dumps(summ[a.variant], indent=1))
+
+
+if __name__ == '__main__':
+    main()

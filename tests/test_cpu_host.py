@@ -1,0 +1,237 @@
+"""CPU-only: the C-ABI library loads and exports every symbol the header declares, the
+host-side logic (geometry helpers, weight tables, dtype rules, argument checks, sharding)
+behaves like the reference, and the product never touches the oracle.
+No compute call is made here: there is no GPU in this container.
+"""
+import ctypes as C
+import io
+import contextlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from .conftest import ROOT, load_golden, assert_close
+
+HEADER = os.path.join(ROOT, 'include', 'imgproc_hip.h')
+
+
+def _declared_symbols():
+    txt = open(HEADER).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(ipa_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_abi_exports_every_declared_symbol():
+    from imgprocessor_amd import _lib
+    lib = _lib.lib()  # raises ImportError if the extension is missing: no fallback
+    names = _declared_symbols()
+    assert len(names) >= 38
+    for n in names:
+        assert hasattr(lib, n), 'libimgproc_hip.so does not export %s' % n
+    bound = set(_lib.PROTOTYPES) | set(_lib._CHARP)
+    assert set(names) == bound, 'ctypes prototypes out of sync with the header: %s' % (
+        set(names) ^ bound)
+    assert lib.ipa_version() == 100
+    assert lib.ipa_status_string(0) == b'ok'
+    assert b'unsupported' in lib.ipa_status_string(-2)
+
+
+def test_no_device_fails_loudly():
+    """without a gfx950 device the context refuses to exist: no CPU fallback anywhere"""
+    import imgprocessor_amd as ia
+    if ia.device_count() > 0:
+        pytest.skip('a GPU is visible here')
+    h = C.c_void_p()
+    from imgprocessor_amd import _lib
+    rc = _lib.lib().ipa_ctx_create(0, C.byref(h))
+    assert rc == _lib.ERR_NO_DEVICE and not h.value
+    with pytest.raises(_lib.ImgProcHipError):
+        ia.Context(0)
+    with pytest.raises(_lib.ImgProcHipError):
+        ia.ops.conv2d(np.zeros((8, 8), np.float32), np.ones((3, 3)))
+    # NULL context is a bad argument, never a crash
+    assert _lib.lib().ipa_ctx_synchronize(None) == _lib.ERR_BAD_ARG
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, 'imgprocessor_amd')
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith(('.py', '.hip', '.hpp', '.cpp', '.h')) or fn == 'Makefile':
+                txt = open(os.path.join(dp, fn), errors='ignore').read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', txt, re.M), fn
+                assert 'liboracle' not in txt and 'oracle.c' not in txt, fn
+    out = subprocess.check_output(['ldd', os.path.join(pkg, 'libimgproc_hip.so')]).decode()
+    assert 'oracle' not in out and 'torch' not in out
+
+
+# ---------------------------------------------------------------- geometry --
+def test_geometry_helpers(oracle):
+    from imgprocessor_amd.utils import (genericCameraMatrix, sortCorners, getPerspectiveTransform,
+                                        getOptimalNewCameraMatrix, perspectiveTransform)
+    K = genericCameraMatrix((480, 640))
+    assert K.dtype == np.float32 and K[0, 2] == 320 and K[1, 2] == 240
+    assert_close(K[0, 0], 320 / np.tan(np.deg2rad(30)), 1e-6)
+    quad = np.array([(8, 2), (198, 6), (198, 410), (9, 411)], float)  # PerspectiveCorrection.py:866-869
+    for perm in ([0, 1, 2, 3], [2, 0, 3, 1], [3, 2, 1, 0]):
+        assert np.array_equal(sortCorners(quad[perm]), quad)  # TL, TR, BR, BL
+    dst = np.array([[0, 0], [200, 0], [200, 400], [0, 400]], float)
+    H = getPerspectiveTransform(quad, dst)
+    assert_close(H, oracle.get_perspective_transform(quad, dst), 1e-9, 1e-12)
+    assert_close(perspectiveTransform(quad, H), dst, 0, 1e-9)
+    # zero distortion: the optimal matrix maps the full frame onto itself
+    K = np.array([[500., 0, 319.5], [0, 500., 239.5], [0, 0, 1]])
+    nK, roi = getOptimalNewCameraMatrix(K, np.zeros(5), (640, 480), 1)
+    assert roi[0] <= 1 and roi[1] <= 1 and roi[2] >= 638 and roi[3] >= 478
+    assert abs(nK[0, 0] - 500 * 639 / 640) < 1e-6 and abs(nK[0, 2] - 319.5 * 639 / 640) < 1e-6
+    # barrel distortion: alpha=1 keeps every source pixel -> smaller focal length, inner roi
+    nK, roi = getOptimalNewCameraMatrix(K, [-0.2, 0.05, 0, 0, 0], (640, 480), 1)
+    assert nK[0, 0] < 500 and 0 < roi[2] < 640 and 0 < roi[3] < 480
+
+
+def test_weight_tables_match_reference(oracle):
+    from imgprocessor_amd.interpolate.interpolate2dStructuredIDW import idw_weights
+    from imgprocessor_amd.interpolate.interpolate2dStructuredFastIDW import growPositions
+    from imgprocessor_amd import ops
+    g = load_golden('idw.npz')
+    pos, dist = growPositions(4)
+    assert np.array_equal(pos, g['grow4_pos']) and np.array_equal(dist, g['grow4_dist'])
+    for (k, p, fx, fy) in ((3, 2, 1, 1), (5, 1, 2, 0.5), (15, 3, 1, 1)):
+        assert np.array_equal(idw_weights(k, p, fx, fy), oracle.idw_weights(k, p, fx, fy))
+    for s in (0.5, 1.0, 1.25, 2.0, 3.7):
+        assert_close(ops.gaussian_kernel1d(s), oracle.gaussian_kernel1d(s), 1e-15)
+    assert ops.gaussian_kernel1d(0.5).size == 5 and ops.gaussian_kernel1d(1.0).size == 9
+
+
+def test_names_and_argument_checks():
+    from imgprocessor_amd import ops, _lib
+    from imgprocessor_amd.filters import maskedConvolve, extendArrayForConvolution
+    assert ops.interp_id('linear') == 1 and ops.interp_id('lanczos4') == 4
+    assert ops.interp_id('linear_cv_q5') == (1 | 0x100) and ops.interp_id('cubic') == 5
+    assert ops.border_id('reflect') == 2 and ops.border_id('mirror') == 4
+    assert ops.border_id('grid-wrap') == 3 and ops.border_id('nearest') == 1
+    with pytest.raises(ValueError):
+        ops.interp_id('bogus')
+    with pytest.raises(ValueError):
+        ops.border_id('bogus')
+    a = np.zeros((10, 12))
+    m = np.ones((10, 12), bool)
+    with pytest.raises(ValueError):  # non-square kernels are out of bounds in the reference
+        maskedConvolve(a, np.ones((3, 5)), m)
+    with pytest.raises(Exception):   # modey='wrap' raises in the reference as well
+        with contextlib.redirect_stdout(io.StringIO()):
+            maskedConvolve(a, np.ones((3, 3)), m, mode='wrap')
+    with pytest.raises(Exception):
+        extendArrayForConvolution(a, (3, 3), modey='wrap')
+    assert _lib.dbl([1, 2, 3], 3)[2] == 3.0
+    with pytest.raises(ValueError):
+        _lib.dbl([1, 2], 3)
+
+
+def test_dtype_rules():
+    from imgprocessor_amd.transformations import toFloatArray, toUIntArray
+    assert toFloatArray(np.zeros(3, np.uint8)).dtype == np.float32
+    assert toFloatArray(np.zeros(3, np.uint16)).dtype == np.float32
+    assert toFloatArray(np.zeros(3, np.uint32)).dtype == np.float64
+    assert toFloatArray(np.zeros(3, np.float64)).dtype == np.float64
+    a = np.array([-3.7, 0.2, 1.9, 254.6, 300.0])
+    u = toUIntArray(a, dtype=np.uint8)
+    assert u.dtype == np.uint8 and u.tolist() == [0, 0, 1, 254, 255]  # clip, then truncate
+
+
+def test_lens_distortion_host_side(tmp_path):
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    ld = LensDistortion()
+    with pytest.raises(RuntimeError):
+        ld.coeffs
+    ld.setCameraParams(800., 810., 319.5, 239.5, -0.1, 0.02, 0.003, 1e-3, -2e-3)
+    # argument order k1,k2,k3,p1,p2 vs stored [k1,k2,p1,p2,k3] (LensDistortion.py:360-380)
+    assert ld.coeffs['distortionCoeffs'].tolist() == [[-0.1, 0.02, 1e-3, -2e-3, 0.003]]
+    assert ld.getCameraParams() == (800., 810., 319.5, 239.5, -0.1, 0.02, 0.003, 1e-3, -2e-3)
+    ld.coeffs = LensDistortion.makeCoeffs(ld.coeffs['cameraMatrix'], ld.coeffs['distortionCoeffs'],
+                                          (480, 640))
+    fn = ld.writeToFile(str(tmp_path / 'cal'))
+    assert fn.endswith('.npz')
+    ld2 = LensDistortion()
+    c = ld2.readFromFile(fn)
+    assert np.array_equal(c['cameraMatrix'], ld.coeffs['cameraMatrix']) and c['shape'] == (480, 640)
+    with pytest.raises(NotImplementedError):
+        ld.calibrate()
+    pts = ld.undistortPoints([(319.5, 239.5), (10., 20.)], keepSize=True)
+    assert pts.shape == (1, 2, 2)
+
+
+def test_perspective_correction_host_side():
+    from imgprocessor_amd.camera.PerspectiveCorrection import PerspectiveCorrection
+    quad = np.array([(8, 2), (198, 6), (198, 410), (9, 411)], float)
+    pc = PerspectiveCorrection((420, 210), new_size=(400, 200), border=5)
+    pc.setReference(quad)
+    H = pc.homography
+    got = pc.correctPoints(quad)[0]
+    assert_close(got, [[5, 5], [195, 5], [195, 395], [5, 395]], 0, 1e-3)
+    assert H.shape == (3, 3)
+    with pytest.raises(NotImplementedError):
+        PerspectiveCorrection((10, 10), do_correctIntensity=True)
+    pc2 = PerspectiveCorrection((10, 10))
+    pc2.setReference(quad)
+    with pytest.raises(NotImplementedError):  # new_size must be explicit
+        pc2.homography
+
+
+# ---------------------------------------------------------------- sharding --
+def test_frame_blocks():
+    from imgprocessor_amd.sharding import frame_block, all_blocks
+    for n in (0, 1, 7, 8, 9, 512, 513):
+        for g in (1, 2, 3, 4, 8):
+            blocks = all_blocks(n, g)
+            covered = [i for (a, b) in blocks for i in range(a, b)]
+            assert covered == list(range(n)), (n, g)
+            assert max(b - a for a, b in blocks) == -(-n // g)
+    assert frame_block(512, 8, 3) == (192, 256)  # C4: 64 frames per GPU
+    with pytest.raises(ValueError):
+        frame_block(4, 2, 2)
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from imgprocessor_amd.sharding import frame_block
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+dist.init_process_group('gloo', rank=rank, world_size=world)
+n = 37
+a, b = frame_block(n, world, rank)
+mine = torch.zeros(n, dtype=torch.int64)
+mine[a:b] = 1
+dist.barrier()
+# the only cross-rank traffic of the benchmark: barrier + max of the elapsed time
+el = torch.tensor([0.25 if rank == 0 else 0.75], dtype=torch.float64)
+dist.all_reduce(el, op=dist.ReduceOp.MAX)
+dist.all_reduce(mine, op=dist.ReduceOp.SUM)  # test-only: check the partition
+if rank == 0:
+    print(json.dumps({'max': float(el[0]), 'cover': mine.tolist()}))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_partition_gloo(tmp_path):
+    """world_size-2 run on CPU (gloo): ranks own disjoint contiguous blocks that cover the
+    batch, and the timing reduction bench.py uses (barrier + MAX) works"""
+    script = tmp_path / 'worker.py'
+    script.write_text(WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29617', WORLD_SIZE='2')
+    procs = []
+    for r in range(2):
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE))
+    outs = [p.communicate(timeout=180) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    import json
+    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert res['max'] == 0.75
+    assert res['cover'] == [1] * 37
