@@ -431,7 +431,37 @@ int ipa_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, 
   IPA_REQUIRE(ctx, d_src && d_dst, "null pointer");
   IPA_REQUIRE(ctx, h > 0 && w > 0, "empty image");
   IPA_REQUIRE(ctx, nky >= 0 && nkx >= 0 && (nky == 0 || ky) && (nkx == 0 || kx), "bad kernel args");
-  IPA_REQUIRE(ctx, nky <= kSepMaxTaps && nkx <= kSepMaxTaps, "at most %d taps per axis", kSepMaxTaps);
+  {
+    // long kernels (e.g. sigma = 11 -> 89 taps, filters/standardDeviation.py:23) do not fit
+    // the kernarg table / LDS planes: run the two axes as two launches of the generic
+    // correlation with the intermediate (rounded to the image dtype, like scipy) in a
+    // temporary device buffer
+    size_t es0 = ipa_dtype_size(dtype);
+    int hxa0 = ((nkx / 2 + 3) / 4) * 4;
+    size_t lds0 = (size_t)(2 * kTileH + 2 * (nky / 2)) * (kTileW + 2 * hxa0) * es0;
+    if (nky > kSepMaxTaps || nkx > kSepMaxTaps || lds0 > 150 * 1024) {
+      IPA_REQUIRE(ctx, d_src != d_dst, "sepconv2d cannot run in place");
+      if (nky == 0 || nkx == 0) {
+        const double* k = nky ? ky : kx;
+        return ipa_conv2d_dev(ctx, d_src, dtype, h, w, src_pitch, k, nky ? nky : 1, nkx ? nkx : 1,
+                              nullptr, 0, d_dst, dst_pitch, n_frames, src_frame_stride,
+                              dst_frame_stride, border_x, border_y, border_value);
+      }
+      void* tmp = nullptr;
+      IPA_HIP(ctx, hipSetDevice(ctx->device));
+      IPA_HIP(ctx, hipMalloc(&tmp, (size_t)n_frames * h * w * es0));
+      int rc = ipa_conv2d_dev(ctx, d_src, dtype, h, w, src_pitch, ky, nky, 1, nullptr, 0, tmp, w,
+                              n_frames, src_frame_stride, (long)h * w, border_x, border_y,
+                              border_value);
+      if (!rc)
+        rc = ipa_conv2d_dev(ctx, tmp, dtype, h, w, w, kx, 1, nkx, nullptr, 0, d_dst, dst_pitch,
+                            n_frames, (long)h * w, dst_frame_stride, border_x, border_y,
+                            border_value);
+      (void)hipStreamSynchronize(ctx->stream);
+      (void)hipFree(tmp);
+      return rc;
+    }
+  }
   IPA_REQUIRE(ctx, (nky == 0 || (nky & 1)) && (nkx == 0 || (nkx & 1)), "tap counts must be odd");
   IPA_REQUIRE(ctx, src_pitch >= w && dst_pitch >= w, "pitch smaller than width");
   IPA_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535, "n_frames must be in [1,65535]");

@@ -2,3 +2,5 @@
 from .filter import filter, gaussian_filter, box_filter  # noqa: F401,A001
 from .maskedConvolve import maskedConvolve  # noqa: F401
 from ._extendArrayForConvolution import extendArrayForConvolution  # noqa: F401
+from .varYSizeGaussianFilter import varYSizeGaussianFilter  # noqa: F401
+from .standardDeviation import standardDeviation2d  # noqa: F401

@@ -307,6 +307,46 @@ def extend_array(arr, kernelXY, modex='reflect', modey='reflect', ctx=None):
     return d_out if dev else d_out.get()
 
 
+def conv_ydep(arr, kernels, modex='wrap', modey='reflect', ctx=None):
+    """row-dependent k0 x k1 correlation, NaN-skipping
+    (filters/varYSizeGaussianFilter.py:53-68); kernels: (H, k0, k1) float64"""
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, ctx=ctx)
+    d_in = arr if dev else ctx.to_device(_float_img(arr))
+    if d_in.ndim != 2:
+        raise ValueError('conv_ydep works on 2-D arrays')
+    h, w = d_in.shape
+    k = np.ascontiguousarray(kernels, dtype=np.float64)
+    if k.ndim != 3 or k.shape[0] != h:
+        raise ValueError('kernels must be (H, k0, k1)')
+    d_k = ctx.to_device(k)
+    d_out = DeviceArray(ctx, (h, w), d_in.dtype)
+    ctx._check(ctx._lib.ipa_conv_ydep_dev(ctx.handle, d_in.ptr, dtype_id(d_in.dtype), h, w, w,
+                                          d_k.ptr, k.shape[1], k.shape[2], border_id(modex),
+                                          border_id(modey), d_out.ptr, w), 'conv_ydep')
+    if dev:
+        d_out._keepalive = d_k  # the table must outlive the asynchronous launch
+        return d_out
+    return d_out.get()
+
+
+def local_std(img, blurred, ksize, ctx=None):
+    """filters/standardDeviation.py:34-70 (_calc) for ksize=(kx, ky)"""
+    dev = _is_dev(img)
+    ctx = _ctx_of(img, blurred, ctx=ctx)
+    d_img = img if dev else ctx.to_device(_float_img(img))
+    d_bl = blurred if _is_dev(blurred) else ctx.to_device(
+        np.ascontiguousarray(blurred, dtype=d_img.dtype))
+    if d_img.ndim != 2 or d_bl.shape != d_img.shape or d_bl.dtype != d_img.dtype:
+        raise ValueError('img and blurred must be 2-D arrays of equal shape and dtype')
+    h, w = d_img.shape
+    d_out = DeviceArray(ctx, (h, w), d_img.dtype)
+    ctx._check(ctx._lib.ipa_local_std_dev(ctx.handle, d_img.ptr, d_bl.ptr, dtype_id(d_img.dtype),
+                                          h, w, w, w, int(ksize[0]), int(ksize[1]), d_out.ptr, w),
+               'local_std')
+    return d_out if dev else d_out.get()
+
+
 # ------------------------------------------------- fused remap -> filter --
 def _fused_out(ctx, src, out, dh, dw, n):
     odt = np.float64 if src.dtype == np.float64 else np.float32

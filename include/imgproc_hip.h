@@ -178,6 +178,22 @@ int ipa_sepconv2d(ipa_ctx* ctx, const void* src, int dtype, int h, int w, const 
                   int nky, const double* kx, int nkx, void* dst, int n_frames, int border_y,
                   int border_x, double border_value);
 
+/* replaces filters/varYSizeGaussianFilter.py:53-68 (_2dConvolutionYdependentKernel):
+ *   dst[r,c] = sum_{ii<k0, jj<k1} kernels[r][ii][jj] * src[r+ii-k0/2, c+jj-k1/2]
+ * with NaN pixels skipped (no renormalisation) and borders resolved on the fly
+ * (the reference pads first; its defaults are modex='wrap', modey='reflect').
+ * d_kernels: DEVICE array of h*k0*k1 doubles (one k0 x k1 table per row). */
+int ipa_conv_ydep_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
+                      const double* d_kernels, int k0, int k1, int border_x, int border_y,
+                      void* d_dst, long dst_pitch);
+
+/* replaces filters/standardDeviation.py:34-70 (_calc): local standard deviation of
+ * img around blurred[i,j] over the window [i-kx/2, min(i+kx/2, h)) x [j-ky/2, min(j+ky/2, w)),
+ * divided by (rows-1)*(cols-1) exactly as the reference does. */
+int ipa_local_std_dev(ipa_ctx* ctx, const void* d_img, const void* d_blurred, int dtype, int h,
+                      int w, long pitch, long blurred_pitch, int ksize_x, int ksize_y,
+                      void* d_out, long out_pitch);
+
 /* replaces filters/_extendArrayForConvolution.py:5-97 for callers that want the
  * padded array itself (the filters above resolve borders while staging and do
  * not need it): dst is (h + 2*(ky/2)) x (w + 2*(kx/2)), kx/ky = kernel size

@@ -1,0 +1,216 @@
+"""GPU: the secondary stencils against the reference fixtures, and the
+BASELINE.json configurations C2..C5 at FULL size — against the oracle directly where it
+finishes in seconds (it is plain C with OpenMP) and through size-independent properties.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from .conftest import load_golden, assert_close, synth
+
+pytestmark = pytest.mark.gpu
+
+RT = 1e-5
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)
+    return imgprocessor_amd
+
+
+@pytest.fixture(scope='module')
+def orc(oracle):
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    oracle.set_threads(max(1, min(n, oracle.max_threads(), 32)))
+    yield oracle
+    oracle.set_threads(1)
+
+
+def close32(got, want, what='', scale=None):
+    want = np.asarray(want, dtype=np.float64)
+    s = np.nanmax(np.abs(want)) if scale is None else scale
+    assert_close(got, want, RT, RT * s, what)
+
+
+# ------------------------------------------------------- a9 / a10 stencils ----
+def test_var_y_gauss_golden(ia):
+    from imgprocessor_amd.filters import varYSizeGaussianFilter
+    g = load_golden('var_y_gauss.npz')
+    assert_close(varYSizeGaussianFilter(g['arr'], (0, 4), 1), g['out_0_4_1'], 1e-12, 1e-14)
+    assert_close(varYSizeGaussianFilter(g['arr'], 3, 0), g['out_3_0'], 1e-12, 1e-14)
+    assert_close(varYSizeGaussianFilter(g['arr_nan'], (0, 4), 1), g['out_nan_0_4_1'], 1e-12, 1e-14)
+    assert_close(varYSizeGaussianFilter(g['arr'], (1, 3), 2, modex='reflect'),
+                 g['out_1_3_2_reflect'], 1e-12, 1e-14)
+    a32 = g['arr'].astype(np.float32)
+    got = varYSizeGaussianFilter(a32, (0, 4), 1)
+    assert got.dtype == np.float32
+    close32(got, g['out_0_4_1'], 'f32', scale=1.0)
+    with pytest.raises(UnboundLocalError):  # the reference's ndarray branch is broken
+        varYSizeGaussianFilter(g['arr'], np.ones(40))
+
+
+def test_std2d_golden(ia):
+    from imgprocessor_amd.filters import standardDeviation2d
+    g = load_golden('std2d.npz')
+    for k in (5, 11):
+        assert_close(standardDeviation2d(g['img'], k), g['std_k%d' % k], 1e-10, 1e-13, 'k%d' % k)
+    close32(standardDeviation2d(g['img32'], 5), g['std32_k5'], 'f32')
+    ctx = ia.default_context(0)
+    d = standardDeviation2d(ctx.to_device(g['img']), 5)
+    assert isinstance(d, ia.DeviceArray)
+    assert_close(d.get(), g['std_k5'], 1e-10, 1e-13)
+
+
+def test_long_separable_kernels(ia, orc):
+    """sigma 11 -> 89 taps: the two-launch fallback of ipa_sepconv2d_dev"""
+    img = synth((150, 210), 3)
+    from imgprocessor_amd.filters import gaussian_filter
+    close32(gaussian_filter(img, 11), orc.gaussian_filter(img, 11), 'sigma 11')
+    close32(gaussian_filter(img, (0, 9)), orc.gaussian_filter(img, (0, 9)), 'x only, sigma 9')
+    i64 = img.astype(np.float64)
+    assert_close(gaussian_filter(i64, 6), orc.gaussian_filter(i64, 6), 1e-12, 1e-13, 'f64 sigma 6')
+
+
+# ------------------------------------------------------------ full-size configs ----
+def camera(h, w):
+    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    return K, np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+
+
+def gauss(n, sigma=1.0):
+    g = np.exp(-0.5 * (np.arange(n) - n // 2) ** 2 / sigma ** 2)
+    return g / g.sum()
+
+
+def persp(quad, h, w):
+    from imgprocessor_amd.utils import getPerspectiveTransform
+    dst = np.array([[0, 0], [w, 0], [w, h], [0, h]], float)
+    return np.linalg.inv(getPerspectiveTransform(np.array(quad, float), dst))
+
+
+def test_c2_1080p_undistort_gauss5(ia, orc):
+    """C2: 1080p float32, LensDistortion radial undistort + 5x5 Gaussian"""
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    from imgprocessor_amd.filters import filter as ipa_filter
+    h, w = 1080, 1920
+    img = synth((h, w), 0)
+    K, d = camera(h, w)
+    k5 = np.outer(gauss(5), gauss(5))
+    ld = LensDistortion(newCameraMatrix='same')
+    ld.setCameraParams(K[0, 0], K[1, 1], K[0, 2], K[1, 2], d[0], d[1], d[4], d[2], d[3])
+    und = ld.correct(img, keepSize=True)
+    out = ipa_filter(und, k5)
+    mx, my = orc.build_undistort_map(K, d, K, h, w)
+    assert np.array_equal(np.stack(ld.getUndistortRectifyMap(w, h)), np.stack([mx, my]))
+    want_u = orc.remap(img, mx, my)
+    close32(und, want_u, 'C2 undistort', scale=1.0)
+    close32(out, orc.conv2d(want_u, k5), 'C2 filter', scale=1.0)
+    ctx = ia.default_context(0)
+    fused = ia.ops.remap_conv2d(ctx.to_device(img), ctx.to_device(mx), ctx.to_device(my), k5).get()
+    close32(fused, orc.conv2d(want_u, k5), 'C2 fused', scale=1.0)
+    an = ia.ops.undistort_conv2d(ctx.to_device(img), K, d, K, k5).get()
+    assert np.array_equal(an, fused)  # analytic == map-based, bit for bit
+    # size-independent properties: linearity in the image, constant image stays constant inside
+    img2 = synth((h, w), 1)
+    a, b = 0.75, -1.25
+    lhs = ipa_filter(ld.correct((a * img + b * img2).astype(np.float32), keepSize=True), k5)
+    rhs = a * out + b * ipa_filter(ld.correct(img2, keepSize=True), k5)
+    assert np.abs(lhs - rhs).max() < 5e-6
+    const = ipa_filter(ld.correct(np.full((h, w), 0.625, np.float32), keepSize=True), k5)
+    inner = (mx > 2) & (mx < w - 3) & (my > 2) & (my < h - 3)
+    inner[:3] = inner[-3:] = False
+    inner[:, :3] = inner[:, -3:] = False
+    import scipy.ndimage as ndi
+    inner = ndi.binary_erosion(inner, iterations=3)
+    assert np.abs(const[inner] - 0.625).max() < 2e-6
+
+
+def test_c3_4k_perspective_sep9(ia, orc):
+    """C3: 4K float32, perspective warp (bilinear and bicubic) + separable 9x9 Gaussian"""
+    h, w = 2160, 3840
+    img = synth((h, w), 0)
+    M = persp([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], h, w)
+    g9 = gauss(9)
+    ctx = ia.default_context(0)
+    d_img = ctx.to_device(img)
+    for interp, iid in (('linear', orc.LINEAR), ('cubic', orc.CUBIC_KEYS)):
+        warped = ia.ops.warp_perspective(d_img, M, (h, w), interp)
+        want_w = orc.warp_perspective(img, M, (h, w), iid)
+        close32(warped.get(), want_w, 'C3 warp ' + interp, scale=1.0)
+        out = ia.ops.sepconv2d(warped, g9, g9).get()
+        close32(out, orc.sepconv2d(want_w, g9, g9), 'C3 sep9 ' + interp, scale=1.0)
+        # the same filter as a dense 9x9 (fused chain, K=9 -> two launches inside)
+        dense = ia.ops.warp_perspective_conv2d(d_img, M, (h, w), np.outer(g9, g9), interp).get()
+        assert np.abs(dense - out).max() < 5e-6
+    # PerspectiveCorrection class at full size, default Lanczos4
+    from imgprocessor_amd.camera.PerspectiveCorrection import PerspectiveCorrection
+    pc = PerspectiveCorrection(img.shape, new_size=(h, w))
+    pc.setReference([(192, 108), (3648, 54), (3744, 2106), (96, 2052)])
+    got = pc.correct(img)
+    close32(got, orc.warp_perspective(img, np.linalg.inv(pc.homography), (h, w), orc.LANCZOS4),
+            'C3 lanczos4', scale=1.0)
+
+
+def test_c4_u16_batch_undistort_k7(ia, orc):
+    """C4 (a slice of it): 4K uint16 -> float32 frames, undistort + dense 7x7, batch sharded"""
+    from imgprocessor_amd.sharding import frame_block
+    h, w, n = 2160, 3840, 4
+    K, d = camera(h, w)
+    k7 = np.random.default_rng(123).random((7, 7))
+    k7 /= k7.sum()
+    frames = np.stack([np.round(synth((h, w), s, np.float64) * 4095).astype(np.uint16)
+                       for s in range(n)])
+    ctx = ia.default_context(0)
+    dmx, dmy = ia.ops.build_undistort_map(K, d, K, h, w, device=True)
+    mx, my = dmx.get(), dmy.get()
+    outs = []
+    for rank in range(2):  # two "ranks" of the batch sharder on one device
+        a, b = frame_block(n, 2, rank)
+        d_fr = ctx.to_device(frames[a:b])
+        outs.append(ia.ops.remap_conv2d(d_fr, dmx, dmy, k7).get())
+    got = np.concatenate(outs)
+    assert got.dtype == np.float32 and got.shape == (n, h, w)
+    for i in (0, n - 1):
+        want = orc.conv2d(orc.remap(frames[i], mx, my, out_dtype=np.float32), k7)
+        close32(got[i], want, 'C4 frame %d' % i)
+    # one launch over the whole batch == per-block launches
+    whole = ia.ops.remap_conv2d(ctx.to_device(frames), dmx, dmy, k7).get()
+    assert np.array_equal(whole, got)
+
+
+def test_c5_8k_bicubic_k11(ia, orc):
+    """C5: 8K float32, bicubic warp under rotation+perspective, dense 11x11 (LDS-pressure case)"""
+    h, w = 4320, 7680
+    img = synth((h, w), 0)
+    a = np.deg2rad(7.0)
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    R = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.]])
+    T = np.array([[1, 0, cx], [0, 1, cy], [0, 0, 1.]])
+    P = np.array([[1, 0, 0], [0, 1, 0], [1.5e-6, -1e-6, 1.]])
+    M = T @ R @ P @ np.linalg.inv(T)
+    k11 = np.random.default_rng(321).random((11, 11))
+    k11 /= k11.sum()
+    ctx = ia.default_context(0)
+    d_img = ctx.to_device(img)
+    got = ia.ops.warp_perspective_conv2d(d_img, M, (h, w), k11, 'cubic').get()
+    want_w = orc.warp_perspective(img, M, (h, w), orc.CUBIC_KEYS)
+    close32(got, orc.conv2d(want_w, k11), 'C5', scale=1.0)
+    # row-band split (single huge frame over G GPUs): bands of OUTPUT rows with an
+    # 11//2 halo computed from the same source equal the monolithic result
+    bands = []
+    G = 4
+    for r in range(G):
+        y0, y1 = r * h // G, (r + 1) * h // G
+        lo, hi = max(y0 - 5, 0), min(y1 + 5, h)
+        Mb = M @ np.array([[1, 0, 0], [0, 1, lo], [0, 0, 1.]])  # output row offset
+        part = ia.ops.conv2d(ia.ops.warp_perspective(d_img, Mb, (hi - lo, w), 'cubic'), k11).get()
+        bands.append(part[y0 - lo:y0 - lo + (y1 - y0)])
+    banded = np.concatenate(bands)
+    # (rows within 5 of a band's own edge see that band's reflect border, and are cropped away)
+    assert np.abs(banded - got).max() < 5e-6
