@@ -19,6 +19,9 @@
 int ipa_wave_conv_launch_k3(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
 int ipa_wave_conv_launch_k5(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
 int ipa_wave_conv_launch_k7(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
+// float32 separable K+K filter on the same skeleton (wave_sep.hip); returns 1 if not covered
+int ipa_wave_sep_launch(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double* ky,
+                        int nky, const double* kx, int nkx, int n_frames, float xcval);
 
 namespace ipa {
 
@@ -473,6 +476,23 @@ int ipa_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, 
   if (dtype != IPA_F32 && dtype != IPA_F64)
     IPA_UNSUPPORTED(ctx, "sepconv2d supports float32/float64 images (got dtype %d)", dtype);
   size_t es = ipa_dtype_size(dtype);
+  if (dtype == IPA_F32 && nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9)) {
+    // float32, equal short tap counts: the wave-marching separable kernel (wave_sep.hip)
+    WaveParams wp;
+    wp.dst = (char*)d_dst; wp.dst_frame_elems = dst_frame_stride;
+    wp.dh = h; wp.dw = w; wp.dpitch = dst_pitch;
+    wp.cbx = border_x; wp.cby = border_y;
+    wp.vec_out = rows_aligned16(d_dst, dst_pitch, dst_frame_stride, n_frames, es);
+    LoadRowSrc src;
+    src.base = (const float*)d_src; src.frame_elems = src_frame_stride; src.pitch = src_pitch;
+    src.vec_in = rows_aligned16(d_src, src_pitch, src_frame_stride, n_frames, es);
+    src.cval = (float)border_value;
+    IPA_HIP(ctx, hipSetDevice(ctx->device));
+    if (ipa_wave_sep_launch(ctx, wp, src, ky, nky, kx, nkx, n_frames, (float)border_value) == 0) {
+      IPA_HIP(ctx, hipGetLastError());
+      return IPA_OK;
+    }
+  }
   SepParams p;
   p.src = (const char*)d_src; p.dst = (char*)d_dst;
   p.src_frame_elems = src_frame_stride; p.dst_frame_elems = dst_frame_stride;
