@@ -61,6 +61,8 @@ PROTOTYPES = {
     'ipa_extend_array_dev': [_vp, _vp, _i, _i, _i, _l, _i, _i, _i, _i, _vp, _l],
     'ipa_conv_ydep_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _i, _i, _vp, _l],
     'ipa_local_std_dev': [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _vp, _l],
+    'ipa_masked_mean_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],
+    'ipa_nan_max_dev': [_vp, _vp, _i, _i, _i, _l, _i, _vp, _l],
     'ipa_remap_conv2d_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _dp, _i, _i, _vp, _i, _i,
                              _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
     'ipa_undistort_conv2d_dev': [_vp, _vp, _i, _i, _i, _l, _dp, _dp, _dp, _dp, _i, _i, _vp, _i,

@@ -5,8 +5,11 @@
 //                    with extendArrayForConvolution, default modex='wrap', modey='reflect')
 //   ipa_local_std*   filters/standardDeviation.py:34-70 (_calc): local standard deviation
 //                    around a given (Gaussian-blurred) mean, reference quirks included
+//   ipa_masked_mean* filters/maskedFilter.py:43-72 (_calcMean): mean of the unmasked pixels of
+//                    the clipped window, for the masked (fill) or the unmasked pixels
+//   ipa_nan_max*     filters/nan_maximum_filter.py:17-37: NaN-ignoring window maximum
 //
-// Both are one-output-pixel-per-lane kernels: a wave covers 64 consecutive
+// All are one-output-pixel-per-lane kernels: a wave covers 64 consecutive
 // pixels of one row, so the per-row coefficient table of conv_ydep is
 // wave-uniform (scalar loads) and the window reads of neighbouring lanes
 // coalesce in L1.  Accumulation is in double like the reference's numba code
@@ -55,11 +58,103 @@ local_std_kernel(const T* __restrict__ img, const T* __restrict__ blurred, int g
   out[(long)i * opitch + j] = (T)sqrt(val / npx);
 }
 
+// filters/maskedFilter.py:43-72 (_calcMean).  FILL: pixels with mask != 0 get the mean of the
+// mask == 0 pixels in the clipped window (left untouched when there are none) — dst may be
+// src, written pixels are never read.  !FILL: pixels with mask == 0 get that mean, the others
+// NaN (the reference's np.full_like(arr, nan) output).
+template <typename T, bool FILL>
+__global__ void __launch_bounds__(256)
+masked_mean_kernel(const T* src, const unsigned char* __restrict__ mask, int gx, int gy,
+                   long pitch, long mpitch, int k, T* dst, long dpitch) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= gx || j >= gy) return;
+  const bool masked = mask[(long)i * mpitch + j] != 0;
+  if (masked != FILL) {
+    if constexpr (!FILL) dst[(long)i * dpitch + j] = (T)__builtin_nan("");
+    return;
+  }
+  int xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+  int ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+  double val = 0.0;
+  int n = 0;
+  for (int ii = xmn; ii < xmx; ii++)
+    for (int jj = ymn; jj < ymx; jj++)
+      if (!mask[(long)ii * mpitch + jj]) {
+        val += (double)src[(long)ii * pitch + jj];
+        n++;
+      }
+  if (n > 0) dst[(long)i * dpitch + j] = (T)(val / (double)n);
+}
+
+// filters/nan_maximum_filter.py:17-37: np.nanmax over the clipped window (NaN when all NaN)
+template <typename T>
+__global__ void __launch_bounds__(256)
+nan_max_kernel(const T* __restrict__ src, int gx, int gy, long pitch, int k, T* __restrict__ dst,
+               long dpitch) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= gx || j >= gy) return;
+  int xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+  int ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+  T m = (T)__builtin_nan("");
+  for (int ii = xmn; ii < xmx; ii++)
+    for (int jj = ymn; jj < ymx; jj++) {
+      T v = src[(long)ii * pitch + jj];
+      if (v == v && !(m >= v)) m = v;
+    }
+  dst[(long)i * dpitch + j] = m;
+}
+
 }  // namespace ipa
 
 using namespace ipa;
 
 extern "C" {
+
+int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,
+                        int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,
+                        void* d_out, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_arr && d_mask && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && ksize >= 2, "empty image or ksize < 2");
+  IPA_REQUIRE(ctx, pitch >= w && mask_pitch >= w && out_pitch >= w, "pitch smaller than width");
+  IPA_REQUIRE(ctx, fill_mask || d_arr != d_out, "fill_mask=0 cannot run in place");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "masked_mean supports float32/float64 (got dtype %d)", dtype);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+#define IPA_MM(T, FILL)                                                                          \
+  hipLaunchKernelGGL((masked_mean_kernel<T, FILL>), grid, block, 0, ctx->stream, (const T*)d_arr, \
+                     d_mask, h, w, pitch, mask_pitch, ksize / 2, (T*)d_out, out_pitch)
+  if (dtype == IPA_F32) {
+    if (fill_mask) IPA_MM(float, true); else IPA_MM(float, false);
+  } else {
+    if (fill_mask) IPA_MM(double, true); else IPA_MM(double, false);
+  }
+#undef IPA_MM
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,
+                    int ksize, void* d_out, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_arr && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && ksize >= 2, "empty image or ksize < 2");
+  IPA_REQUIRE(ctx, pitch >= w && out_pitch >= w, "pitch smaller than width");
+  IPA_REQUIRE(ctx, d_arr != d_out, "nan_max cannot run in place");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "nan_max supports float32/float64 (got dtype %d)", dtype);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == IPA_F32)
+    hipLaunchKernelGGL((nan_max_kernel<float>), grid, block, 0, ctx->stream, (const float*)d_arr,
+                       h, w, pitch, ksize / 2, (float*)d_out, out_pitch);
+  else
+    hipLaunchKernelGGL((nan_max_kernel<double>), grid, block, 0, ctx->stream,
+                       (const double*)d_arr, h, w, pitch, ksize / 2, (double*)d_out, out_pitch);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
 
 int ipa_conv_ydep_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
                       const double* d_kernels, int k0, int k1, int border_x, int border_y,

@@ -4,3 +4,5 @@ from .maskedConvolve import maskedConvolve  # noqa: F401
 from ._extendArrayForConvolution import extendArrayForConvolution  # noqa: F401
 from .varYSizeGaussianFilter import varYSizeGaussianFilter  # noqa: F401
 from .standardDeviation import standardDeviation2d  # noqa: F401
+from .maskedFilter import maskedFilter  # noqa: F401
+from .nan_maximum_filter import nan_maximum_filter  # noqa: F401

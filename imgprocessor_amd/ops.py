@@ -347,6 +347,51 @@ def local_std(img, blurred, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
+def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None):
+    """filters/maskedFilter.py:43-72 (_calcMean).  fill_mask=True fills ``arr`` IN PLACE (host
+    arrays are copied back into ``arr``); fill_mask=False returns a new NaN-padded array."""
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, mask, ctx=ctx)
+    if dev:
+        if not _is_dev(mask):
+            raise TypeError('device array needs a device mask')
+        d_arr, d_mask = arr, mask
+        if d_arr.dtype not in (np.float32, np.float64):
+            raise TypeError('masked_mean needs float32/float64 arrays')
+    else:
+        if not (isinstance(arr, np.ndarray) and arr.dtype in (np.float32, np.float64)):
+            raise TypeError('masked_mean needs a float32/float64 ndarray')
+        d_arr = ctx.to_device(np.ascontiguousarray(arr))
+        d_mask = ctx.to_device(np.ascontiguousarray(mask, dtype=np.uint8))
+    if d_arr.ndim != 2 or tuple(d_mask.shape) != tuple(d_arr.shape) or d_mask.dtype != np.uint8:
+        raise ValueError('arr and mask must be 2-D arrays of equal shape (mask uint8/bool)')
+    h, w = d_arr.shape
+    d_out = d_arr if fill_mask else DeviceArray(ctx, (h, w), d_arr.dtype)
+    ctx._check(ctx._lib.ipa_masked_mean_dev(ctx.handle, d_arr.ptr, dtype_id(d_arr.dtype),
+                                            d_mask.ptr, h, w, w, w, int(ksize), int(bool(fill_mask)),
+                                            d_out.ptr, w), 'masked_mean')
+    if dev:
+        return d_out
+    if fill_mask:
+        arr[...] = d_out.get()
+        return arr
+    return d_out.get()
+
+
+def nan_max(arr, ksize, ctx=None):
+    """filters/nan_maximum_filter.py:17-37"""
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, ctx=ctx)
+    d_arr = arr if dev else ctx.to_device(_float_img(arr))
+    if d_arr.ndim != 2 or d_arr.dtype not in (np.float32, np.float64):
+        raise TypeError('nan_max needs a 2-D float32/float64 array')
+    h, w = d_arr.shape
+    d_out = DeviceArray(ctx, (h, w), d_arr.dtype)
+    ctx._check(ctx._lib.ipa_nan_max_dev(ctx.handle, d_arr.ptr, dtype_id(d_arr.dtype), h, w, w,
+                                        int(ksize), d_out.ptr, w), 'nan_max')
+    return d_out if dev else d_out.get()
+
+
 # ------------------------------------------------- fused remap -> filter --
 def _fused_out(ctx, src, out, dh, dw, n):
     odt = np.float64 if src.dtype == np.float64 else np.float32

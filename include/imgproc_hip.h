@@ -194,6 +194,23 @@ int ipa_local_std_dev(ipa_ctx* ctx, const void* d_img, const void* d_blurred, in
                       int w, long pitch, long blurred_pitch, int ksize_x, int ksize_y,
                       void* d_out, long out_pitch);
 
+/* replaces filters/maskedFilter.py:43-72 (_calcMean, reached from maskedFilter(fn='mean'),
+ * :12-37): mean of the pixels with mask == 0 inside the window
+ * [i-ksize/2, min(i+ksize/2, h)) x [j-ksize/2, min(j+ksize/2, w)).
+ *   fill_mask != 0: written for the pixels with mask != 0 that have at least one such
+ *                   neighbour, everything else of d_out untouched; d_out may be d_arr
+ *                   (the reference's in-place fill);
+ *   fill_mask == 0: written for the pixels with mask == 0, NaN elsewhere; not in place.
+ * d_mask: DEVICE uint8 h x w (non-zero = masked).  float32/float64, double accumulation. */
+int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,
+                        int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,
+                        void* d_out, long out_pitch);
+
+/* replaces filters/nan_maximum_filter.py:17-37 (_calc): np.nanmax over the same clipped
+ * window; NaN where the whole window is NaN. */
+int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,
+                    int ksize, void* d_out, long out_pitch);
+
 /* replaces filters/_extendArrayForConvolution.py:5-97 for callers that want the
  * padded array itself (the filters above resolve borders while staging and do
  * not need it): dst is (h + 2*(ky/2)) x (w + 2*(kx/2)), kx/ky = kernel size

@@ -14,6 +14,8 @@
  *                                                                 orc_gaussian_kernel1d
  *   - imgProcessor/filters/varYSizeGaussianFilter.py:53-68     -> orc_conv_ydep
  *   - imgProcessor/filters/standardDeviation.py:34-70          -> orc_std2d
+ *   - imgProcessor/filters/maskedFilter.py:43-72 (mean)        -> orc_masked_mean
+ *   - imgProcessor/filters/nan_maximum_filter.py:17-37         -> orc_nan_max
  *   - imgProcessor/interpolate/interpolate2dStructuredIDW.py:26-65      -> orc_idw
  *   - imgProcessor/interpolate/interpolate2dStructuredFastIDW.py:29-63  -> orc_fast_idw
  *   - imgProcessor/camera/LensDistortion.py:316-330,342-358 (cv2.remap,
@@ -681,6 +683,47 @@ int orc_fast_idw(void* grid, int dt, const uint8_t* mask, long s0, long s1, cons
       if (sumWi != 0) store_px(grid, dt, i * s1 + j, value / sumWi);
     }
   free(in);
+  return 0;
+}
+
+/* filters/maskedFilter.py:43-72 (_calcMean): for every pixel with sel[i,j] != 0 the mean of
+ * the pixels with use[ii,jj] != 0 in [i-k, min(i+k,gx)) x [j-k, min(j+k,gy)); written only
+ * when at least one such pixel exists.  out may alias arr (fill_mask=True): pixels that are
+ * written are never read. */
+int orc_masked_mean(const void* arr, int dt, const uint8_t* sel, const uint8_t* use, long gx,
+                    long gy, long k, void* out) {
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      if (!sel[i * gy + j]) continue;
+      long xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+      long ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+      double val = 0;
+      long n = 0;
+      for (long ii = xmn; ii < xmx; ii++)
+        for (long jj = ymn; jj < ymx; jj++)
+          if (use[ii * gy + jj]) { val += load_px(arr, dt, ii * gy + jj); n++; }
+      if (n > 0) store_px(out, dt, i * gy + j, val / (double)n);
+    }
+  return 0;
+}
+
+/* filters/nan_maximum_filter.py:17-37: np.nanmax over [i-k, min(i+k,gx)) x [j-k, min(j+k,gy));
+ * an all-NaN window gives NaN */
+int orc_nan_max(const void* arr, int dt, long gx, long gy, long k, void* out) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      long xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+      long ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+      double m = NAN;
+      for (long ii = xmn; ii < xmx; ii++)
+        for (long jj = ymn; jj < ymx; jj++) {
+          double v = load_px(arr, dt, ii * gy + jj);
+          if (v == v && !(m >= v)) m = v;
+        }
+      store_px(out, dt, i * gy + j, m);
+    }
   return 0;
 }
 

@@ -47,7 +47,7 @@ def lib():
                      'orc_warp_perspective', 'orc_extend_array', 'orc_conv2d',
                      'orc_masked_convolve', 'orc_gaussian_kernel1d', 'orc_sepconv2d',
                      'orc_conv_ydep', 'orc_std2d', 'orc_idw', 'orc_fast_idw',
-                     'orc_remap_conv2d'):
+                     'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max'):
             getattr(_LIB, name).restype = C.c_int
     return _LIB
 
@@ -261,6 +261,33 @@ def standardDeviation2d(img, ksize=5, blurred=None):
     _chk(lib().orc_std2d(_p(img), _dt(img), C.c_long(img.shape[0]), C.c_long(img.shape[1]),
                          C.c_long(ksize[0]), C.c_long(ksize[1]), _p(blurred), _p(std)), 'std2d')
     return std
+
+
+def maskedFilter(arr, mask, ksize=30, fill_mask=True, fn='mean'):
+    """filters/maskedFilter.py:12-37, fn='mean' (the median variant is not restated)"""
+    assert fn == 'mean'
+    mask = np.ascontiguousarray(mask, dtype=bool)
+    if fill_mask:
+        sel, out = mask, arr
+        assert arr.flags.c_contiguous
+    else:
+        sel, out = ~mask, np.full_like(arr, fill_value=np.nan)
+    use = np.ascontiguousarray(~mask, dtype=np.uint8)
+    sel = np.ascontiguousarray(sel, dtype=np.uint8)
+    arr = np.ascontiguousarray(arr)
+    _chk(lib().orc_masked_mean(_p(arr), _dt(arr), _p(sel), _p(use), C.c_long(arr.shape[0]),
+                               C.c_long(arr.shape[1]), C.c_long(ksize // 2), _p(out)),
+         'masked_mean')
+    return out
+
+
+def nan_maximum_filter(arr, ksize):
+    """filters/nan_maximum_filter.py:6-14"""
+    arr = np.ascontiguousarray(arr)
+    out = np.empty_like(arr)
+    _chk(lib().orc_nan_max(_p(arr), _dt(arr), C.c_long(arr.shape[0]), C.c_long(arr.shape[1]),
+                           C.c_long(ksize // 2), _p(out)), 'nan_max')
+    return out
 
 
 # ---------------------------------------------------------- interpolate ----

@@ -193,6 +193,30 @@ def gen_stencils():
     out['grow4_dist'] = dist
     np.savez_compressed(os.path.join(HERE, 'idw.npz'), **out)
 
+    # (f2) maskedFilter (mean) and nan_maximum_filter ------------------------------
+    from imgProcessor.filters.maskedFilter import maskedFilter
+    from imgProcessor.filters.nan_maximum_filter import nan_maximum_filter
+    out = {}
+    a = synth((40, 52), 8, np.float64)
+    rng = np.random.default_rng(13)
+    m = rng.random(a.shape) < 0.2
+    m[5:12, 8:20] = True
+    out['arr'] = a
+    out['mask'] = m
+    for ks in (6, 11, 30):
+        out['mean_fill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=True, fn='mean')
+        out['mean_nofill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=False,
+                                                   fn='mean')
+    a32 = a.astype(np.float32)
+    out['mean32_fill_k6'] = maskedFilter(a32.copy(), m, ksize=6, fill_mask=True, fn='mean')
+    an = a.copy()
+    an[rng.random(a.shape) < 0.3] = np.nan
+    an[20:30, 30:45] = np.nan  # a block bigger than the small windows: stays NaN inside
+    out['arr_nan'] = an
+    for ks in (3, 6, 9):
+        out['nanmax_k%d' % ks] = nan_maximum_filter(an, ks)
+    np.savez_compressed(os.path.join(HERE, 'masked_filter.npz'), **out)
+
 
 # ---------------------------------------------------------------------------
 def undistort_map_np(K, d, newK, h, w):

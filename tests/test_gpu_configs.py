@@ -214,3 +214,43 @@ def test_c5_8k_bicubic_k11(ia, orc):
     banded = np.concatenate(bands)
     # (rows within 5 of a band's own edge see that band's reflect border, and are cropped away)
     assert np.abs(banded - got).max() < 5e-6
+
+
+# ------------------------------------------------- transform/ wrappers (§8 f3) ----
+def test_transform_wrappers(ia, orc):
+    from imgprocessor_amd.transform import (rotate, simplePerspectiveTransform, linearToPolar,
+                                            polarToLinear, linearToPolarMaps)
+    from imgprocessor_amd.transform.rotate import rotation_matrix_2d
+    # rotate: the reference's own check (transform/rotate.py:26-32)
+    a = np.tile(np.linspace(0, 1, 50), (50, 1))
+    c = rotate(rotate(a, 14), -14)
+    assert np.abs(a - c).mean() < 0.005
+    # non-square image: (width, height) = (s0, s1) as the reference passes image.shape to cv2
+    img = synth((60, 90), 4)
+    r = rotate(img, 30)
+    assert r.shape == (90, 60)
+    M = np.vstack([rotation_matrix_2d((59 / 2., 89 / 2.), 30), [0, 0, 1.]])
+    close32(r, orc.warp_perspective(img, np.linalg.inv(M), (90, 60), orc.CUBIC_CV | orc.Q5,
+                                    orc.REFLECT), 'rotate', scale=1.0)
+    # simplePerspectiveTransform: quad -> rectangle of the average edge lengths, and back
+    quad = np.array([(8, 2), (80, 6), (82, 55), (5, 57)], float)
+    out = simplePerspectiveTransform(img, quad)
+    assert out.shape == (52, 75)
+    from imgprocessor_amd.utils import getPerspectiveTransform
+    H = getPerspectiveTransform(quad, [[0, 0], [75, 0], [75, 52], [0, 52]])
+    close32(out, orc.warp_perspective(img, np.linalg.inv(H), (52, 75)), 'simplePersp', scale=1.0)
+    out2 = simplePerspectiveTransform(img, quad, shape=(40, 64), interpolation='cubic')
+    assert out2.shape == (40, 64)
+    # polar maps: the reference's round trip (transform/polarTransform.py:121-127) in spirit:
+    # concentric rings survive linear -> polar -> linear
+    y, x = np.mgrid[0:257, 0:257]
+    rings = (0.5 + 0.5 * np.cos(np.hypot(x - 128, y - 128) / 6.0)).astype(np.float32)
+    pol = linearToPolar(rings)
+    mY, mX = linearToPolarMaps(rings.shape)
+    assert pol.shape == mY.shape
+    close32(pol, orc.remap(rings, mY, mX, orc.LINEAR, orc.REFLECT), 'linearToPolar', scale=1.0)
+    # rings are (nearly) constant along phi in the polar image
+    # (radii < 120 px: beyond that the circle leaves the 257 px image and BORDER_REFLECT fills in)
+    assert np.abs(pol - pol.mean(axis=1, keepdims=True))[5:120].max() < 0.12
+    back = polarToLinear(pol, shape=rings.shape)
+    assert back.shape == rings.shape

@@ -309,6 +309,38 @@ def test_gaussian_golden(ia, oracle):
     close32(gaussian_filter(big, 3.0), oracle.gaussian_filter(big, 3.0), 'sigma 3 (25 taps)')
 
 
+def test_masked_filter_and_nan_max(ia, oracle):
+    from imgprocessor_amd.filters import maskedFilter, nan_maximum_filter
+    g = load_golden('masked_filter.npz')
+    for ks in (6, 11, 30):
+        a = g['arr'].copy()
+        assert maskedFilter(a, g['mask'], ks) is a  # in place like the reference
+        assert_close(a, g['mean_fill_k%d' % ks], 1e-13, 1e-15)
+        got, want = maskedFilter(g['arr'].copy(), g['mask'], ks, fill_mask=False), \
+            g['mean_nofill_k%d' % ks]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert_close(np.nan_to_num(got), np.nan_to_num(want), 1e-13, 1e-15)
+    a32 = g['arr'].astype(np.float32)
+    close32(maskedFilter(a32, g['mask'], 6), g['mean32_fill_k6'], 'mean f32')
+    for ks in (3, 6, 9):
+        assert np.array_equal(nan_maximum_filter(g['arr_nan'], ks), g['nanmax_k%d' % ks],
+                              equal_nan=True)
+    # device arrays + a bigger frame against the oracle (ragged size, all-masked columns)
+    big = synth((301, 517), 21, np.float64)
+    m = np.random.default_rng(3).random(big.shape) < 0.3
+    m[:, 200:240] = True
+    d = ia.default_context().to_device(big)
+    dm = ia.default_context().to_device(m.astype(np.uint8))
+    assert maskedFilter(d, dm, 30) is d
+    assert_close(d.get(), oracle.maskedFilter(big.copy(), m, 30), 1e-13, 1e-15)
+    bn = big.copy()
+    bn[m] = np.nan
+    assert np.array_equal(nan_maximum_filter(bn.astype(np.float32), 7),
+                          oracle.nan_maximum_filter(bn.astype(np.float32), 7), equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        maskedFilter(big, m, 5, fn='median')
+
+
 # ---------------------------------------------------------------- fused ----
 def test_fused_chain(ia, oracle):
     ctx = ia.default_context(0)

@@ -68,6 +68,24 @@ def test_std2d(oracle):
     assert_close(oracle.standardDeviation2d(g['img32'], 5), g['std32_k5'], 2e-6, 1e-7)
 
 
+def test_masked_filter_and_nan_max(oracle):
+    g = load_golden('masked_filter.npz')
+    for ks in (6, 11, 30):
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, True)
+        assert_close(got, g['mean_fill_k%d' % ks], 1e-13, 1e-15)
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, False)
+        want = g['mean_nofill_k%d' % ks]
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert_close(np.nan_to_num(got), np.nan_to_num(want), 1e-13, 1e-15)
+    got = oracle.maskedFilter(g['arr'].astype(np.float32), g['mask'], 6, True)
+    assert got.dtype == np.float32
+    assert_close(got, g['mean32_fill_k6'], 1e-6, 1e-7)
+    for ks in (3, 6, 9):
+        got, want = oracle.nan_maximum_filter(g['arr_nan'], ks), g['nanmax_k%d' % ks]
+        assert np.isnan(want).any() or ks > 3
+        assert np.array_equal(got, want, equal_nan=True)
+
+
 def test_idw(oracle):
     g = load_golden('idw.npz')
     grid = g['grid']
