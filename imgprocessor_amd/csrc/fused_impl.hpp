@@ -54,7 +54,7 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(p.dh, p.dw, f.n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid((p.strips + 3) / 4, (unsigned)f.n_frames), block(256);
+  dim3 grid((p.strips + IPA_WPB - 1) / IPA_WPB, (unsigned)f.n_frames), block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_kernel<Src, K>), grid, block, 0, ctx->stream, p, s, w);
 }
 
@@ -118,7 +118,7 @@ int IPA_CAT(ipa_wave_conv_launch_k, IPA_FUSED_K)(ipa_ctx* ctx, const ipa::WavePa
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(p.dh, p.dw, n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid((p.strips + 3) / 4, (unsigned)n_frames), block(256);
+  dim3 grid((p.strips + IPA_WPB - 1) / IPA_WPB, (unsigned)n_frames), block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_kernel<LoadRowSrc, K>), grid, block, 0, ctx->stream, p, src, w);
   return IPA_OK;
 }

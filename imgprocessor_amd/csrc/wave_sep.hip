@@ -42,7 +42,8 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const LoadRo
       constexpr int d = decltype(Dd)::value;
       const int t = tb + d;
       float cur[4];
-      src.template row<FAST, D>(c, vv, ch, d, cur);
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = ch.v[d][k];
 
       // y pass: the arriving row feeds K intermediate rows
       static_for<0, K>([&](auto Ii) {

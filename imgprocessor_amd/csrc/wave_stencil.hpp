@@ -127,11 +127,14 @@ struct LoadRowSrc {
       }
     }
   }
+  static constexpr int kLdsFloatsPerRow = 0;
   template <bool FAST, int D>
-  __device__ __forceinline__ void row(const Cols&, const int (&)[D], const Chunk<D>& ch, int d,
-                                      float (&cur)[4]) const {
+  __device__ __forceinline__ void rows_of_chunk(const Cols&, const int (&)[D], const Chunk<D>& ch,
+                                                float (&rows)[D][4], float*) const {
 #pragma unroll
-    for (int k = 0; k < 4; k++) cur[k] = ch.v[d][k];
+    for (int d = 0; d < D; d++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) rows[d][k] = ch.v[d][k];
   }
 };
 
@@ -167,12 +170,18 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
   }
   __device__ __forceinline__ bool vectors_ok() const { return !kMap || map_vec != 0; }
 
+  // FAST strips sample in LANE-INTERLEAVED order: footprint k of lane L is strip pixel
+  // L + 64 k, so the 64 gathers of one instruction walk along the source row (neighbouring
+  // lanes hit the same cache lines) instead of striding 4 px; the blended row is put back
+  // into the filter's 4-px-per-lane order through a wave-private LDS row (rows_of_chunk).
+  static constexpr int kLdsFloatsPerRow = 256;
   template <bool FAST>
   __device__ __forceinline__ void coords_of_row(const Cols& c, int vv, C (&sx)[4],
                                                 C (&sy)[4]) const {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      if constexpr (FAST) coord.get(c.xo + k, vv, sx[k], sy[k]);
+      if constexpr (FAST) coord.get(c.xo - 3 * lane + 64 * k, vv, sx[k], sy[k]);
       else coord.get(c.uu[k] < 0 ? 0 : c.uu[k], vv < 0 ? 0 : vv, sx[k], sy[k]);
     }
   }
@@ -182,17 +191,16 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
                                              Chunk<D>& ch) const {
     C sx[D][4], sy[D][4];
     if constexpr (kMap && FAST) {
-      float4 a[D], b[D];  // stage A: every map row of the chunk first
+      // stage A: every map row of the chunk first (4 coalesced dword loads per map row)
+      const int lane = threadIdx.x & 63;
 #pragma unroll
       for (int d = 0; d < D; d++) {
-        long o = (long)vv[d] * coord.pitch + c.xo;
-        a[d] = *reinterpret_cast<const float4*>(coord.mx + o);
-        b[d] = *reinterpret_cast<const float4*>(coord.my + o);
-      }
+        long o = (long)vv[d] * coord.pitch + (c.xo - 3 * lane);
 #pragma unroll
-      for (int d = 0; d < D; d++) {
-        sx[d][0] = a[d].x; sx[d][1] = a[d].y; sx[d][2] = a[d].z; sx[d][3] = a[d].w;
-        sy[d][0] = b[d].x; sy[d][1] = b[d].y; sy[d][2] = b[d].z; sy[d][3] = b[d].w;
+        for (int k = 0; k < 4; k++) {
+          sx[d][k] = coord.mx[o + 64 * k];
+          sy[d][k] = coord.my[o + 64 * k];
+        }
       }
     } else {
 #pragma unroll
@@ -204,22 +212,41 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
   }
 
   template <bool FAST, int D>
-  __device__ __forceinline__ void row(const Cols& c, const int (&vv)[D], const Chunk<D>& ch,
-                                      int d, float (&cur)[4]) const {
+  __device__ __forceinline__ void rows_of_chunk(const Cols& c, const int (&vv)[D],
+                                                const Chunk<D>& ch, float (&rows)[D][4],
+                                                float* xp) const {
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 4; k++) cur[k] = batch_blend_one<ST, INTERP, 4>(s, ch.t[d], k);
-    if (ch.t[d].interior != 0xfu) {
-      // footprints touching the source border (rare): redo them tap by tap
-      C sx[4], sy[4];
-      coords_of_row<FAST>(c, vv[d], sx, sy);
+    for (int d = 0; d < D; d++) {
+      float cur[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (!((ch.t[d].interior >> k) & 1u)) cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+      for (int k = 0; k < 4; k++) cur[k] = batch_blend_one<ST, INTERP, 4>(s, ch.t[d], k);
+      if (ch.t[d].interior != 0xfu) {
+        // footprints touching the source border (rare): redo them tap by tap
+        C sx[4], sy[4];
+        coords_of_row<FAST>(c, vv[d], sx, sy);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (!((ch.t[d].interior >> k) & 1u))
+            cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+      }
+      if constexpr (FAST) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) xp[d * 256 + 64 * k + lane] = cur[k];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) rows[d][k] = (vv[d] < 0 || c.uu[k] < 0) ? ccval : cur[k];
+      }
     }
-    if constexpr (!FAST) {
+    if constexpr (FAST) {
+      // wave-private LDS rows: the wave's own ds_write/ds_read pairs execute in order
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int k = 0; k < 4; k++)
-        if (vv[d] < 0 || c.uu[k] < 0) cur[k] = ccval;
+      for (int d = 0; d < D; d++) {
+        float4 q = *reinterpret_cast<const float4*>(xp + d * 256 + 4 * lane);
+        rows[d][0] = q.x; rows[d][1] = q.y; rows[d][2] = q.z; rows[d][3] = q.w;
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
 };
@@ -237,8 +264,8 @@ __device__ __forceinline__ int opaque_zero_after(float dep) {
 template <bool FAST, typename Src, int K>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                const Weights<float, K * K>& wts,
-                                               const float* wl, const Cols& c, int y0, int nrows,
-                                               bool writer, float* dst) {
+                                               const float* wl, float* xp, const Cols& c,
+                                               int y0, int nrows, bool writer, float* dst) {
   using G = wave_geom<K>;
   constexpr int D = Src::template depth<K>::value;
   const int T = nrows + K - 1;  // input rows of this strip
@@ -255,12 +282,15 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
     }
     typename Src::template Chunk<D> ch;
     src.template load_chunk<FAST, D>(c, vv, ch);
+    float rows[D][4];
+    src.template rows_of_chunk<FAST, D>(c, vv, ch, rows, xp);
 
     static_for<0, D>([&](auto Dd) {
       constexpr int d = decltype(Dd)::value;
       const int t = tb + d;
       float cur[4];
-      src.template row<FAST, D>(c, vv, ch, d, cur);
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = rows[d][k];
 
       // window = own 4 px + H px from each side (neighbouring lanes)
       float win[G::NW];
@@ -337,16 +367,22 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #define IPA_WAVE_MIN_WAVES 1
 #endif
 template <typename Src, int K>
-__global__ void __launch_bounds__(256, IPA_WAVE_MIN_WAVES)
+#ifndef IPA_WPB
+#define IPA_WPB 4   // waves per workgroup
+#endif
+__global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
 wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   using G = wave_geom<K>;
   constexpr int D = Src::template depth<K>::value;
   const int lane = threadIdx.x & 63;
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned sid = b * 4 + (threadIdx.x >> 6);
+  const unsigned sid = b * IPA_WPB + (threadIdx.x >> 6);
   __shared__ float wl[K >= 9 ? K * K : 1];
+  constexpr int kXp = Src::kLdsFloatsPerRow * D;  // per wave
+  __shared__ __attribute__((aligned(16))) float xpose[kXp ? IPA_WPB * kXp : 1];
+  float* xp = xpose + (threadIdx.x >> 6) * kXp;
   if constexpr (K >= 9) {
-    for (int i = threadIdx.x; i < K * K; i += 256) wl[i] = wts.w[i];
+    for (int i = threadIdx.x; i < K * K; i += 64 * IPA_WPB) wl[i] = wts.w[i];
     __syncthreads();
   }
   if (sid >= p.strips) return;  // whole wave
@@ -370,17 +406,19 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
-    wave_run_strip<true, Src, K>(p, src, wts, wl, c, y0, nrows, writer, dst);
+    wave_run_strip<true, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
   } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
-    wave_run_strip<false, Src, K>(p, src, wts, wl, c, y0, nrows, writer, dst);
+    wave_run_strip<false, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
   }
 }
 
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
 // problems enough waves to fill 256 CUs
 static inline int wave_strip_height(int dh, int dw, int n_frames, int K) {
+  if (const char* e = getenv("IPA_STRIP_H"))  // tuning knob (tests/bench_micro.py strip)
+    if (atoi(e) > 0) return atoi(e);
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
   long sx = (dw + ow - 1) / ow;
   // measured on 16 x 4K frames (MI355X): 16-32 rows best, 64 within 3 %, 128+ and 8 clearly
