@@ -104,11 +104,136 @@ nan_max_kernel(const T* __restrict__ src, int gx, int gy, long pitch, int k, T* 
   dst[(long)i * dpitch + j] = m;
 }
 
+// ---------------------------------------------------------------------------
+// 3x3 median + relative threshold (filters/medianThreshold.py:7-30), optionally behind the
+// dark-current / flat-field stages of CameraCalibration.correct
+// (camera/CameraCalibration.py:416-437): the stage-corrected pixel is computed ONCE per pixel
+// into an LDS tile (block 64 x 4 outputs + 1-px symmetric halo), the median is a 19-exchange
+// selection network on the 9 LDS values.
+template <typename T> struct finite_max;
+template <> struct finite_max<float> { static constexpr float value = 3.402823466e+38f; };
+template <> struct finite_max<double> { static constexpr double value = 1.7976931348623157e+308; };
+
+template <typename T> __device__ __forceinline__ void order2(T& a, T& b) {
+  const bool lt = a < b;
+  const T lo = lt ? a : b, hi = lt ? b : a;
+  a = lo;
+  b = hi;
+}
+
+template <typename T> __device__ __forceinline__ T median_of_9(T (&p)[9]) {
+  // exchanges of the classic median-of-9 selection network; p[4] ends as the median
+  constexpr int net[19][2] = {{1, 2}, {4, 5}, {7, 8}, {0, 1}, {3, 4}, {6, 7}, {1, 2},
+                              {4, 5}, {7, 8}, {0, 3}, {5, 8}, {4, 7}, {3, 6}, {1, 4},
+                              {2, 5}, {4, 7}, {4, 2}, {6, 4}, {4, 2}};
+#pragma unroll
+  for (int i = 0; i < 19; i++) order2(p[net[i][0]], p[net[i][1]]);
+  return p[4];
+}
+
+template <typename T, bool CALIB>
+__global__ void __launch_bounds__(256)
+median_threshold_kernel(const T* __restrict__ img, const T* __restrict__ bg,
+                        const T* __restrict__ ff, int h, int w, long pitch, long bgpitch,
+                        long ffpitch, double threshold, int cond_less, T* __restrict__ out,
+                        long opitch, unsigned char* __restrict__ indices, long ipitch) {
+  constexpr int TW = 66, TH = 6;
+  __shared__ T tile[TH][TW + 1];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int e = tid; e < TW * TH; e += 256) {
+    const int ty = e / TW, tx = e - ty * TW;
+    // scipy 'reflect' == edge pixel repeated; the clamp only keeps far-outside halo
+    // elements of edge tiles (never read by an in-range pixel) inside the image
+    int yy = resolve_idx(y0 + ty - 1, h, IPA_BORDER_REFLECT);
+    int xx = resolve_idx(x0 + tx - 1, w, IPA_BORDER_REFLECT);
+    T v = img[(long)yy * pitch + xx];
+    if constexpr (CALIB) {
+      if (bg) v -= bg[(long)yy * bgpitch + xx];
+      if (ff) {
+        const T d = ff[(long)yy * ffpitch + xx];
+        if (d != (T)0) v /= d;
+      }
+      if (threshold > 0) {  // np.nan_to_num belongs to the artefact stage
+        if (v != v) v = (T)0;
+        else if (v > finite_max<T>::value) v = finite_max<T>::value;
+        else if (v < -finite_max<T>::value) v = -finite_max<T>::value;
+      }
+    }
+    tile[ty][tx] = v;
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const T a = tile[threadIdx.y + 1][threadIdx.x + 1];
+  T res = a;
+  bool hit = false;
+  if (threshold > 0) {
+    T p[9];
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+      for (int dx = 0; dx < 3; dx++) p[dy * 3 + dx] = tile[threadIdx.y + dy][threadIdx.x + dx];
+    const T blur = median_of_9(p);
+    const double rel = fabs(((double)a - (double)blur) / (double)blur);
+    hit = cond_less ? rel < threshold : rel > threshold;
+    if (hit) res = blur;
+  }
+  out[(long)y * opitch + x] = res;
+  if (indices) indices[(long)y * ipitch + x] = hit ? 1 : 0;
+}
+
 }  // namespace ipa
 
 using namespace ipa;
 
 extern "C" {
+
+static int median_threshold_launch(ipa_ctx* ctx, const void* d_img, int dtype, const void* d_bg,
+                                   const void* d_ff, bool calib, int h, int w, long pitch,
+                                   long bg_pitch, long ff_pitch, double threshold, int cond_less,
+                                   void* d_out, long out_pitch, unsigned char* d_indices,
+                                   long idx_pitch) {
+  IPA_REQUIRE(ctx, d_img && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0, "empty image");
+  IPA_REQUIRE(ctx, pitch >= w && out_pitch >= w && (!d_bg || bg_pitch >= w) &&
+                       (!d_ff || ff_pitch >= w) && (!d_indices || idx_pitch >= w),
+              "pitch smaller than width");
+  IPA_REQUIRE(ctx, d_img != d_out, "the 3x3 median cannot run in place");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "median threshold supports float32/float64 (got dtype %d)", dtype);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+#define IPA_MT(T, CALIB)                                                                        \
+  hipLaunchKernelGGL((median_threshold_kernel<T, CALIB>), grid, block, 0, ctx->stream,          \
+                     (const T*)d_img, (const T*)d_bg, (const T*)d_ff, h, w, pitch, bg_pitch,     \
+                     ff_pitch, threshold, cond_less, (T*)d_out, out_pitch, d_indices, idx_pitch)
+  if (dtype == IPA_F32) {
+    if (calib) IPA_MT(float, true); else IPA_MT(float, false);
+  } else {
+    if (calib) IPA_MT(double, true); else IPA_MT(double, false);
+  }
+#undef IPA_MT
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_median_threshold_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w, long pitch,
+                             double threshold, int cond_less, void* d_out, long out_pitch,
+                             unsigned char* d_indices, long idx_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, threshold > 0, "threshold must be > 0 (the reference returns the input as is)");
+  return median_threshold_launch(ctx, d_img, dtype, nullptr, nullptr, false, h, w, pitch, 0, 0,
+                                 threshold, cond_less, d_out, out_pitch, d_indices, idx_pitch);
+}
+
+int ipa_calib_prefilter_dev(ipa_ctx* ctx, const void* d_img, int dtype, const void* d_bg,
+                            const void* d_ff, int h, int w, long pitch, long bg_pitch,
+                            long ff_pitch, double threshold, void* d_out, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  return median_threshold_launch(ctx, d_img, dtype, d_bg, d_ff, true, h, w, pitch, bg_pitch,
+                                 ff_pitch, threshold, 0, d_out, out_pitch, nullptr, 0);
+}
 
 int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,
                         int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,

@@ -141,6 +141,14 @@ class DeviceArray(object):
                                                      self.nbytes), 'memcpy_d2h')
         return out
 
+    def copy_from(self, other):
+        """stream-ordered device-to-device copy of an equally shaped DeviceArray"""
+        if other.shape != self.shape or other.dtype != self.dtype:
+            raise ValueError('copy_from needs equal shape and dtype')
+        self.ctx._check(self.ctx._lib.ipa_memcpy_d2d(self.ctx.handle, self.ptr, other.ptr,
+                                                     self.nbytes), 'memcpy_d2d')
+        return self
+
     def frame(self, i):
         """view of frame i of a (n, h, w) batch (no copy, not owning)"""
         if self.ndim != 3:

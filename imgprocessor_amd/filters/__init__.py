@@ -6,3 +6,4 @@ from .varYSizeGaussianFilter import varYSizeGaussianFilter  # noqa: F401
 from .standardDeviation import standardDeviation2d  # noqa: F401
 from .maskedFilter import maskedFilter  # noqa: F401
 from .nan_maximum_filter import nan_maximum_filter  # noqa: F401
+from .medianThreshold import medianThreshold  # noqa: F401

@@ -392,6 +392,59 @@ def nan_max(arr, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
+def median_threshold(img, threshold=0.1, condition='>', want_indices=True, ctx=None):
+    """filters/medianThreshold.py:7-30 (size=3): -> (out, indices) new arrays"""
+    if condition not in ('>', '<'):
+        raise ValueError("condition must be '>' or '<'")
+    dev = _is_dev(img)
+    ctx = _ctx_of(img, ctx=ctx)
+    d_img = img if dev else ctx.to_device(_float_img(img))
+    if d_img.ndim != 2 or d_img.dtype not in (np.float32, np.float64):
+        raise TypeError('median_threshold needs a 2-D float32/float64 array')
+    h, w = d_img.shape
+    d_out = DeviceArray(ctx, (h, w), d_img.dtype)
+    d_idx = DeviceArray(ctx, (h, w), np.uint8) if want_indices else None
+    ctx._check(ctx._lib.ipa_median_threshold_dev(
+        ctx.handle, d_img.ptr, dtype_id(d_img.dtype), h, w, w, float(threshold),
+        int(condition == '<'), d_out.ptr, w, d_idx.ptr if want_indices else None, w),
+        'median_threshold')
+    if dev:
+        return d_out, d_idx
+    return d_out.get(), (d_idx.get().astype(bool) if want_indices else None)
+
+
+def calib_prefilter(img, bg=None, ff=None, threshold=0.1, out=None, ctx=None):
+    """stages 2-4 of CameraCalibration.correct (camera/CameraCalibration.py:416-437) in one
+    kernel: dark current, flat field, nan_to_num + thresholded 3x3 median.  bg / ff are cast to
+    the image dtype; returns a new array (DeviceArray for device input)."""
+    dev = _is_dev(img)
+    ctx = _ctx_of(img, bg, ff, ctx=ctx)
+    d_img = img if dev else ctx.to_device(_float_img(img))
+    if d_img.ndim != 2 or d_img.dtype not in (np.float32, np.float64):
+        raise TypeError('calib_prefilter needs a 2-D float32/float64 array')
+    h, w = d_img.shape
+
+    def side(a, name):
+        if a is None:
+            return None
+        if _is_dev(a):
+            if a.dtype != d_img.dtype or tuple(a.shape) != (h, w):
+                raise ValueError('%s must match the image shape and dtype' % name)
+            return a
+        a = np.asarray(a)
+        if a.shape != (h, w):
+            a = np.broadcast_to(a, (h, w))
+        return ctx.to_device(np.ascontiguousarray(a, dtype=d_img.dtype))
+
+    d_bg, d_ff = side(bg, 'bg'), side(ff, 'ff')
+    d_out = _dev_out(ctx, out, (h, w), d_img.dtype) if dev else DeviceArray(ctx, (h, w), d_img.dtype)
+    ctx._check(ctx._lib.ipa_calib_prefilter_dev(
+        ctx.handle, d_img.ptr, dtype_id(d_img.dtype), d_bg.ptr if d_bg is not None else None,
+        d_ff.ptr if d_ff is not None else None, h, w, w, w, w, float(threshold), d_out.ptr, w),
+        'calib_prefilter')
+    return d_out if dev else d_out.get()
+
+
 # ------------------------------------------------- fused remap -> filter --
 def _fused_out(ctx, src, out, dh, dw, n):
     odt = np.float64 if src.dtype == np.float64 else np.float32

@@ -211,6 +211,25 @@ int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsign
 int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,
                     int ksize, void* d_out, long out_pitch);
 
+/* replaces filters/medianThreshold.py:7-30 with size=3:
+ *   blur = scipy.ndimage.median_filter(img, size=3)   (mode 'reflect': edge pixel repeated)
+ *   hit  = |(img - blur) / blur| > threshold           ('<' when cond_less != 0), float64, IEEE
+ *   out  = hit ? blur : img;   d_indices (uint8 h x w, may be NULL) = hit
+ * threshold must be > 0 (the reference returns its input untouched otherwise).  Not in place. */
+int ipa_median_threshold_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w, long pitch,
+                             double threshold, int cond_less, void* d_out, long out_pitch,
+                             unsigned char* d_indices, long idx_pitch);
+
+/* replaces stages 2-4 of CameraCalibration.correct (camera/CameraCalibration.py:416-437) in one
+ * pass over the frame:
+ *   v = img - bg                      (:505  _correctDarkCurrent;   d_bg NULL = stage skipped)
+ *   v = ff != 0 ? v / ff : v          (:527-528 _correctVignetting; d_ff NULL = stage skipped)
+ *   if threshold > 0: v = nan_to_num(v); medianThreshold(v, threshold, size 3, '>')  (:566-567)
+ * d_bg / d_ff: DEVICE arrays of the image dtype (float32/float64).  Not in place. */
+int ipa_calib_prefilter_dev(ipa_ctx* ctx, const void* d_img, int dtype, const void* d_bg,
+                            const void* d_ff, int h, int w, long pitch, long bg_pitch,
+                            long ff_pitch, double threshold, void* d_out, long out_pitch);
+
 /* replaces filters/_extendArrayForConvolution.py:5-97 for callers that want the
  * padded array itself (the filters above resolve borders while staging and do
  * not need it): dst is (h + 2*(ky/2)) x (w + 2*(kx/2)), kx/ky = kernel size

@@ -727,6 +727,81 @@ int orc_nan_max(const void* arr, int dt, long gx, long gy, long k, void* out) {
   return 0;
 }
 
+/* scipy.ndimage.median_filter(img, size=3) (default mode='reflect' = edge pixel repeated): the
+ * middle of the 9 window values; selection only, so the value is exact in any dtype */
+static double median3x3(const void* img, int dt, long h, long w, long y, long x) {
+  double v[9];
+  int n = 0;
+  for (long dy = -1; dy <= 1; dy++)
+    for (long dx = -1; dx <= 1; dx++)
+      v[n++] = load_px(img, dt, resolve_idx(y + dy, h, ORC_REFLECT) * w +
+                                    resolve_idx(x + dx, w, ORC_REFLECT));
+  for (int i = 1; i < 9; i++) { /* insertion sort */
+    double t = v[i];
+    int j = i - 1;
+    while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; j--; }
+    v[j + 1] = t;
+  }
+  return v[4];
+}
+
+/* filters/medianThreshold.py:7-30 with size=3: blur = float64(median3x3); indices =
+ * |(img - blur) / blur| > threshold ('<' when cond_less); out = indices ? blur : img.
+ * IEEE semantics as numpy under errstate(ignore): blur == 0 gives inf (replaced for '>') or
+ * NaN (0/0: comparison false, kept).  indices may be NULL. */
+int orc_median_threshold(const void* img, int dt, long h, long w, double threshold, int cond_less,
+                         void* out, uint8_t* indices) {
+  if (dt != ORC_F32 && dt != ORC_F64) return -2;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long y = 0; y < h; y++)
+    for (long x = 0; x < w; x++) {
+      double a = load_px(img, dt, y * w + x), blur = median3x3(img, dt, h, w, y, x);
+      double rel = fabs((a - blur) / blur);
+      int hit = cond_less ? rel < threshold : rel > threshold;
+      if (indices) indices[y * w + x] = (uint8_t)hit;
+      store_px(out, dt, y * w + x, hit ? blur : a);
+    }
+  return 0;
+}
+
+/* camera/CameraCalibration.py:416-437 (stages 2-4 of correct()): image -= bg (:505);
+ * image[ff != 0] /= ff[ff != 0] (:527-528); image = np.nan_to_num(image) (:566);
+ * medianThreshold(image, threshold, copy=False) (:567) when threshold > 0 (:430).
+ * bg / ff may be NULL (stage skipped); arithmetic in the image dtype. */
+int orc_calib_prefilter(const void* img, int dt, const void* bg, const void* ff, long h, long w,
+                        double threshold, void* out) {
+  if (dt != ORC_F32 && dt != ORC_F64) return -2;
+  void* tmp = malloc((size_t)h * w * (dt == ORC_F32 ? 4 : 8));
+  if (!tmp) return -3;
+  const double big = dt == ORC_F32 ? (double)FLT_MAX : DBL_MAX;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < h * w; i++) {
+    double v = load_px(img, dt, i);
+    if (bg) {
+      v -= load_px(bg, dt, i);
+      if (dt == ORC_F32) v = (double)(float)v;
+    }
+    if (ff) {
+      double d = load_px(ff, dt, i);
+      if (d != 0) {
+        v /= d;
+        if (dt == ORC_F32) v = (double)(float)v;
+      }
+    }
+    if (threshold > 0) { /* np.nan_to_num is part of _correctArtefacts, skipped with it */
+      if (v != v) v = 0.0;
+      else if (v > big) v = big;
+      else if (v < -big) v = -big;
+    }
+    store_px(tmp, dt, i, v);
+  }
+  int rc = 0;
+  if (threshold > 0) rc = orc_median_threshold(tmp, dt, h, w, threshold, 0, out, NULL);
+  else memcpy(out, tmp, (size_t)h * w * (dt == ORC_F32 ? 4 : 8));
+  free(tmp);
+  return rc;
+}
+
 /* headline chain for the CPU baseline: map-based undistort then K x K filter */
 int orc_remap_conv2d(const void* src, int src_dt, long h, long w, const float* mapx,
                      const float* mapy, const double* kern, long kh, long kw, void* tmp, void* dst,

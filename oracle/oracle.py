@@ -47,7 +47,8 @@ def lib():
                      'orc_warp_perspective', 'orc_extend_array', 'orc_conv2d',
                      'orc_masked_convolve', 'orc_gaussian_kernel1d', 'orc_sepconv2d',
                      'orc_conv_ydep', 'orc_std2d', 'orc_idw', 'orc_fast_idw',
-                     'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max'):
+                     'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max',
+                     'orc_median_threshold', 'orc_calib_prefilter'):
             getattr(_LIB, name).restype = C.c_int
     return _LIB
 
@@ -287,6 +288,38 @@ def nan_maximum_filter(arr, ksize):
     out = np.empty_like(arr)
     _chk(lib().orc_nan_max(_p(arr), _dt(arr), C.c_long(arr.shape[0]), C.c_long(arr.shape[1]),
                            C.c_long(ksize // 2), _p(out)), 'nan_max')
+    return out
+
+
+def medianThreshold(img, threshold=0.1, size=3, condition='>', copy=True):
+    """filters/medianThreshold.py:7-30 (size=3 only) -> (img, indices)"""
+    assert size == 3
+    if not threshold > 0:
+        return img, None
+    src = np.ascontiguousarray(img)
+    out = np.empty_like(src)
+    idx = np.empty(src.shape, np.uint8)
+    _chk(lib().orc_median_threshold(_p(src), _dt(src), C.c_long(src.shape[0]),
+                                    C.c_long(src.shape[1]), C.c_double(threshold),
+                                    C.c_int(condition != '>'), _p(out), _p(idx)),
+         'median_threshold')
+    if copy:
+        return out, idx.astype(bool)
+    img[...] = out
+    return img, idx.astype(bool)
+
+
+def calib_prefilter(img, bg=None, ff=None, threshold=0.1):
+    """camera/CameraCalibration.py:416-437 + :505, :527-528, :566-567: dark current,
+    flat field, nan_to_num, thresholded 3x3 median — returns a new array"""
+    img = np.ascontiguousarray(img)
+    out = np.empty_like(img)
+    b = None if bg is None else np.ascontiguousarray(bg, dtype=img.dtype)
+    f = None if ff is None else np.ascontiguousarray(ff, dtype=img.dtype)
+    _chk(lib().orc_calib_prefilter(_p(img), _dt(img), _p(b) if b is not None else None,
+                                   _p(f) if f is not None else None, C.c_long(img.shape[0]),
+                                   C.c_long(img.shape[1]), C.c_double(threshold), _p(out)),
+         'calib_prefilter')
     return out
 
 

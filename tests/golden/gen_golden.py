@@ -217,6 +217,54 @@ def gen_stencils():
         out['nanmax_k%d' % ks] = nan_maximum_filter(an, ks)
     np.savez_compressed(os.path.join(HERE, 'masked_filter.npz'), **out)
 
+    # (f2/f4) medianThreshold and the pre-lens stages of CameraCalibration.correct -------
+    from imgProcessor.filters.medianThreshold import medianThreshold
+    if not hasattr(np, 'asfarray'):  # removed in numpy 2; documented behaviour restored
+        np.asfarray = lambda a, dtype=np.float64: np.asarray(a, dtype=dtype)
+    out = {}
+    rng = np.random.default_rng(14)
+    a = 0.2 + synth((45, 61), 9, np.float64)
+    spikes = rng.random(a.shape) < 0.03
+    a[spikes] *= rng.choice([0.2, 3.0, 10.0], size=spikes.sum())
+    a[7, 9] = 0.0
+    a[0, 0] = 5.0     # corners / edges: reflect border of the median
+    a[44, 60] = 0.01
+    out['img'] = a
+    for thr, cond in ((0.1, '>'), (0.5, '>'), (0.05, '<')):
+        o, ind = medianThreshold(a, thr, condition=cond)
+        key = 'thr%s_%s' % (str(thr).replace('.', 'p'), 'gt' if cond == '>' else 'lt')
+        out['out_' + key] = o
+        out['ind_' + key] = ind
+    a32 = a.astype(np.float32)
+    o, ind = medianThreshold(a32, 0.1)
+    out['out32_thr0p1_gt'], out['ind32_thr0p1_gt'] = o, ind
+    z = a.copy()
+    z[20:24, 30:34] = 0.0   # 3x3 median == 0 inside: (img-0)/0 = nan (kept) / inf (replaced)
+    z[21, 31] = 1.0
+    out['img_zero'] = z
+    out['out_zero'], out['ind_zero'] = medianThreshold(z, 0.1)
+    # CameraCalibration.correct stages 2-4 as written at camera/CameraCalibration.py:505
+    # (image -= bg), :527-528 (image[i] /= d[i], i = d != 0), :566-567 (nan_to_num, then the
+    # reference's medianThreshold in place).  The module itself needs cv2 to import, so the three
+    # numpy statements are restated here around the reference's own medianThreshold.
+    raw = 40 + 1000 * a
+    bg = 40 + rng.standard_normal(a.shape)
+    ff = 0.6 + 0.4 * synth((45, 61), 10, np.float64)
+    ff[3, 4] = 0.0          # untouched by the division
+    raw[10, 10] = np.nan    # -> 0 by nan_to_num
+    raw[30, 40] = np.inf    # -> finfo.max by nan_to_num
+    out['cal_raw'], out['cal_bg'], out['cal_ff'] = raw, bg, ff
+    for thr in (0.1, 0.0):
+        image = raw.copy()
+        image -= bg
+        i = ff != 0
+        image[i] /= ff[i]
+        if thr > 0:
+            image = np.nan_to_num(image)
+            medianThreshold(image, thr, copy=False)
+        out['cal_out_thr%s' % str(thr).replace('.', 'p')] = image
+    np.savez_compressed(os.path.join(HERE, 'median_threshold.npz'), **out)
+
 
 # ---------------------------------------------------------------------------
 def undistort_map_np(K, d, newK, h, w):

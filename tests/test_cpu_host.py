@@ -182,6 +182,54 @@ def test_perspective_correction_host_side():
         pc2.homography
 
 
+def test_camera_calibration_host_side(tmp_path):
+    """container, date lookup and .cal pickle round trip (CameraCalibration.py:60-322, 583-604)"""
+    from imgprocessor_amd.camera.CameraCalibration import CameraCalibration, _getFromDate
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    cal = CameraCalibration()
+    cal.setCamera('cam0', 12)
+    ff_old, ff_new = np.full((6, 8), 0.5), np.full((6, 8), 0.8)
+    cal.addFlatField(ff_old, date='01 Nov 15 - 10:00', info='old')
+    cal.addFlatField(ff_new, date='30 Nov 15 - 13:20', info='new', light_spectrum='IR')
+    cal.addFlatField(ff_new, date='30 Nov 15 - 13:20', info='new')
+    assert cal.coeffs['shape'] == (6, 8) and cal.coeffs['light spectra'] == ['visible', 'IR']
+    assert cal.dates('flat field', 'visible') == ['30 Nov 15 - 13:20', '01 Nov 15 - 10:00']
+    assert cal.infos('flat field', 'visible') == ['new', 'old']
+    with pytest.raises(Exception):
+        cal.addFlatField(np.ones((8, 6)))
+    # newest entry for date=None; for a date, the entry just NEWER than it (l[i-1], :37-49)
+    assert cal.getCoeff('flat field', 'visible')[1] == 'new'
+    assert cal.getCoeff('flat field', 'visible', '15 Nov 15 - 00:00')[1] == 'new'
+    assert cal.getCoeff('flat field', 'visible', '15 Oct 15 - 00:00')[1] == 'old'
+    assert cal.getCoeff('flat field', 'UV')[1] == 'new'        # falls back to the first light
+    assert cal.getCoeff('psf', 'visible') is None
+    assert _getFromDate([['x']], 'not a date') == ['x']
+    cal.addDarkCurrent(np.full((6, 8), 3.0), date='02 Nov 15 - 10:00')
+    assert np.array_equal(cal.calcDarkCurrent(1.5), np.full((6, 8), 3.0))
+    cal.addDarkCurrent(np.ones((6, 8)), np.zeros((6, 8)), date='03 Nov 15 - 10:00')
+    assert type(cal.calcDarkCurrent(1.5)) is tuple  # as written at :509 - never evaluated
+    ld = LensDistortion()
+    ld.setCameraParams(8., 8., 3.5, 2.5, -0.1, 0.0, 0.0, 0.0, 0.0)
+    ld.coeffs['shape'] = (6, 8)
+    cal.addLens(ld, date='04 Nov 15 - 10:00')
+    path = cal.saveToFile(str(tmp_path / 'cam'))
+    assert path.endswith('.cal')
+    cal2 = CameraCalibration.loadFromFile(str(tmp_path / 'cam'))
+    assert cal2.coeffs['name'] == 'cam0' and cal2.coeffs['depth'] == 12
+    assert np.array_equal(cal2.getCoeff('flat field', 'IR')[2], ff_new)
+    assert np.array_equal(cal2.getCoeff('lens', 'visible')[2]['cameraMatrix'],
+                          ld.coeffs['cameraMatrix'])
+    cal2.transpose()
+    assert cal2.coeffs['shape'] == (8, 6) and cal2.getCoeff('flat field', 'IR')[2].shape == (8, 6)
+    cal.addNoise([1., 2., 3.], date='05 Nov 15 - 10:00')
+    cal.clearOldCalibrations()  # keeps entry [-1] of the newest-first lists (:289-298)
+    assert cal.infos('flat field', 'visible') == ['old']
+    with pytest.raises(NotImplementedError):
+        cal.correct(np.zeros((6, 8)), deblur=True)
+    with pytest.raises(NotImplementedError):
+        cal.correct([np.zeros((6, 8)), np.zeros((6, 8))])
+
+
 # ---------------------------------------------------------------- sharding --
 def test_frame_blocks():
     from imgprocessor_amd.sharding import frame_block, all_blocks

@@ -341,6 +341,88 @@ def test_masked_filter_and_nan_max(ia, oracle):
         maskedFilter(big, m, 5, fn='median')
 
 
+def test_median_threshold_golden(ia, oracle):
+    from imgprocessor_amd.filters import medianThreshold
+    g = load_golden('median_threshold.npz')
+    for key, thr, cond in (('thr0p1_gt', 0.1, '>'), ('thr0p5_gt', 0.5, '>'),
+                           ('thr0p05_lt', 0.05, '<')):
+        out, ind = medianThreshold(g['img'], thr, condition=cond)
+        assert np.array_equal(out, g['out_' + key]), key
+        assert ind.dtype == bool and np.array_equal(ind, g['ind_' + key]), key
+    out, ind = medianThreshold(g['img'].astype(np.float32), 0.1)
+    assert out.dtype == np.float32 and np.array_equal(out, g['out32_thr0p1_gt'])
+    assert np.array_equal(ind, g['ind32_thr0p1_gt'])
+    out, ind = medianThreshold(g['img_zero'], 0.1)
+    assert np.array_equal(out, g['out_zero']) and np.array_equal(ind, g['ind_zero'])
+    img = g['img'].copy()
+    assert medianThreshold(img, 0.1, copy=False)[0] is img
+    assert np.array_equal(img, g['out_thr0p1_gt'])
+    assert medianThreshold(img, 0.0) == (img, None)
+    with pytest.raises(NotImplementedError):
+        medianThreshold(img, 0.1, size=5)
+    # ragged sizes (tile edges in both directions) against the oracle, device arrays
+    big = 0.2 + synth((203, 391), 5, np.float64)
+    big[::7, ::11] *= 4
+    d = ia.default_context().to_device(big)
+    dout, dind = medianThreshold(d, 0.2)
+    want, wind = oracle.medianThreshold(big, 0.2)
+    assert np.array_equal(dout.get(), want) and np.array_equal(dind.get().astype(bool), wind)
+    one = synth((1, 5), 1, np.float32) + 0.5  # single row: every vertical neighbour is the row
+    assert np.array_equal(medianThreshold(one, 0.01)[0], oracle.medianThreshold(one, 0.01)[0])
+
+
+def test_camera_calibration_correct(ia, oracle, capsys):
+    """CameraCalibration.correct: stages 2-4 pinned by the golden chain, stage 5 = the lens remap"""
+    from imgprocessor_amd.camera.CameraCalibration import CameraCalibration
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    g = load_golden('median_threshold.npz')
+    raw, bg, ff = g['cal_raw'], g['cal_bg'], g['cal_ff']
+    for thr, key in ((0.1, 'cal_out_thr0p1'), (0.0, 'cal_out_thr0p0')):
+        got = ia.ops.calib_prefilter(raw, bg, ff, thr)
+        assert np.array_equal(got, g[key], equal_nan=True), key
+    assert np.array_equal(ia.ops.calib_prefilter(raw, None, None, 0.0), raw, equal_nan=True)
+    r32 = raw.astype(np.float32)
+    assert np.array_equal(ia.ops.calib_prefilter(r32, bg, ff, 0.1),
+                          oracle.calib_prefilter(r32, bg, ff, 0.1))
+
+    cal = CameraCalibration()
+    cal.addDarkCurrent(bg, date='02 Nov 15 - 10:00')
+    cal.addFlatField(ff, date='03 Nov 15 - 10:00')
+    out = cal.correct(raw, exposure_time=1.0, threshold=0.1)
+    assert 'CORRECT CAMERA' in capsys.readouterr().out
+    assert out.dtype == np.float64 and np.array_equal(out, g['cal_out_thr0p1'])
+    # explicit background image wins over the stored dark current (:481-498)
+    out = cal.correct(raw, bgImages=[bg + 1.0], threshold=0.1)
+    assert np.array_equal(out, oracle.calib_prefilter(raw, bg + 1.0, ff, 0.1))
+    # + lens stage: equals the oracle chain prefilter -> undistort (keep_size True and False)
+    h, w = raw.shape
+    from imgprocessor_amd.utils import getOptimalNewCameraMatrix
+    ld = LensDistortion()
+    ld.setCameraParams(60., 60., (w - 1) / 2., (h - 1) / 2., -0.12, 0.03, 0.0, 1e-3, -5e-4)
+    ld.coeffs['shape'] = (h, w)
+    cal.addLens(ld, date='04 Nov 15 - 10:00')
+    out_lens = cal.correct(raw, exposure_time=1.0, threshold=0.1, keep_size=True)
+    K, d = ld.coeffs['cameraMatrix'], ld.coeffs['distortionCoeffs'].ravel()
+    nK, roi = getOptimalNewCameraMatrix(K, d, (w, h), 1, (w, h))
+    want = oracle.undistort(g['cal_out_thr0p1'], K, d, nK)
+    assert out_lens.shape == (h, w)
+    assert_close(out_lens, want, 1e-12, 1e-9)
+    crop = cal.correct(raw, exposure_time=1.0, threshold=0.1, keep_size=False)
+    x, y, rw, rh = roi
+    assert_close(crop, want[y:y + rh, x:x + rw], 1e-12, 1e-9)
+    # the reference's dark-current model is broken for (slope, intercept): stage reported+skipped
+    cal2 = CameraCalibration()
+    cal2.addDarkCurrent(bg, np.zeros_like(bg), date='02 Nov 15 - 10:00')
+    out = cal2.correct(raw, exposure_time=1.0, threshold=0.0)
+    assert 'Error:' in capsys.readouterr().out
+    assert np.array_equal(out, raw, equal_nan=True)
+    # float32 frames (extension) and device-resident frames
+    out32 = cal.correct(r32, exposure_time=1.0, threshold=0.1, dtype=np.float32)
+    assert out32.dtype == np.float32 and np.abs(out32 - want).max() < 2e-3 * np.abs(want).max()
+    dev = cal.correct(ia.default_context().to_device(raw), exposure_time=1.0, threshold=0.1)
+    assert np.array_equal(dev.get(), out_lens)
+
+
 # ---------------------------------------------------------------- fused ----
 def test_fused_chain(ia, oracle):
     ctx = ia.default_context(0)

@@ -86,6 +86,30 @@ def test_masked_filter_and_nan_max(oracle):
         assert np.array_equal(got, want, equal_nan=True)
 
 
+def test_median_threshold_and_calibration_stages(oracle):
+    """bit-exact against the reference's medianThreshold and the numpy statements of
+    CameraCalibration.correct stages 2-4 (selection + IEEE division only)"""
+    g = load_golden('median_threshold.npz')
+    for key, thr, cond in (('thr0p1_gt', 0.1, '>'), ('thr0p5_gt', 0.5, '>'),
+                           ('thr0p05_lt', 0.05, '<')):
+        out, ind = oracle.medianThreshold(g['img'], thr, condition=cond)
+        assert np.array_equal(out, g['out_' + key]) and np.array_equal(ind, g['ind_' + key])
+        assert 0 < ind.sum() < ind.size
+    out, ind = oracle.medianThreshold(g['img'].astype(np.float32), 0.1)
+    assert out.dtype == np.float32 and np.array_equal(out, g['out32_thr0p1_gt'])
+    assert np.array_equal(ind, g['ind32_thr0p1_gt'])
+    out, ind = oracle.medianThreshold(g['img_zero'], 0.1)  # median == 0: inf replaced, nan kept
+    assert np.array_equal(out, g['out_zero']) and np.array_equal(ind, g['ind_zero'])
+    img = g['img'].copy()
+    assert oracle.medianThreshold(img, 0.1, copy=False)[0] is img
+    assert np.array_equal(img, g['out_thr0p1_gt'])
+    assert oracle.medianThreshold(img, 0.0) == (img, None)
+    for thr, key in ((0.1, 'cal_out_thr0p1'), (0.0, 'cal_out_thr0p0')):
+        got = oracle.calib_prefilter(g['cal_raw'], g['cal_bg'], g['cal_ff'], thr)
+        assert np.array_equal(got, g[key], equal_nan=True), key
+    assert np.isnan(g['cal_out_thr0p0']).any() and np.isfinite(g['cal_out_thr0p1']).all()
+
+
 def test_idw(oracle):
     g = load_golden('idw.npz')
     grid = g['grid']
