@@ -278,10 +278,13 @@ template <typename ST, int INTERP, int N> struct BatchTaps {
   unsigned interior;  // bit k: footprint k fully inside the source
 };
 
-template <int INTERP, typename CT, typename C>
+// QM selects the coordinate rule at compile time where the caller can (the per-strip loops
+// of wave_stencil.hpp): -1 = s.q5 decides at run time, 0 = exact, 1 = 1/32-px rounding
+template <int INTERP, typename CT, typename C, int QM = -1>
 __device__ __forceinline__ void axis_frac(const SrcView& s, C c, int& i0, CT& t) {
   int ip;
-  if (s.q5) {
+  const bool q5 = QM < 0 ? s.q5 != 0 : QM == 1;
+  if (q5) {
     int qi = (int)ipa_rint(c * (C)32);
     ip = qi >> 5;
     t = (CT)(qi & 31) * (CT)0.03125;
@@ -305,7 +308,7 @@ __device__ __forceinline__ void weights_from_frac(const SrcView& s, CT t,
   }
 }
 
-template <typename ST, int INTERP, int N, typename C>
+template <typename ST, int INTERP, int N, int QM = -1, typename C>
 __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], const C (&sy)[N],
                                             BatchTaps<ST, INTERP, N>& b) {
   using CT = typename compute_of<ST>::type;
@@ -318,11 +321,13 @@ __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], 
     bool ok = sx[k] > (C)-kCoordLimit && sx[k] < (C)kCoordLimit && sy[k] > (C)-kCoordLimit &&
               sy[k] < (C)kCoordLimit;
     int ix0, iy0;
-    axis_frac<INTERP, CT, C>(s, ok ? sx[k] : (C)0, ix0, b.tx[k]);
-    axis_frac<INTERP, CT, C>(s, ok ? sy[k] : (C)0, iy0, b.ty[k]);
+    axis_frac<INTERP, CT, C, QM>(s, ok ? sx[k] : (C)0, ix0, b.tx[k]);
+    axis_frac<INTERP, CT, C, QM>(s, ok ? sy[k] : (C)0, iy0, b.ty[k]);
     bool in = ok && ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
     b.interior |= in ? (1u << k) : 0u;
-    e[k] = in ? iy0 * s.pitch + ix0 : 0;
+    // |iy0| <= kCoordLimit < 2^23 and pitch < 2^23 (checked at the entry points): one
+    // full-rate v_mul_i32_i24 (+ add) instead of a quarter-rate 32-bit multiply
+    e[k] = in ? __mul24(iy0, s.pitch) + ix0 : 0;
   }
 #pragma unroll
   for (int k = 0; k < N; k++)

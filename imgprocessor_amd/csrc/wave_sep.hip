@@ -86,7 +86,9 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const LoadRo
           float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
           const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
           if constexpr (FAST) {
-            *reinterpret_cast<float4*>(row) = float4{out[0], out[1], out[2], out[3]};
+            float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
+            *reinterpret_cast<float4*>(rows_ + 4u * (threadIdx.x & 63u)) =
+                float4{out[0], out[1], out[2], out[3]};
           } else if (p.vec_out && n == 4) {
             *reinterpret_cast<float4*>(row) = float4{out[0], out[1], out[2], out[3]};
           } else {
@@ -106,14 +108,18 @@ wave_sep_kernel(WaveParams p, LoadRowSrc src, SepTaps<K> w, float xcval) {
   constexpr int H = K / 2, D = 4, OW = 256 - 8;
   static_assert(H <= 4, "one halo lane per side");
   const int lane = threadIdx.x & 63;
-  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned sid = b * 4 + (threadIdx.x >> 6);
+  unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
+  if (p.frames_inner) {  // dispatch order of wave_stencil_kernel
+    frame = b % (unsigned)p.frames_inner;
+    b /= (unsigned)p.frames_inner;
+  }
+  const unsigned sid = b * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
   if (sid >= p.strips) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
-  const unsigned frame = blockIdx.y;
   src.set_frame(frame);
   const int xs = sxi * OW - 4;
   Cols c;
+  c.xs = xs;
   c.xo = xs + lane * 4;
   const int y0 = syi * p.strip_h;
   const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
@@ -144,7 +150,7 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const LoadRowSrc& src, const 
   p.strips_x = (p.dw + 247) / 248;
   p.strip_h = wave_strip_height(p.dh, p.dw, n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid((p.strips + 3) / 4, (unsigned)n_frames), block(256);
+  dim3 grid = wave_grid(p, n_frames, 4, true), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<K>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 

@@ -82,11 +82,25 @@ struct WaveParams {
   int strips_x, strip_h;
   unsigned strips;     // per frame
   int vec_out;
+  int frames_inner;    // 0: grid.y = frame; n: 1-D grid, frame index fastest (see the kernel)
 };
+
+// grid for a launch over n_frames; fills p.frames_inner
+static inline dim3 wave_grid(WaveParams& p, int n_frames, int waves_per_block, bool frames_inner) {
+  unsigned blocks = (p.strips + waves_per_block - 1) / waves_per_block;
+  if (const char* e = getenv("IPA_FRAMES_INNER")) frames_inner = atoi(e) != 0;  // tuning knob
+  if (frames_inner && n_frames > 1 && (unsigned long)blocks * n_frames < (1ul << 31)) {
+    p.frames_inner = n_frames;
+    return dim3(blocks * (unsigned)n_frames, 1);
+  }
+  p.frames_inner = 0;
+  return dim3(blocks, (unsigned)n_frames);
+}
 
 // columns of the filter domain a lane covers, resolved once per strip
 struct Cols {
-  int xo;       // first column (may be < 0 or >= dw for halo lanes at the rim)
+  int xs;       // first column of the strip (lane 0) - wave-uniform, lives in an SGPR
+  int xo;       // first column of the lane = xs + 4*lane (may be < 0 or >= dw at the rim)
   int uu[4];    // border-resolved column per pixel, -1 = constant border
 };
 
@@ -109,13 +123,16 @@ struct LoadRowSrc {
   __device__ __forceinline__ void set_frame(unsigned f) { base += (long)f * frame_elems; }
   __device__ __forceinline__ bool vectors_ok() const { return vec_in != 0; }
 
-  template <bool FAST, int D>
+  static constexpr bool kHasQ5 = false;
+  template <bool FAST, int D, int QM = -1>
   __device__ __forceinline__ void load_chunk(const Cols& c, const int (&vv)[D],
                                              Chunk<D>& ch) const {
 #pragma unroll
     for (int d = 0; d < D; d++) {
       if constexpr (FAST) {
-        float4 q = *reinterpret_cast<const float4*>(base + (long)vv[d] * pitch + c.xo);
+        // scalar row pointer + unsigned 32-bit lane offset: global_load with an SGPR base
+        const float* rowp = base + ((long)vv[d] * pitch + c.xs);
+        float4 q = *reinterpret_cast<const float4*>(rowp + 4u * (threadIdx.x & 63u));
         ch.v[d][0] = q.x; ch.v[d][1] = q.y; ch.v[d][2] = q.z; ch.v[d][3] = q.w;
       } else {
         const float* row = base + (long)(vv[d] < 0 ? 0 : vv[d]) * pitch;
@@ -181,25 +198,28 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      if constexpr (FAST) coord.get(c.xo - 3 * lane + 64 * k, vv, sx[k], sy[k]);
+      if constexpr (FAST) coord.get(c.xs + lane + 64 * k, vv, sx[k], sy[k]);
       else coord.get(c.uu[k] < 0 ? 0 : c.uu[k], vv < 0 ? 0 : vv, sx[k], sy[k]);
     }
   }
 
-  template <bool FAST, int D>
+  static constexpr bool kHasQ5 = true;  // FAST strips pick the coordinate rule per strip
+  template <bool FAST, int D, int QM = -1>
   __device__ __forceinline__ void load_chunk(const Cols& c, const int (&vv)[D],
                                              Chunk<D>& ch) const {
     C sx[D][4], sy[D][4];
     if constexpr (kMap && FAST) {
-      // stage A: every map row of the chunk first (4 coalesced dword loads per map row)
-      const int lane = threadIdx.x & 63;
+      // every map row of the chunk first (4 coalesced dword loads per map row)
+      const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
       for (int d = 0; d < D; d++) {
-        long o = (long)vv[d] * coord.pitch + (c.xo - 3 * lane);
+        const long o = (long)vv[d] * coord.pitch + c.xs;  // scalar
+        const float* rx = coord.mx + o;
+        const float* ry = coord.my + o;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-          sx[d][k] = coord.mx[o + 64 * k];
-          sy[d][k] = coord.my[o + 64 * k];
+          sx[d][k] = rx[lane + 64u * k];
+          sy[d][k] = ry[lane + 64u * k];
         }
       }
     } else {
@@ -208,7 +228,7 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     }
     // stage B: footprints + all tap gathers of the chunk
 #pragma unroll
-    for (int d = 0; d < D; d++) batch_issue<ST, INTERP, 4>(s, sx[d], sy[d], ch.t[d]);
+    for (int d = 0; d < D; d++) batch_issue<ST, INTERP, 4, QM>(s, sx[d], sy[d], ch.t[d]);
   }
 
   template <bool FAST, int D>
@@ -261,7 +281,7 @@ __device__ __forceinline__ int opaque_zero_after(float dep) {
   return z;
 }
 
-template <bool FAST, typename Src, int K>
+template <bool FAST, typename Src, int K, int QM = -1>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                const Weights<float, K * K>& wts,
                                                const float* wl, float* xp, const Cols& c,
@@ -281,7 +301,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
       else vv[d] = resolve_idx(y0 - G::H + tb + d, p.dh, p.cby);
     }
     typename Src::template Chunk<D> ch;
-    src.template load_chunk<FAST, D>(c, vv, ch);
+    src.template load_chunk<FAST, D, QM>(c, vv, ch);
     float rows[D][4];
     src.template rows_of_chunk<FAST, D>(c, vv, ch, rows, xp);
 
@@ -348,7 +368,8 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
         float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
         const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
         if constexpr (FAST) {  // FAST strips: whole 16-byte-aligned chunks inside the image
-          *reinterpret_cast<float4*>(row) =
+          float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
+          *reinterpret_cast<float4*>(rows_ + 4u * (threadIdx.x & 63u)) =
               float4{acc[K - 1][0], acc[K - 1][1], acc[K - 1][2], acc[K - 1][3]};
         } else if (p.vec_out && n == 4) {
           *reinterpret_cast<float4*>(row) =
@@ -375,23 +396,34 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   using G = wave_geom<K>;
   constexpr int D = Src::template depth<K>::value;
   const int lane = threadIdx.x & 63;
-  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned sid = b * IPA_WPB + (threadIdx.x >> 6);
+  // Two dispatch orders.  grid = (strip blocks, frames): frame after frame.  grid = (strip
+  // blocks * frames, 1) with p.frames_inner = n_frames: the frames of ONE strip block are
+  // neighbours in the (XCD-contiguous) order, so they run at the same time on the same XCD and
+  // the read-only rows they share (the remap's map rows) are fetched into that L2 once.
+  unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
+  if (p.frames_inner) {
+    frame = b % (unsigned)p.frames_inner;
+    b /= (unsigned)p.frames_inner;
+  }
+  // the wave index as a SCALAR: everything derived from the strip id (rows, row addresses,
+  // the FAST decision) then lives in SGPRs and is computed on the scalar unit
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned sid = b * IPA_WPB + wave;
   __shared__ float wl[K >= 9 ? K * K : 1];
   constexpr int kXp = Src::kLdsFloatsPerRow * D;  // per wave
   __shared__ __attribute__((aligned(16))) float xpose[kXp ? IPA_WPB * kXp : 1];
-  float* xp = xpose + (threadIdx.x >> 6) * kXp;
+  float* xp = xpose + wave * kXp;
   if constexpr (K >= 9) {
     for (int i = threadIdx.x; i < K * K; i += 64 * IPA_WPB) wl[i] = wts.w[i];
     __syncthreads();
   }
   if (sid >= p.strips) return;  // whole wave
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
-  const unsigned frame = blockIdx.y;
   src.set_frame(frame);
 
   const int xs = sxi * G::OW - 4 * G::HL;  // first column of the strip (lane 0)
   Cols c;
+  c.xs = xs;
   c.xo = xs + lane * 4;
   const int y0 = syi * p.strip_h;
   const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
@@ -406,7 +438,13 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
-    wave_run_strip<true, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+    if constexpr (Src::kHasQ5) {
+      // wave-uniform choice hoisted out of the per-sample code
+      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+      else wave_run_strip<true, Src, K, 0>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+    } else {
+      wave_run_strip<true, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
