@@ -1,36 +1,48 @@
 // wave_stencil.hpp — the K x K stencil skeleton tuned for CDNA4: a wave64
-// marches down a column strip, no LDS, no barriers.
+// marches down a column strip; no workgroup barrier, LDS only wave-private.
 //
 //   * one wave owns a strip 256 px wide (64 lanes x 4 px: every global access
 //     is a coalesced 16-byte-per-lane vector) and `strip_h` output rows tall;
+//     everything derived from the strip id is wave-uniform and lives in SGPRs
+//     (the wave index is read with readfirstlane), rows are addressed as a
+//     scalar base + a 32-bit lane offset;
 //   * it walks the strip's strip_h + K - 1 input rows top to bottom in CHUNKS
 //     of D rows.  All memory traffic of a chunk is issued up front in straight-
 //     line code (D row loads; for the fused kernels D map-row loads, then the
 //     4 x D tap gathers), only then are the rows consumed one by one — so the
-//     waitcnt scoreboard sees counted waits and every wave keeps D KB (plus
-//     8 D gathers) in flight; 12-16 waves per CU cover the HBM latency without
-//     any workgroup-level staging phase;
-//   * horizontal neighbours come from the adjacent lanes with DPP wave shifts
-//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1) — a K/2-px exchange per row
-//     instead of an LDS round trip;
+//     waitcnt scoreboard sees counted waits; 16-20 waves per CU cover the
+//     latency without any workgroup-level staging phase;
+//   * every arriving row goes through a wave-private LDS row (256 px + pad).
+//     Each lane reads the K+2 overlapping PAIRS of its 4 + 2H pixel window
+//     from it: the horizontal halo needs no cross-lane exchange, and one
+//     v_pk_fma_f32 per coefficient advances two output pixels.  The wave's own
+//     ds_write / ds_read execute in order: no barrier;
 //   * vertical reuse is in registers: an arriving input row is scattered into
-//     the K output rows it contributes to (K x 4 running sums per lane, shifted
-//     by one row per step inside the fma chain itself); the oldest row is
-//     complete after each step and is stored as one float4.
-//     Strips overlap by 8*HL px (HL = halo lanes per side) instead of loading
-//     ragged halos: lanes 0 and 63 (0,1,62,63 for K = 11) only supply
-//     neighbours.
+//     the K output rows it contributes to (K x 2 running pair sums per lane,
+//     shifted by one row per step inside the fma chain itself); the oldest row
+//     is complete after each step and is stored as one float4.
+//     Strips overlap by 8 px instead of loading ragged halos: lanes 0 and 63
+//     only supply neighbours.
 //
 // Input rows are produced by a row source: plain image rows (the filters/
 // convolution) or remapped rows sampled on the fly (undistort / perspective
 // warp fused with the filter: the intermediate image never exists in HBM).
+// Interior strips of the sampling source take their footprints in lane-
+// interleaved order (footprint k of lane L = strip pixel L + 64 k), so the 64
+// gathers of one instruction walk along the source row; the LDS row puts the
+// samples back into pixel order for free.
 //
 // Two code paths per kernel, chosen per strip (wave-uniform):
 //   FAST  every column and row the strip touches lies inside the image and
-//         vector alignment holds: unconditional 16-byte accesses;
+//         vector alignment holds: unconditional 16-byte accesses; the remap's
+//         coordinate rule (exact / 1/32-px) is a compile-time parameter here;
 //   rim   strips touching the image border: columns / rows are resolved
 //         through the FILTER's border mode (per lane once, per row on the
 //         scalar unit), element accesses with selects instead of branches.
+//
+// Dispatch order: the frames of one strip block are neighbours in the
+// XCD-contiguous block order (wave_grid / frames_inner), so a batch's frames
+// march through the same map rows together and fetch them into L2 once.
 //
 // Summation order per output pixel is identical to conv_tile.hpp: kernel rows
 // i = 0..K-1, taps j = 0..K-1, one float fma chain -> bit-identical results.
@@ -109,12 +121,17 @@ struct Cols {
 // (vv[d] = border-resolved row, -1 = constant border; never -1 when FAST);
 // row<FAST, D>(d) turns row d of the chunk into the lane's 4 pixels.
 
+// LDS row of a wave: 256 strip pixels + 4 pad floats on each side (the halo lanes' windows
+// reach past the strip; what they read there is never used)
+constexpr int kRowPad = 4, kRowStride = 256 + 2 * kRowPad;
+
 // plain float32 image rows
 struct LoadRowSrc {
 #ifndef IPA_LOAD_DEPTH
 #define IPA_LOAD_DEPTH 8
 #endif
-  template <int K> struct depth { static constexpr int value = K >= 9 ? 4 : IPA_LOAD_DEPTH; };
+  // K = 7 holds 9 window pairs + 14 sum pairs per lane: a shallow chunk keeps occupancy 5
+  template <int K> struct depth { static constexpr int value = K >= 7 ? 2 : IPA_LOAD_DEPTH; };
   template <int D> struct Chunk { float v[D][4]; };
   const float* base;   // frame 0
   long frame_elems, pitch;
@@ -144,14 +161,15 @@ struct LoadRowSrc {
       }
     }
   }
-  static constexpr int kLdsFloatsPerRow = 0;
+  // rows of the chunk into the wave's LDS rows (natural pixel order, see wave_run_strip)
   template <bool FAST, int D>
-  __device__ __forceinline__ void rows_of_chunk(const Cols&, const int (&)[D], const Chunk<D>& ch,
-                                                float (&rows)[D][4], float*) const {
+  __device__ __forceinline__ void stage_rows(const Cols&, const int (&)[D], const Chunk<D>& ch,
+                                             float* xp) const {
+    const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
     for (int d = 0; d < D; d++)
-#pragma unroll
-      for (int k = 0; k < 4; k++) rows[d][k] = ch.v[d][k];
+      *reinterpret_cast<float4*>(xp + d * kRowStride + kRowPad + 4u * lane) =
+          float4{ch.v[d][0], ch.v[d][1], ch.v[d][2], ch.v[d][3]};
   }
 };
 
@@ -189,9 +207,8 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 
   // FAST strips sample in LANE-INTERLEAVED order: footprint k of lane L is strip pixel
   // L + 64 k, so the 64 gathers of one instruction walk along the source row (neighbouring
-  // lanes hit the same cache lines) instead of striding 4 px; the blended row is put back
-  // into the filter's 4-px-per-lane order through a wave-private LDS row (rows_of_chunk).
-  static constexpr int kLdsFloatsPerRow = 256;
+  // lanes hit the same cache lines) instead of striding 4 px; stage_rows writes the blended
+  // samples to the wave's LDS row at their pixel positions.
   template <bool FAST>
   __device__ __forceinline__ void coords_of_row(const Cols& c, int vv, C (&sx)[4],
                                                 C (&sy)[4]) const {
@@ -231,11 +248,11 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     for (int d = 0; d < D; d++) batch_issue<ST, INTERP, 4, QM>(s, sx[d], sy[d], ch.t[d]);
   }
 
+  // blend the chunk's samples and put the rows into the wave's LDS rows in natural pixel order
   template <bool FAST, int D>
-  __device__ __forceinline__ void rows_of_chunk(const Cols& c, const int (&vv)[D],
-                                                const Chunk<D>& ch, float (&rows)[D][4],
-                                                float* xp) const {
-    const int lane = threadIdx.x & 63;
+  __device__ __forceinline__ void stage_rows(const Cols& c, const int (&vv)[D],
+                                             const Chunk<D>& ch, float* xp) const {
+    const unsigned lane = threadIdx.x & 63u;
 #pragma unroll
     for (int d = 0; d < D; d++) {
       float cur[4];
@@ -250,48 +267,44 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
           if (!((ch.t[d].interior >> k) & 1u))
             cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
       }
-      if constexpr (FAST) {
+      float* row = xp + d * kRowStride + kRowPad;
+      if constexpr (FAST) {  // lane-interleaved samples: pixel L + 64 k
 #pragma unroll
-        for (int k = 0; k < 4; k++) xp[d * 256 + 64 * k + lane] = cur[k];
+        for (int k = 0; k < 4; k++) row[64u * k + lane] = cur[k];
       } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) rows[d][k] = (vv[d] < 0 || c.uu[k] < 0) ? ccval : cur[k];
+        for (int k = 0; k < 4; k++) cur[k] = (vv[d] < 0 || c.uu[k] < 0) ? ccval : cur[k];
+        *reinterpret_cast<float4*>(row + 4u * lane) = float4{cur[0], cur[1], cur[2], cur[3]};
       }
-    }
-    if constexpr (FAST) {
-      // wave-private LDS rows: the wave's own ds_write/ds_read pairs execute in order
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        float4 q = *reinterpret_cast<const float4*>(xp + d * 256 + 4 * lane);
-        rows[d][0] = q.x; rows[d][1] = q.y; rows[d][2] = q.z; rows[d][3] = q.w;
-      }
-      __builtin_amdgcn_wave_barrier();
     }
   }
 };
 
 // -------------------------------------------------------------------- kernel --
-// a zero the optimiser cannot see through: added to the LDS index of a
-// coefficient it keeps the reads inside the row loop (big kernels: 81/121
-// coefficients fit neither the SGPR file nor, hoisted, the VGPR budget)
-__device__ __forceinline__ int opaque_zero_after(float dep) {
-  int z;
-  asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(dep));
-  return z;
-}
+// Row windows come from LDS and the K x K sums run in packed fp32:
+// every arriving row is first written to a wave-private LDS row (natural pixel order), then
+// each lane reads the K+2 overlapping PAIRS (px m, px m+1) of its 4 + 2H pixel window - the
+// horizontal halo comes out of the same reads, no DPP exchange - and one v_pk_fma_f32 per
+// coefficient and pixel pair advances two output pixels.  Summation order per pixel is
+// unchanged (rows i, taps j ascending).
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <bool FAST, typename Src, int K, int QM = -1>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
-                                               const Weights<float, K * K>& wts,
-                                               const float* wl, float* xp, const Cols& c,
-                                               int y0, int nrows, bool writer, float* dst) {
+                                                   const Weights<float, K * K>& wts, float* xp,
+                                                   const Cols& c, int y0, int nrows, bool writer,
+                                                   float* dst) {
   using G = wave_geom<K>;
+  static_assert(K <= 7, "coefficients live in SGPRs");
   constexpr int D = Src::template depth<K>::value;
   const int T = nrows + K - 1;  // input rows of this strip
+  const unsigned lane = threadIdx.x & 63u;
 
-  // acc[i] = running sums of output row (t - i) after input row t was added
-  float acc[K][4];
+  unsigned lane4_opaque = 4u * lane;
+  asm volatile("" : "+v"(lane4_opaque));
+
+  // acc[i][h] = running sums of output row (t - i), pixel pair h, after input row t was added
+  v2f acc[K][2];
 #pragma unroll 1
   for (int tb = 0; tb < T; tb += D) {
     int vv[D];  // wave-uniform row indices of the chunk (border-resolved on the rim path)
@@ -302,61 +315,36 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
     }
     typename Src::template Chunk<D> ch;
     src.template load_chunk<FAST, D, QM>(c, vv, ch);
-    float rows[D][4];
-    src.template rows_of_chunk<FAST, D>(c, vv, ch, rows, xp);
+    src.template stage_rows<FAST, D>(c, vv, ch, xp);
+    // wave-private LDS rows: the wave's own ds_write / ds_read execute in order
+    __builtin_amdgcn_wave_barrier();
 
     static_for<0, D>([&](auto Dd) {
       constexpr int d = decltype(Dd)::value;
       const int t = tb + d;
-      float cur[4];
+      // pair[m] = (px 4L-H+m, px 4L-H+m+1), m = 0 .. K+1
+      // Pairs at even and at odd m are read through two offsets the compiler cannot relate:
+      // read once, the odd pairs would straddle register pairs and fall back to scalar fmas.
+      const float* wp = xp + d * kRowStride + kRowPad - G::H + 4u * lane;
+      const float* wq = xp + d * kRowStride + kRowPad - G::H + lane4_opaque;
+      v2f pair[K + 2];
 #pragma unroll
-      for (int k = 0; k < 4; k++) cur[k] = rows[d][k];
+      for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
 
-      // window = own 4 px + H px from each side (neighbouring lanes)
-      float win[G::NW];
-#pragma unroll
-      for (int k = 0; k < 4; k++) win[G::H + k] = cur[k];
-      {
-        float l1[4], r1[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          l1[k] = from_lane_below(cur[k]);
-          r1[k] = from_lane_above(cur[k]);
-        }
-#pragma unroll
-        for (int m = 0; m < G::H && m < 4; m++) {
-          win[G::H - 1 - m] = l1[3 - m];
-          win[G::H + 4 + m] = r1[m];
-        }
-        if constexpr (G::H > 4) {
-#pragma unroll
-          for (int m = 4; m < G::H; m++) {
-            win[G::H - 1 - m] = from_lane_below(l1[3 - (m - 4)]);
-            win[G::H + 4 + m] = from_lane_above(r1[m - 4]);
-          }
-        }
-      }
-
-      // scatter this input row into the K output rows it feeds.  Going from
-      // the oldest output row down, the first fma of row i reads acc[i-1] and
-      // writes acc[i]: the running sums shift by one row per step for free.
       static_for<0, K>([&](auto Ii) {
         constexpr int i = K - 1 - decltype(Ii)::value;
-        // K >= 9: coefficients come from LDS (uniform address = broadcast read,
-        // re-read every row step); smaller kernels keep them in SGPRs.  The
-        // opaque zero is chained to the previous kernel row's result so only
-        // one row of K coefficients is live at a time.
-        int z = 0;
-        if constexpr (K >= 9) z = opaque_zero_after(i == K - 1 ? win[0] : acc[i + 1][3]);
 #pragma unroll
         for (int j = 0; j < K; j++) {
-          const float w = K >= 9 ? wl[i * K + j + z] : wts.w[i * K + j];
+          const float w = wts.w[i * K + j];
+          const v2f w2 = v2f{w, w};
 #pragma unroll
-          for (int ox = 0; ox < 4; ox++) {
+          for (int h = 0; h < 2; h++) {
             if constexpr (i == 0) {
-              acc[0][ox] = j == 0 ? w * win[ox] : fmaf(w, win[ox + j], acc[0][ox]);
+              acc[0][h] = j == 0 ? w2 * pair[2 * h]
+                                 : __builtin_elementwise_fma(w2, pair[j + 2 * h], acc[0][h]);
             } else {
-              acc[i][ox] = fmaf(w, win[ox + j], j == 0 ? acc[i - 1][ox] : acc[i][ox]);
+              acc[i][h] = __builtin_elementwise_fma(w2, pair[j + 2 * h],
+                                                    j == 0 ? acc[i - 1][h] : acc[i][h]);
             }
           }
         }
@@ -365,22 +353,23 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
       // output row t - (K-1) is complete
       const int o = t - (K - 1);
       if (o >= 0 && o < nrows && writer) {
+        const float4 q = float4{acc[K - 1][0].x, acc[K - 1][0].y, acc[K - 1][1].x, acc[K - 1][1].y};
         float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
         const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
         if constexpr (FAST) {  // FAST strips: whole 16-byte-aligned chunks inside the image
           float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
-          *reinterpret_cast<float4*>(rows_ + 4u * (threadIdx.x & 63u)) =
-              float4{acc[K - 1][0], acc[K - 1][1], acc[K - 1][2], acc[K - 1][3]};
+          *reinterpret_cast<float4*>(rows_ + 4u * lane) = q;
         } else if (p.vec_out && n == 4) {
-          *reinterpret_cast<float4*>(row) =
-              float4{acc[K - 1][0], acc[K - 1][1], acc[K - 1][2], acc[K - 1][3]};
+          *reinterpret_cast<float4*>(row) = q;
         } else {
+          const float e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
           for (int k = 0; k < 4; k++)
-            if (k < n) row[k] = acc[K - 1][k];
+            if (k < n) row[k] = e[k];
         }
       }
     });
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -409,14 +398,9 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   // the FAST decision) then lives in SGPRs and is computed on the scalar unit
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned sid = b * IPA_WPB + wave;
-  __shared__ float wl[K >= 9 ? K * K : 1];
-  constexpr int kXp = Src::kLdsFloatsPerRow * D;  // per wave
-  __shared__ __attribute__((aligned(16))) float xpose[kXp ? IPA_WPB * kXp : 1];
+  constexpr int kXp = kRowStride * D;  // LDS floats per wave
+  __shared__ __attribute__((aligned(16))) float xpose[IPA_WPB * kXp];
   float* xp = xpose + wave * kXp;
-  if constexpr (K >= 9) {
-    for (int i = threadIdx.x; i < K * K; i += 64 * IPA_WPB) wl[i] = wts.w[i];
-    __syncthreads();
-  }
   if (sid >= p.strips) return;  // whole wave
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
   src.set_frame(frame);
@@ -440,15 +424,15 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
     if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
-      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
-      else wave_run_strip<true, Src, K, 0>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst);
+      else wave_run_strip<true, Src, K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst);
     } else {
-      wave_run_strip<true, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+      wave_run_strip<true, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst);
     }
   } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
-    wave_run_strip<false, Src, K>(p, src, wts, wl, xp, c, y0, nrows, writer, dst);
+    wave_run_strip<false, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst);
   }
 }
 
