@@ -56,20 +56,38 @@ def gauss5():
     return np.outer(g, g)
 
 
-def cpu_baseline(h, w, K, dist, k5, budget_s=12.0):
-    """oracle (C restatement, 'port') on the host cores; bounded sample"""
+def usable_cores():
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            txt = open(path).read().split()
+            if path.endswith('cpu.max'):
+                quota, period = txt[0], float(txt[1])
+            else:
+                quota, period = txt[0], float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota not in ('max', '-1'):
+                n = min(n, max(1, int(float(quota) / period)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, n)
+
+
+def cpu_baseline(h, w, K, dist, k5, budget_s=15.0):
+    """oracle (C restatement, 'port') on the host cores; bounded sample.  The thread counts
+    1, usable cores and a few in between are timed; the fastest is reported with ITS count."""
     from oracle import oracle as orc
     orc.build()
     frame = synth_frames(1, h, w, 1000)[0]
     mx, my = orc.build_undistort_map(K, dist, K, h, w)
-    res = {}
-    # cores this process may actually run on (cgroup/affinity), not the host's core count
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    avail = max(1, min(avail, orc.max_threads()))
-    for label, threads in (('1', 1), ('all', avail)):
+    avail = max(1, min(usable_cores(), orc.max_threads()))
+    counts = sorted({1, avail} | {c for c in (4, 8, 16, 32) if c < avail})
+    res, total = {}, 0
+    for threads in counts:
         orc.set_threads(threads)
         orc.remap_conv2d(frame, mx, my, k5)  # warm
         n, t0 = 0, time.perf_counter()
@@ -77,15 +95,16 @@ def cpu_baseline(h, w, K, dist, k5, budget_s=12.0):
             orc.remap_conv2d(frame, mx, my, k5)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s / 2 or n >= 50:
+            if el > budget_s / len(counts) or n >= 50:
                 break
-        res[label] = (n * h * w / el / 1e6, threads, n)
+        res[threads] = n * h * w / el / 1e6
+        total += n
     orc.set_threads(1)
-    v_all, cores, n_all = res['all']
-    return {'value': round(v_all, 2), 'unit': 'Mpix/s', 'cores': cores, 'kind': 'port',
-            'sample': '%d frame(s) of %dx%d float32, map-based undistort + 5x5, oracle/oracle.c '
-                      'with OpenMP on %d threads; single-thread: %.2f Mpix/s'
-                      % (n_all, w, h, cores, res['1'][0])}
+    best = max(res, key=res.get)
+    return {'value': round(res[best], 2), 'unit': 'Mpix/s', 'cores': best, 'kind': 'port',
+            'sample': '%d frame(s) of %dx%d float32 in total, map-based undistort + 5x5, '
+                      'oracle/oracle.c with OpenMP; Mpix/s by thread count: %s'
+                      % (total, w, h, ', '.join('%d: %.1f' % (c, res[c]) for c in counts))}
 
 
 def pmc_traffic(variant, batch, h, w):

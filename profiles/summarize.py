@@ -24,13 +24,18 @@ import shutil
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def find(d, pattern):
+    return glob.glob(os.path.join(d, pattern)) + glob.glob(os.path.join(d, '*', pattern))
+
+
 def mean_counter(d, counter):
-    out = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(d, '*', '*counter_collection.csv')):
+    """per kernel: mean over dispatches of the counter summed over its rows of one dispatch"""
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for f in find(d, '*counter_collection.csv'):
         for r in csv.DictReader(open(f)):
             if r['Counter_Name'] == counter:
-                out[r['Kernel_Name']].append(float(r['Counter_Value']))
-    return {k: (sum(v) / len(v), len(v)) for k, v in out.items()}
+                per[r['Kernel_Name']][r['Dispatch_Id']] += float(r['Counter_Value'])
+    return {k: (sum(v.values()) / len(v), len(v)) for k, v in per.items()}
 
 
 def main():
@@ -45,7 +50,7 @@ def main():
     ap.add_argument('--width', type=int, default=3840)
     a = ap.parse_args()
 
-    stats = glob.glob(os.path.join(a.stats_dir, '*', '*kernel_stats.csv'))
+    stats = find(a.stats_dir, '*kernel_stats.csv')
     if stats:
         shutil.copy(stats[0], os.path.join(HERE, '%s_kernel_stats.csv' % a.tag))
     fetch = mean_counter(a.fetch_dir, 'FETCH_SIZE')
