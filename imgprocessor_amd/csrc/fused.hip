@@ -42,6 +42,7 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   IPA_REQUIRE(ctx, d_src && d_dst && kernel, "null pointer");
   IPA_REQUIRE(ctx, sh > 0 && sw > 0 && dh > 0 && dw > 0, "empty image");
   IPA_REQUIRE(ctx, src_pitch >= sw && dst_pitch >= dw, "pitch smaller than width");
+  IPA_REQUIRE(ctx, src_pitch < (1l << 23), "source pitch must be below 2^23 elements");  // mul24
   IPA_REQUIRE(ctx, n_frames >= 1 && n_frames <= 65535, "n_frames must be in [1,65535]");
   int rc = ipa_check_interp_border(ctx, interp, border_mode);
   if (rc) return rc;

@@ -212,6 +212,7 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   IPA_REQUIRE(ctx, a.sh > 0 && a.sw > 0 && a.dh > 0 && a.dw > 0, "empty image (%dx%d -> %dx%d)",
               a.sh, a.sw, a.dh, a.dw);
   IPA_REQUIRE(ctx, a.spitch >= a.sw && a.dpitch >= a.dw, "pitch smaller than width");
+  IPA_REQUIRE(ctx, a.spitch < (1l << 23), "source pitch must be below 2^23 elements");  // mul24
   IPA_REQUIRE(ctx, a.n_frames >= 1 && a.n_frames <= 65535, "n_frames must be in [1,65535]");
   int rc = ipa_check_interp_border(ctx, a.interp, a.border);
   if (rc) return rc;

@@ -94,6 +94,30 @@ def persp(quad, h, w):
     return np.linalg.inv(getPerspectiveTransform(np.array(quad, float), dst))
 
 
+def test_c1_512_masked_convolve_box3(ia, orc):
+    """C1 (the reference's own CPU-runnable case): 512x512 float32, maskedConvolve with
+    ones(3,3)/9 and an all-true mask == filter(img, box3) == scipy uniform_filter(3, 'reflect')
+    (SURVEY §8c probe: 5.6e-16 against the reference itself)"""
+    import io
+    import contextlib
+    import scipy.ndimage as ndi
+    from imgprocessor_amd.filters import maskedConvolve, filter as ipa_filter
+    img = synth((512, 512), 0)
+    box = np.ones((3, 3)) / 9
+    with contextlib.redirect_stdout(io.StringIO()):  # the reference prints the padded shape
+        got = maskedConvolve(img, box, np.ones(img.shape, bool))
+    assert got.dtype == np.float32 and got.shape == img.shape
+    close32(got, orc.maskedConvolve(img, box, np.ones(img.shape, bool)), 'C1 vs oracle', scale=1.0)
+    close32(got, ndi.uniform_filter(img.astype(np.float64), 3, mode='reflect'), 'C1 vs scipy',
+            scale=1.0)
+    assert np.array_equal(got, ipa_filter(img, box))  # the identity of SURVEY §8b
+    half = np.zeros(img.shape, bool)
+    half[:, :256] = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = maskedConvolve(img, box, half)
+    assert np.array_equal(m[:, :256], got[:, :256]) and not m[:, 256:].any()
+
+
 def test_c2_1080p_undistort_gauss5(ia, orc):
     """C2: 1080p float32, LensDistortion radial undistort + 5x5 Gaussian"""
     from imgprocessor_amd.camera.LensDistortion import LensDistortion

@@ -86,6 +86,17 @@ def test_masked_filter_and_nan_max(oracle):
         assert np.array_equal(got, want, equal_nan=True)
 
 
+def test_c1_512_box3(oracle):
+    """BASELINE config C1 at full size: maskedConvolve(ones(3,3)/9, all-true mask) equals
+    scipy's uniform_filter(3, 'reflect') (the SURVEY §8c probe against the reference itself)"""
+    import scipy.ndimage as ndi
+    from .conftest import synth
+    img = synth((512, 512), 0)
+    got = oracle.maskedConvolve(img, np.ones((3, 3)) / 9, np.ones(img.shape, bool))
+    assert got.dtype == np.float32
+    assert_close(got, ndi.uniform_filter(img.astype(np.float64), 3, mode='reflect'), 1e-6, 1e-7)
+
+
 def test_median_threshold_and_calibration_stages(oracle):
     """bit-exact against the reference's medianThreshold and the numpy statements of
     CameraCalibration.correct stages 2-4 (selection + IEEE division only)"""
