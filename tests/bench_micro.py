@@ -70,3 +70,29 @@ if __name__ == '__main__':
         t = timeit(ctx, lambda: ops.undistort(src, Kc, dc, Kc, out=dst))
         print('undistort(analytic) %8.1f us  %7.1f Gpx/s %6.0f GB/s(8B/px)'
               % (t, px / t / 1e3, 8 * px / t / 1e3))
+    if what == 'host':
+        # PCIe-inclusive: host ndarray in, host ndarray out (pageable numpy buffers), one 4K frame
+        import time
+        from imgprocessor_amd.camera.LensDistortion import LensDistortion
+        from imgprocessor_amd.filters import filter as ipa_filter
+        img = src.get()[0]
+        ld = LensDistortion(newCameraMatrix='same', ctx=ctx)
+        ld.setCameraParams(Kc[0, 0], Kc[1, 1], Kc[0, 2], Kc[1, 2], dc[0], dc[1], dc[4], dc[2], dc[3])
+        dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
+
+        def wall(fn, n=10):
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            return (time.perf_counter() - t0) / n * 1e3
+        t = wall(lambda: ipa_filter(ld.correct(img, keepSize=True), k5))
+        print('host: correct() then filter(), 2 round trips   %7.2f ms/frame  %6.2f Gpx/s'
+              % (t, h * w / t / 1e6))
+        t = wall(lambda: ops.remap_conv2d(ctx.to_device(img), dmx, dmy, k5).get())
+        print('host: fused remap_conv2d, 1 round trip          %7.2f ms/frame  %6.2f Gpx/s'
+              % (t, h * w / t / 1e6))
+        batch = src.get()
+        t = wall(lambda: ops.remap_conv2d(ctx.to_device(batch), dmx, dmy, k5).get(), n=3)
+        print('host: fused, 16-frame batch, 1 round trip       %7.2f ms/frame  %6.2f Gpx/s'
+              % (t / B, B * h * w / t / 1e6))
