@@ -71,6 +71,12 @@ PROTOTYPES = {
                                  _i, _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
     'ipa_warp_perspective_conv2d_dev': [_vp, _vp, _i, _i, _i, _l, _dp, _dp, _i, _i, _vp, _i, _i,
                                         _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
+    'ipa_remap_sepconv2d_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _dp, _i, _dp, _i, _vp, _i,
+                                _i, _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
+    'ipa_undistort_sepconv2d_dev': [_vp, _vp, _i, _i, _i, _l, _dp, _dp, _dp, _dp, _i, _dp, _i, _vp,
+                                    _i, _i, _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
+    'ipa_warp_perspective_sepconv2d_dev': [_vp, _vp, _i, _i, _i, _l, _dp, _dp, _i, _dp, _i, _vp, _i,
+                                           _i, _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],
     'ipa_idw_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _dp],
     'ipa_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _dp],
     'ipa_fast_idw_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _vp, _dp, _i, _i],

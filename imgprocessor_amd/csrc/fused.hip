@@ -1,8 +1,11 @@
 // fused.hip — C-ABI entry points of the fused remap -> K x K filter chain
 // (kernels: fused_impl.hpp, one translation unit per K).
-#include "fused_impl.hpp"
+#include "fused_sep_impl.hpp"
 
 using namespace ipa;
+
+void ipa_fused_sep_launch_a(ipa_ctx*, const FusedCall&, const FusedSep&);  // 3, 5 taps
+void ipa_fused_sep_launch_b(ipa_ctx*, const FusedCall&, const FusedSep&);  // 7, 9 taps
 
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
@@ -34,12 +37,12 @@ static int big_kernel_tmp(ipa_ctx* ctx, int kh, int kw, int dst_dtype, int dh, i
   return IPA_OK;
 }
 
-static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
-                        int sw, long src_pitch, const double* kernel, int kh, int kw, void* d_dst,
-                        int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
-                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
-                        double border_value, int cbx, int cby) {
-  IPA_REQUIRE(ctx, d_src && d_dst && kernel, "null pointer");
+// validation + everything of a FusedCall that does not depend on the filter
+static int fused_fill(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh, int sw,
+                      long src_pitch, void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch,
+                      int n_frames, long src_frame_stride, long dst_frame_stride, int interp,
+                      int border_mode, double border_value, int cbx, int cby) {
+  IPA_REQUIRE(ctx, d_src && d_dst, "null pointer");
   IPA_REQUIRE(ctx, sh > 0 && sw > 0 && dh > 0 && dw > 0, "empty image");
   IPA_REQUIRE(ctx, src_pitch >= sw && dst_pitch >= dw, "pitch smaller than width");
   IPA_REQUIRE(ctx, src_pitch < (1l << 23), "source pitch must be below 2^23 elements");  // mul24
@@ -48,9 +51,6 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   if (rc) return rc;
   IPA_REQUIRE(ctx, cbx >= 0 && cbx <= IPA_BORDER_REFLECT101 && cby >= 0 && cby <= IPA_BORDER_REFLECT101,
               "unknown filter border mode");
-  if (kh != kw || !(kh == 3 || kh == 5 || kh == 7 || kh == 9 || kh == 11))
-    IPA_UNSUPPORTED(ctx, "fused remap+filter is built for square 3/5/7/9/11 kernels (got %dx%d); "
-                         "use ipa_remap_dev + ipa_conv2d_dev", kh, kw);
   size_t ss = ipa_dtype_size(src_dtype), ds = ipa_dtype_size(dst_dtype);
   IPA_REQUIRE(ctx, ss && ds, "unknown dtype");
   size_t frame_bytes = ((size_t)(sh - 1) * src_pitch + sw) * ss;
@@ -77,6 +77,23 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   else
     f.map_vec = 0;
   f.src_dt = src_dtype; f.dst_dt = dst_dtype; f.interp_base = base; f.n_frames = n_frames;
+  f.kernel = nullptr;
+  return IPA_OK;
+}
+
+static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
+                        int sw, long src_pitch, const double* kernel, int kh, int kw, void* d_dst,
+                        int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                        double border_value, int cbx, int cby) {
+  IPA_REQUIRE(ctx, kernel, "null pointer");
+  if (kh != kw || !(kh == 3 || kh == 5 || kh == 7 || kh == 9 || kh == 11))
+    IPA_UNSUPPORTED(ctx, "fused remap+filter is built for square 3/5/7/9/11 kernels (got %dx%d); "
+                         "use ipa_remap_dev + ipa_conv2d_dev", kh, kw);
+  int rc = fused_fill(ctx, f, d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw,
+                      dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp, border_mode,
+                      border_value, cbx, cby);
+  if (rc) return rc;
   f.kernel = kernel;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   switch (kh) {
@@ -90,7 +107,119 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   return IPA_OK;
 }
 
+// remap -> separable filter.  One kernel where wave_sep_kernel covers the case; otherwise
+// `two(tmp)` materialises the remap in the context workspace and the plain separable filter
+// follows (same results: the fused kernel rounds the remapped row to float32 as well).
+template <typename TwoLaunch>
+static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const void* d_src,
+                            int src_dtype, int sh, int sw, long src_pitch, const double* ky, int nky,
+                            const double* kx, int nkx, void* d_dst, int dst_dtype, int dh, int dw,
+                            long dst_pitch, int n_frames, long src_frame_stride,
+                            long dst_frame_stride, int interp, int border_mode, double border_value,
+                            int cby, int cbx) {
+  IPA_REQUIRE(ctx, ky && kx && nky > 0 && nkx > 0 && (nky & 1) && (nkx & 1),
+              "ky / kx must be given with odd lengths");
+  IPA_REQUIRE(ctx, dst_dtype == IPA_F32, "remap + separable filter writes float32");
+  const int base = interp & 0xff;
+  // bicubic: built and correct, but 16 taps per sample on the K-1 extra halo rows of every
+  // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
+  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9) &&
+                          src_dtype == IPA_F32 && base == IPA_INTER_LINEAR;
+  if (!one_kernel) {
+    IPA_REQUIRE(ctx, dh > 0 && dw > 0 && n_frames >= 1, "empty image");
+    int rc = ipa_ws_reserve(ctx, (size_t)n_frames * dh * dw * 4);
+    if (rc) return rc;
+    rc = two(ctx->ws);
+    if (rc) return rc;
+    return ipa_sepconv2d_dev(ctx, ctx->ws, IPA_F32, dh, dw, dw, ky, nky, kx, nkx, d_dst, dst_pitch,
+                             n_frames, (long)dh * dw, dst_frame_stride, cby, cbx, 0.0);
+  }
+  int rc = fused_fill(ctx, f, d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw,
+                      dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp, border_mode,
+                      border_value, cbx, cby);
+  if (rc) return rc;
+  FusedSep q{ky, kx, nky, 0.0f};
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (nky <= 5) ipa_fused_sep_launch_a(ctx, f, q);
+  else ipa_fused_sep_launch_b(ctx, f, q);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
 extern "C" {
+
+int ipa_remap_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                            long src_pitch, const float* d_mapx, const float* d_mapy,
+                            long map_pitch, const double* ky, int nky, const double* kx, int nkx,
+                            void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                            long src_frame_stride, long dst_frame_stride, int interp,
+                            int border_mode, double border_value, int conv_border_y,
+                            int conv_border_x) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  FusedCall f;
+  f.coord_kind = 0;
+  f.map = MapCoord{d_mapx, d_mapy, map_pitch};
+  auto two = [&](void* tmp) {
+    return ipa_remap_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, tmp,
+                         IPA_F32, dh, dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
+                         border_mode, border_value);
+  };
+  return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
+                          dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                          dst_frame_stride, interp, border_mode, border_value, conv_border_y,
+                          conv_border_x);
+}
+
+int ipa_undistort_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                                long src_pitch, const double* K, const double* dist5,
+                                const double* newK, const double* ky, int nky, const double* kx,
+                                int nkx, void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch,
+                                int n_frames, long src_frame_stride, long dst_frame_stride,
+                                int interp, int border_mode, double border_value, int conv_border_y,
+                                int conv_border_x) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  FusedCall f;
+  f.coord_kind = 1;
+  UndistortCoord& c = f.und;
+  IPA_REQUIRE(ctx, inv3f(newK, c.ir) == 0, "newK is singular");
+  c.fx = K[0]; c.fy = K[4]; c.cx = K[2]; c.cy = K[5];
+  c.k1 = dist5[0]; c.k2 = dist5[1]; c.p1 = dist5[2]; c.p2 = dist5[3]; c.k3 = dist5[4];
+  c.affine = (c.ir[6] == 0.0 && c.ir[7] == 0.0 && c.ir[8] == 1.0) ? 1 : 0;
+  auto two = [&](void* tmp) {
+    return ipa_undistort_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, tmp, IPA_F32,
+                             dh, dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
+                             border_mode, border_value);
+  };
+  return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
+                          dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                          dst_frame_stride, interp, border_mode, border_value, conv_border_y,
+                          conv_border_x);
+}
+
+int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
+                                       int sw, long src_pitch, const double* M, const double* ky,
+                                       int nky, const double* kx, int nkx, void* d_dst,
+                                       int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                                       long src_frame_stride, long dst_frame_stride, int interp,
+                                       int border_mode, double border_value, int conv_border_y,
+                                       int conv_border_x) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, M, "null matrix");
+  FusedCall f;
+  f.coord_kind = 2;
+  for (int i = 0; i < 9; i++) f.hom.m[i] = M[i];
+  auto two = [&](void* tmp) {
+    return ipa_warp_perspective_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, tmp, IPA_F32, dh,
+                                    dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
+                                    border_mode, border_value);
+  };
+  return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
+                          dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                          dst_frame_stride, interp, border_mode, border_value, conv_border_y,
+                          conv_border_x);
+}
 
 int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
                          long src_pitch, const float* d_mapx, const float* d_mapy, long map_pitch,

@@ -1,0 +1,48 @@
+// fused_sep_impl.hpp — remap -> separable K+K filter in ONE kernel (BASELINE config C3:
+// PerspectiveCorrection remap + separable 9-tap Gaussian; the reference obtains such chains as
+// cv2.warpPerspective / cv2.remap followed by scipy.ndimage.gaussian_filter).
+//
+// wave_sep_kernel with a sampling row source: the remapped image never exists in HBM
+// (8 B/px analytic, 16 B/px map-based instead of 16 / 24 for two launches).  Built for
+// float32 -> float32, K = 3, 5, 7, 9 taps on both axes; fused.hip routes bilinear here and
+// every other combination (bicubic included: measured slower fused) through two launches.
+#pragma once
+
+#include "fused_impl.hpp"
+#include "wave_sep.hpp"
+
+namespace ipa {
+
+struct FusedSep {
+  const double* ky;
+  const double* kx;
+  int n;        // taps per axis
+  float xcval;  // constant x border of the intermediate (scipy pads the intermediate)
+};
+
+template <typename ST, int INTERP, typename Coord, int K>
+static void fused_sep_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const FusedSep& q) {
+  using Src = SampleRowSrc<ST, INTERP, Coord>;
+  Src s;
+  s.coord = c;
+  s.src = f.src; s.src_frame_bytes = f.src_frame_bytes; s.src_bytes = f.src_bytes;
+  s.sh = f.sh; s.sw = f.sw; s.spitch = f.spitch;
+  s.border = f.border; s.q5 = f.q5; s.cubic_a = f.cubic_a; s.lanczos = nullptr;
+  s.cval = (float)f.cval; s.ccval = (float)f.conv_cval; s.map_vec = f.map_vec;
+  launch_sep<Src, K>(ctx, f.p, s, q.ky, q.kx, f.n_frames, q.xcval);
+}
+
+template <typename Coord, int K>
+static void fused_sep_interp(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const FusedSep& q) {
+  fused_sep_one<float, kLinear, Coord, K>(ctx, f, c, q);
+}
+
+template <int K> static void fused_sep_k(ipa_ctx* ctx, const FusedCall& f, const FusedSep& q) {
+  switch (f.coord_kind) {
+    case 0: fused_sep_interp<MapCoord, K>(ctx, f, f.map, q); break;
+    case 1: fused_sep_interp<UndistortCoord, K>(ctx, f, f.und, q); break;
+    default: fused_sep_interp<HomographyCoord, K>(ctx, f, f.hom, q); break;
+  }
+}
+
+}  // namespace ipa

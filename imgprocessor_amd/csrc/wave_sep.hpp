@@ -1,0 +1,195 @@
+// wave_sep.hpp - separable K+K correlation (scipy.ndimage.gaussian_filter order: axis 0
+// then axis 1, intermediate rounded to float32) on the wave-marching skeleton of
+// wave_stencil.hpp, float32, K = 3, 5, 7, 9 taps on both axes.
+//
+// A wave64 owns a 256-px-wide strip.  Each arriving input row is scattered into the K
+// running y-sums it belongs to (K x 4 registers per lane, shifted inside the fma
+// chain); the y-row that completes is already the float32 intermediate scipy
+// stores between its two passes; its x pass needs K/2 neighbours per side,
+// taken from the adjacent lanes with DPP wave shifts, and the result is stored
+// as one float4.  2K fma per pixel instead of K*K, one pass over HBM, no barriers.
+//
+// Row sources: plain image rows (LoadRowSrc: rows stay in registers) or rows of a remapped
+// image sampled on the fly (SampleRowSrc: blended samples pass through the wave-private LDS
+// row of wave_stencil.hpp, which also undoes the lane-interleaved sampling order) - the
+// remap -> Gaussian chain of PerspectiveCorrection.correct / LensDistortion.correct followed
+// by scipy.ndimage.gaussian_filter in one kernel.
+// Reference call sites: filters/standardDeviation.py:23, filters/fastFilter.py:42,
+// camera/flatField/flatField.py:47.
+#pragma once
+
+#include "common.hpp"
+#include "wave_stencil.hpp"
+
+namespace ipa {
+
+template <int K> struct SepTaps {
+  float ky[K], kx[K];
+};
+
+// chunk rows.  Sampling sources with analytic (f64) coordinates take one row at a time here:
+// two rows of coordinates next to K x 4 running sums cost 190-200 VGPRs (occupancy 2) and
+// measured 13 % slower on the 4K perspective + 9-tap chain.
+template <typename Src, int K> struct sep_depth {
+  static constexpr int value = Src::kMap ? Src::template depth<K>::value : 1;
+};
+template <int K> struct sep_depth<LoadRowSrc, K> { static constexpr int value = 4; };
+
+template <bool FAST, typename Src, int K, int QM = -1>
+__device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& src,
+                                               const SepTaps<K>& w, float* xp, const Cols& c,
+                                               int y0, int nrows, bool writer, float* dst,
+                                               float xcval) {
+  constexpr int H = K / 2;
+  constexpr int D = sep_depth<Src, K>::value;
+  constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;  // rows stay in registers
+  const int T = nrows + K - 1;
+  float acc[K][4];  // acc[i] = y-sum of intermediate row (t - i)
+#pragma unroll 1
+  for (int tb = 0; tb < T; tb += D) {
+    int vv[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      if constexpr (FAST) vv[d] = y0 - H + tb + d;
+      else vv[d] = resolve_idx(y0 - H + tb + d, p.dh, p.cby);
+    }
+    typename Src::template Chunk<D> ch;
+    src.template load_chunk<FAST, D, QM>(c, vv, ch);
+    if constexpr (!kRegs) {
+      src.template stage_rows<FAST, D>(c, vv, ch, xp);
+      __builtin_amdgcn_wave_barrier();  // wave-private LDS rows: in-order ds_write / ds_read
+    }
+
+    static_for<0, D>([&](auto Dd) {
+      constexpr int d = decltype(Dd)::value;
+      const int t = tb + d;
+      float cur[4];
+      if constexpr (kRegs) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = ch.v[d][k];
+      } else {
+        const float4 q = *reinterpret_cast<const float4*>(xp + d * kRowStride + kRowPad +
+                                                          4u * (threadIdx.x & 63u));
+        cur[0] = q.x; cur[1] = q.y; cur[2] = q.z; cur[3] = q.w;
+      }
+
+      // y pass: the arriving row feeds K intermediate rows
+      static_for<0, K>([&](auto Ii) {
+        constexpr int i = K - 1 - decltype(Ii)::value;
+#pragma unroll
+        for (int ox = 0; ox < 4; ox++) {
+          if constexpr (i == 0) acc[0][ox] = w.ky[0] * cur[ox];
+          else acc[i][ox] = fmaf(w.ky[i], cur[ox], acc[i - 1][ox]);
+        }
+      });
+
+      const int o = t - (K - 1);
+      if (o >= 0 && o < nrows) {  // wave-uniform: intermediate row o is complete
+        float mid[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) mid[k] = acc[K - 1][k];
+        if constexpr (!FAST) {
+          // constant x border: scipy pads the INTERMEDIATE with cval
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (c.uu[k] < 0) mid[k] = xcval;
+        }
+        float win[4 + 2 * H];
+#pragma unroll
+        for (int k = 0; k < 4; k++) win[H + k] = mid[k];
+#pragma unroll
+        for (int m = 0; m < H; m++) {
+          win[H - 1 - m] = from_lane_below(mid[3 - m]);
+          win[H + 4 + m] = from_lane_above(mid[m]);
+        }
+        float out[4];
+#pragma unroll
+        for (int ox = 0; ox < 4; ox++) {
+          float a = w.kx[0] * win[ox];
+#pragma unroll
+          for (int j = 1; j < K; j++) a = fmaf(w.kx[j], win[ox + j], a);
+          out[ox] = a;
+        }
+        if (writer) {
+          float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
+          const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
+          if constexpr (FAST) {
+            float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
+            *reinterpret_cast<float4*>(rows_ + 4u * (threadIdx.x & 63u)) =
+                float4{out[0], out[1], out[2], out[3]};
+          } else if (p.vec_out && n == 4) {
+            *reinterpret_cast<float4*>(row) = float4{out[0], out[1], out[2], out[3]};
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (k < n) row[k] = out[k];
+          }
+        }
+      }
+    });
+    if constexpr (!kRegs) __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <typename Src, int K>
+__global__ void __launch_bounds__(256)
+wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
+  constexpr int H = K / 2, D = sep_depth<Src, K>::value, OW = 256 - 8;
+  constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;
+  __shared__ __attribute__((aligned(16))) float xpose[kRegs ? 1 : 4 * kRowStride * D];
+  static_assert(H <= 4, "one halo lane per side");
+  const int lane = threadIdx.x & 63;
+  unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
+  if (p.frames_inner) {  // dispatch order of wave_stencil_kernel
+    frame = b % (unsigned)p.frames_inner;
+    b /= (unsigned)p.frames_inner;
+  }
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
+  const unsigned sid = b * 4 + wave;
+  float* xp = xpose + (kRegs ? 0 : wave * kRowStride * D);
+  if (sid >= p.strips) return;
+  const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
+  src.set_frame(frame);
+  const int xs = sxi * OW - 4;
+  Cols c;
+  c.xs = xs;
+  c.xo = xs + lane * 4;
+  const int y0 = syi * p.strip_h;
+  const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
+  const bool writer = lane >= 1 && lane < 63 && c.xo < p.dw;
+  float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
+  const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
+  const bool fast = src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw && y0 - H >= 0 &&
+                    y0 - H + rows_touched <= p.dh;
+  if (fast) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
+    if constexpr (!kRegs) {
+      if (src.q5) wave_sep_strip<true, Src, K, 1>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
+      else wave_sep_strip<true, Src, K, 0>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
+    } else {
+      wave_sep_strip<true, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+    wave_sep_strip<false, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
+  }
+}
+
+template <typename Src, int K>
+static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double* ky,
+                       const double* kx, int n_frames, float xcval) {
+  SepTaps<K> w;
+  for (int i = 0; i < K; i++) {
+    w.ky[i] = (float)ky[i];
+    w.kx[i] = (float)kx[i];
+  }
+  p.strips_x = (p.dw + 247) / 248;
+  p.strip_h = wave_strip_height(p.dh, p.dw, n_frames, K);
+  p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
+  dim3 grid = wave_grid(p, n_frames, 4, true), block(256);
+  hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
+}
+
+}  // namespace ipa

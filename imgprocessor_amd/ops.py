@@ -511,6 +511,73 @@ def warp_perspective_conv2d(src, M_dst2src, out_shape, kernel, interpolation='li
     return dst
 
 
+def _sep_taps(ky, kx):
+    ky = np.ascontiguousarray(ky, dtype=np.float64).ravel()
+    kx = np.ascontiguousarray(kx, dtype=np.float64).ravel()
+    dp = C.POINTER(C.c_double)
+    return ky, kx, ky.ctypes.data_as(dp), kx.ctypes.data_as(dp)
+
+
+def remap_sepconv2d(src, mapx, mapy, ky, kx, interpolation='linear', border_mode='constant',
+                    border_value=0.0, conv_mode='reflect', out=None, ctx=None):
+    """remap followed by a separable correlation (axis 0 with ky, then axis 1 with kx; the
+    scipy.ndimage.gaussian_filter order) — one kernel where built, device arrays only"""
+    ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
+    if not (_is_dev(src) and _is_dev(mapx) and _is_dev(mapy)):
+        raise TypeError('remap_sepconv2d works on DeviceArrays (use Context.to_device)')
+    ky, kx, pky, pkx = _sep_taps(ky, kx)
+    n, sh, sw = as_frames(src)
+    dh, dw = mapx.shape
+    dst = _dev_out(ctx, out, (dh, dw) if src.ndim == 2 else (n, dh, dw), np.float32)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_remap_sepconv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw, mapx.ptr, mapy.ptr, dw, pky, ky.size,
+        pkx, kx.size, dst.ptr, dtype_id(np.float32), dh, dw, dw, n, sh * sw, dh * dw,
+        interp_id(interpolation), border_id(border_mode), float(border_value), cb, cb),
+        'remap_sepconv2d')
+    return dst
+
+
+def undistort_sepconv2d(src, K, dist5, newK, ky, kx, interpolation='linear',
+                        border_mode='constant', border_value=0.0, conv_mode='reflect',
+                        out_shape=None, out=None, ctx=None):
+    ctx = _ctx_of(src, ctx=ctx)
+    if not _is_dev(src):
+        raise TypeError('undistort_sepconv2d works on DeviceArrays (use Context.to_device)')
+    if newK is None:
+        newK = K
+    ky, kx, pky, pkx = _sep_taps(ky, kx)
+    n, sh, sw = as_frames(src)
+    dh, dw = out_shape or (sh, sw)
+    dst = _dev_out(ctx, out, (dh, dw) if src.ndim == 2 else (n, dh, dw), np.float32)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_undistort_sepconv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw, L.dbl(np.ravel(K), 9),
+        L.dbl(np.ravel(dist5)[:5], 5), L.dbl(np.ravel(newK), 9), pky, ky.size, pkx, kx.size,
+        dst.ptr, dtype_id(np.float32), dh, dw, dw, n, sh * sw, dh * dw, interp_id(interpolation),
+        border_id(border_mode), float(border_value), cb, cb), 'undistort_sepconv2d')
+    return dst
+
+
+def warp_perspective_sepconv2d(src, M_dst2src, out_shape, ky, kx, interpolation='linear',
+                               border_mode='constant', border_value=0.0, conv_mode='reflect',
+                               out=None, ctx=None):
+    ctx = _ctx_of(src, ctx=ctx)
+    if not _is_dev(src):
+        raise TypeError('warp_perspective_sepconv2d works on DeviceArrays (use Context.to_device)')
+    ky, kx, pky, pkx = _sep_taps(ky, kx)
+    n, sh, sw = as_frames(src)
+    dh, dw = int(out_shape[0]), int(out_shape[1])
+    dst = _dev_out(ctx, out, (dh, dw) if src.ndim == 2 else (n, dh, dw), np.float32)
+    cb = border_id(conv_mode)
+    ctx._check(ctx._lib.ipa_warp_perspective_sepconv2d_dev(
+        ctx.handle, src.ptr, dtype_id(src.dtype), sh, sw, sw,
+        L.dbl(np.ravel(np.asarray(M_dst2src, dtype=np.float64)), 9), pky, ky.size, pkx, kx.size,
+        dst.ptr, dtype_id(np.float32), dh, dw, dw, n, sh * sw, dh * dw, interp_id(interpolation),
+        border_id(border_mode), float(border_value), cb, cb), 'warp_perspective_sepconv2d')
+    return dst
+
+
 # ------------------------------------------------------------------- IDW --
 def idw_fill(grid, mask, ksize, weights, ctx=None):
     """in-place IDW hole filling (interpolate2dStructuredIDW._calc)"""

@@ -263,6 +263,36 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
                                     long dst_frame_stride, int interp, int border_mode,
                                     double border_value, int conv_border_x, int conv_border_y);
 
+/* The same chain with a SEPARABLE filter (BASELINE config C3: PerspectiveCorrection remap +
+ * separable 9-tap Gaussian; in the reference cv2.remap / cv2.warpPerspective followed by
+ * scipy.ndimage.gaussian_filter, e.g. PerspectiveCorrection.py:401-405 then
+ * filters/fastFilter.py:42): axis 0 with ky[nky], the float32 intermediate, then axis 1 with
+ * kx[nkx], exactly as ipa_sepconv2d_dev on the materialised remap result.  One kernel for
+ * float32 sources, INTER_LINEAR and nky == nkx in {3,5,7,9}; any other combination runs
+ * as remap + ipa_sepconv2d_dev through the context workspace (same results).  dst is
+ * IPA_F32; a constant filter border uses 0. */
+int ipa_remap_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                            long src_pitch, const float* d_mapx, const float* d_mapy,
+                            long map_pitch, const double* ky, int nky, const double* kx, int nkx,
+                            void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                            long src_frame_stride, long dst_frame_stride, int interp,
+                            int border_mode, double border_value, int conv_border_y,
+                            int conv_border_x);
+int ipa_undistort_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
+                                long src_pitch, const double* K, const double* dist5,
+                                const double* newK, const double* ky, int nky, const double* kx,
+                                int nkx, void* d_dst, int dst_dtype, int dh, int dw, long dst_pitch,
+                                int n_frames, long src_frame_stride, long dst_frame_stride,
+                                int interp, int border_mode, double border_value, int conv_border_y,
+                                int conv_border_x);
+int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
+                                       int sw, long src_pitch, const double* M, const double* ky,
+                                       int nky, const double* kx, int nkx, void* d_dst,
+                                       int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
+                                       long src_frame_stride, long dst_frame_stride, int interp,
+                                       int border_mode, double border_value, int conv_border_y,
+                                       int conv_border_x);
+
 /* ------------------------------------------------------------ interpolate */
 /* replaces interpolate/interpolate2dStructuredIDW.py:26-65 (_calc): every
  * pixel with mask!=0 becomes the weighted mean of the unmasked pixels in the

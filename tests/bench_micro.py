@@ -96,3 +96,33 @@ if __name__ == '__main__':
         t = wall(lambda: ops.remap_conv2d(ctx.to_device(batch), dmx, dmy, k5).get(), n=3)
         print('host: fused, 16-frame batch, 1 round trip       %7.2f ms/frame  %6.2f Gpx/s'
               % (t / B, B * h * w / t / 1e6))
+    if what == 'configs':
+        # kernel-only timings of the BASELINE configurations C3..C5 at batch 16 (C5: 4 x 8K)
+        dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
+        k7 = np.random.default_rng(123).random((7, 7))
+        k7 /= k7.sum()
+        u16 = ctx.to_device((rng.random((B, h, w)) * 4095).astype(np.uint16))
+        t = timeit(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst))
+        print('C4 u16->f32 undistort + 7x7 fused   %8.1f us  %7.1f Gpx/s' % (t, px / t / 1e3))
+        t = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst))
+        print('   f32      undistort + 7x7 fused   %8.1f us  %7.1f Gpx/s' % (t, px / t / 1e3))
+        from imgprocessor_amd.utils import getPerspectiveTransform
+        quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+        rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+        Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))
+        g9 = ops.gaussian_kernel1d(1.0)
+        tmp = ctx.empty((B, h, w), np.float32)
+        for interp in ('linear', 'cubic'):
+            t1 = timeit(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), interp, out=tmp))
+            t2 = timeit(ctx, lambda: ops.sepconv2d(tmp, g9, g9, out=dst))
+            print('C3 warp %-6s %8.1f us + sep 9+9 %8.1f us  %7.1f Gpx/s'
+                  % (interp, t1, t2, px / (t1 + t2) / 1e3))
+            t = timeit(ctx, lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, interp,
+                                                                   out=dst))
+            print('C3 warp %-6s -> sep 9+9 in one kernel %8.1f us  %7.1f Gpx/s'
+                  % (interp, t, px / t / 1e3))
+        k11 = np.random.default_rng(321).random((11, 11))
+        k11 /= k11.sum()
+        t = timeit(ctx, lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k11, 'cubic', out=dst))
+        print('C5-like 4K bicubic warp + 11x11 (2 launches) %8.1f us  %7.1f Gpx/s'
+              % (t, px / t / 1e3))

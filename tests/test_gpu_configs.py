@@ -169,6 +169,10 @@ def test_c3_4k_perspective_sep9(ia, orc):
         close32(warped.get(), want_w, 'C3 warp ' + interp, scale=1.0)
         out = ia.ops.sepconv2d(warped, g9, g9).get()
         close32(out, orc.sepconv2d(want_w, g9, g9), 'C3 sep9 ' + interp, scale=1.0)
+        # the chain as ONE kernel (remap -> separable 9+9)
+        fused = ia.ops.warp_perspective_sepconv2d(d_img, M, (h, w), g9, g9, interp).get()
+        close32(fused, orc.sepconv2d(want_w, g9, g9), 'C3 fused sep9 ' + interp, scale=1.0)
+        assert np.abs(fused - out).max() < 2e-6
         # the same filter as a dense 9x9 (fused chain, K=9 -> two launches inside)
         dense = ia.ops.warp_perspective_conv2d(d_img, M, (h, w), np.outer(g9, g9), interp).get()
         assert np.abs(dense - out).max() < 5e-6

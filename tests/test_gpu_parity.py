@@ -459,6 +459,53 @@ def test_fused_chain(ia, oracle):
     close32(ia.ops.remap_conv2d(d16, dmx, dmy, k7).get(), want, 'fused u16')
 
 
+def test_fused_separable_chain(ia, oracle):
+    """remap -> separable filter in one kernel == oracle remap then sepconv2d (and == two launches)"""
+    ctx = ia.default_context(0)
+    g = load_golden('remap_scipy.npz')
+    img = g['img']
+    d_img = ctx.to_device(img)
+    mx, my = g['mapx_radial'], g['mapy_radial']
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    K, d, nK = g['K_strong'], g['dist_strong'], g['newK_strong']
+    M = load_golden('warp_skimage.npz')['M_rot7']
+    rng = np.random.default_rng(5)
+    for n in (3, 5, 7, 9, 11, 13):   # 11, 13: two launches inside
+        ky, kx = rng.random(n), rng.random(n)
+        ky /= ky.sum()
+        kx /= kx.sum()
+        for interp, iid in (('linear', oracle.LINEAR), ('cubic', oracle.CUBIC_KEYS)):
+            for cmode in ('reflect', 'wrap', 'constant', 'mirror'):
+                want = oracle.sepconv2d(oracle.remap(img, mx, my, iid, oracle.CONSTANT, 0.1),
+                                        ky, kx, cmode)
+                got = ia.ops.remap_sepconv2d(d_img, dmx, dmy, ky, kx, interp, 'constant', 0.1,
+                                             cmode).get()
+                close32(got, want, 'fused sep map n%d %s %s' % (n, interp, cmode))
+        want = oracle.sepconv2d(oracle.undistort(img, K, d, nK), ky, kx)
+        close32(ia.ops.undistort_sepconv2d(d_img, K, d, nK, ky, kx).get(), want,
+                'fused sep undistort n%d' % n)
+        want = oracle.sepconv2d(oracle.warp_perspective(img, M, (80, 100), oracle.CUBIC_KEYS), ky, kx)
+        close32(ia.ops.warp_perspective_sepconv2d(d_img, M, (80, 100), ky, kx, 'cubic').get(), want,
+                'fused sep warp n%d' % n)
+    g9 = oracle.gaussian_kernel1d(1.0)
+    two = ia.ops.sepconv2d(ia.ops.remap(d_img, dmx, dmy), g9, g9).get()
+    assert np.array_equal(ia.ops.remap_sepconv2d(d_img, dmx, dmy, g9, g9).get(), two)
+    # cv2-style quantised coordinates, a batch, and a frame wide enough for interior strips
+    big = synth((200, 900), 3)
+    yy, xx = np.mgrid[0:200, 0:900].astype(np.float32)
+    bmx = (xx + 3.3 * np.sin(yy / 40)).astype(np.float32)
+    bmy = (yy + 2.1 * np.cos(xx / 90)).astype(np.float32)
+    batch = np.stack([big, big[::-1].copy(), synth((200, 900), 4)])
+    for interp, iid in (('linear', oracle.LINEAR), ('linear_cv_q5', oracle.LINEAR | oracle.Q5)):
+        got = ia.ops.remap_sepconv2d(ctx.to_device(batch), ctx.to_device(bmx), ctx.to_device(bmy),
+                                     g9, g9, interp).get()
+        for i in range(3):
+            want = oracle.sepconv2d(oracle.remap(batch[i], bmx, bmy, iid), g9, g9)
+            close32(got[i], want, 'fused sep batch %d %s' % (i, interp))
+    with pytest.raises(ValueError):
+        ia.ops.remap_sepconv2d(d_img, dmx, dmy, np.ones(4) / 4, g9)
+
+
 # ------------------------------------------------------------------ IDW ----
 def test_idw_golden(ia):
     from imgprocessor_amd.interpolate import (interpolate2dStructuredIDW,
