@@ -7,6 +7,7 @@ numpy-like shape/dtype, so frames can stay in HBM between calls
 """
 import ctypes as C
 import threading
+import weakref
 
 import numpy as np
 
@@ -58,6 +59,20 @@ class Context(object):
         d = DeviceArray(self, arr.shape, arr.dtype)
         d.set(arr)
         return d
+
+    def pinned_empty(self, shape, dtype):
+        """page-locked host ndarray (ipa_host_alloc): copies to / from it run at PCIe rate and
+        do not pass through the driver's staging buffer.  Freed when the array is collected."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = C.c_void_p()
+        self._check(self._lib.ipa_host_alloc(self.handle, max(nbytes, 1), C.byref(p)), 'host_alloc')
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape, dtype=np.int64)))
+        arr = arr.reshape(shape)
+        lib, handle = self._lib, self.handle
+        weakref.finalize(buf, lambda: lib.ipa_host_free(handle, p))
+        return arr
 
     # -- events (HIP events on the stream the kernels run on) --------------
     def event(self):

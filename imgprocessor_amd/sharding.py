@@ -63,3 +63,62 @@ class ShardedRunner(object):
             if e is not None:
                 raise e
         return results
+
+
+class FramePipeline(object):
+    """Host-to-host streaming of independent frames through ONE device with copies and
+    kernels overlapped.
+
+    ``depth`` workers, each with its own context (= its own HIP stream) on the same device
+    and its own device buffers, take the frames round-robin: while one worker's kernel runs,
+    the others' H2D / D2H copies use the copy engines.  ``fn(ctx, d_in, d_out)`` is the
+    device-side work on one frame, written into ``d_out`` (e.g. ``lambda ctx, d, o:
+    ops.remap_conv2d(d, mx[ctx], my[ctx], k, out=o)``); per-context read-only state (maps) is
+    the caller's to build once per context (``pipe.contexts``).  Device buffers are allocated
+    once per worker.
+
+    For PCIe-rate transfers the host arrays should be page-locked: allocate them with
+    ``pipe.pinned_empty`` (or ``Context.pinned_empty``); pageable arrays work but pass through
+    the driver's staging copies.
+    """
+
+    def __init__(self, device=0, depth=3):
+        if depth < 1:
+            raise ValueError('depth must be >= 1')
+        self.contexts = [Context(device) for _ in range(depth)]
+
+    def pinned_empty(self, shape, dtype):
+        return self.contexts[0].pinned_empty(shape, dtype)
+
+    def run(self, frames, out, fn):
+        """for every frame i: upload frames[i], fn(ctx, d_in, d_out), download into out[i];
+        `frames` and `out` are indexable by frame (ndarrays (N, ...) or lists of ndarrays)"""
+        n = len(frames)
+        if len(out) != n:
+            raise ValueError('frames and out must hold the same number of frames')
+        errors = [None] * len(self.contexts)
+
+        def work(t):
+            ctx = self.contexts[t]
+            d_in = d_out = None
+            try:
+                for i in range(t, n, len(self.contexts)):
+                    f, o = frames[i], out[i]
+                    if d_in is None or d_in.shape != f.shape or d_in.dtype != f.dtype:
+                        d_in = ctx.empty(f.shape, f.dtype)
+                    if d_out is None or d_out.shape != o.shape or d_out.dtype != o.dtype:
+                        d_out = ctx.empty(o.shape, o.dtype)
+                    d_in.set(f)
+                    fn(ctx, d_in, d_out)
+                    d_out.get(o)
+            except Exception as e:  # re-raised on the caller's thread
+                errors[t] = e
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(len(self.contexts))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for e in errors:
+            if e is not None:
+                raise e
+        return out

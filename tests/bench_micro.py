@@ -126,3 +126,29 @@ if __name__ == '__main__':
         t = timeit(ctx, lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k11, 'cubic', out=dst))
         print('C5-like 4K bicubic warp + 11x11 (2 launches) %8.1f us  %7.1f Gpx/s'
               % (t, px / t / 1e3))
+    if what == 'pipeline':
+        # end to end, host to host, with page-locked arrays and overlapped workers (C4 style)
+        import time
+        from imgprocessor_amd.sharding import FramePipeline
+        k7 = np.random.default_rng(123).random((7, 7))
+        k7 /= k7.sum()
+        N = 48
+        for depth in (1, 2, 3, 4):
+            pipe = FramePipeline(0, depth)
+            maps = {id(c): ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=c, device=True)
+                    for c in pipe.contexts}
+            for dt in (np.uint16, np.float32):
+                fin = pipe.pinned_empty((N, h, w), dt)
+                fout = pipe.pinned_empty((N, h, w), np.float32)
+                fin[...] = (rng.random((1, h, w)) * 4095).astype(dt)
+
+                def fn(c, d, o):
+                    mx, my = maps[id(c)]
+                    ops.remap_conv2d(d, mx, my, k7, out=o)
+                pipe.run(fin[:depth], fout[:depth], fn)  # warm
+                t0 = time.perf_counter()
+                pipe.run(fin, fout, fn)
+                t = (time.perf_counter() - t0) / N * 1e3
+                print('pipeline depth %d  %-7s -> f32 undistort + 7x7  %6.2f ms/frame  %6.2f Gpx/s'
+                      % (depth, np.dtype(dt).name, t, h * w / t / 1e6))
+                del fin, fout

@@ -282,3 +282,33 @@ def test_transform_wrappers(ia, orc):
     assert np.abs(pol - pol.mean(axis=1, keepdims=True))[5:120].max() < 0.12
     back = polarToLinear(pol, shape=rings.shape)
     assert back.shape == rings.shape
+
+
+def test_frame_pipeline_end_to_end(ia, orc):
+    """host-to-host streaming with pinned arrays and overlapped workers == frame-by-frame calls"""
+    from imgprocessor_amd.sharding import FramePipeline
+    h, w, n = 270, 480, 7
+    K, d = camera(h, w)
+    k5 = np.outer(gauss(5), gauss(5))
+    pipe = FramePipeline(0, depth=3)
+    maps = {id(c): ia.ops.build_undistort_map(K, d, K, h, w, ctx=c, device=True)
+            for c in pipe.contexts}
+    fin = pipe.pinned_empty((n, h, w), np.uint16)
+    fout = pipe.pinned_empty((n, h, w), np.float32)
+    for i in range(n):
+        fin[i] = np.round(synth((h, w), i, np.float64) * 4095).astype(np.uint16)
+
+    def fn(c, d_in, d_out):
+        mx, my = maps[id(c)]
+        ia.ops.remap_conv2d(d_in, mx, my, k5, out=d_out)
+    assert pipe.run(fin, fout, fn) is fout
+    mx, my = orc.build_undistort_map(K, d, K, h, w)
+    for i in (0, 3, n - 1):
+        want = orc.conv2d(orc.remap(np.array(fin[i]), mx, my, out_dtype=np.float32), k5)
+        close32(fout[i], want, 'pipeline frame %d' % i)
+    # pageable lists of frames work as well
+    outs = [np.empty((h, w), np.float32) for _ in range(n)]
+    pipe.run([np.array(f) for f in fin], outs, fn)
+    assert all(np.array_equal(o, f) for o, f in zip(outs, fout))
+    with pytest.raises(ValueError):
+        pipe.run(fin, fout[:2], fn)
