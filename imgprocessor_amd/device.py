@@ -6,6 +6,7 @@ numpy-like shape/dtype, so frames can stay in HBM between calls
 (`lens.correct(d_img)` -> `filter(d_img, k)` never touches the host).
 """
 import ctypes as C
+import os
 import threading
 import weakref
 
@@ -34,6 +35,13 @@ class Context(object):
         L.check(self._lib.ipa_ctx_create(int(device_id), C.byref(h)), None, 'ipa_ctx_create')
         self.handle = h
         self.device_id = int(device_id)
+        # freed device blocks are kept for reuse (exact size match): hipMalloc / hipFree cost
+        # 100s of microseconds and synchronise the device, an output array per call would
+        # otherwise dominate every small op.  Reuse is stream-ordered like the kernels.
+        self._pool = {}
+        self._pool_bytes = 0
+        self._pool_limit = int(os.environ.get('IMGPROC_HIP_POOL_MB', '8192')) << 20
+        self._pool_lock = threading.Lock()
 
     # -- info -------------------------------------------------------------
     def device_info(self):
@@ -51,6 +59,39 @@ class Context(object):
         self._check(self._lib.ipa_ctx_synchronize(self.handle), 'synchronize')
 
     # -- memory -----------------------------------------------------------
+    def _alloc(self, nbytes):
+        with self._pool_lock:
+            blocks = self._pool.get(nbytes)
+            if blocks:
+                self._pool_bytes -= nbytes
+                return blocks.pop()
+        p = C.c_void_p()
+        try:
+            self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
+        except MemoryError:
+            self.trim()  # give the pooled blocks back and retry once
+            self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
+        return p
+
+    def _release(self, ptr, nbytes):
+        if self.handle is None:
+            return
+        with self._pool_lock:
+            if self._pool_bytes + nbytes <= self._pool_limit:
+                self._pool.setdefault(nbytes, []).append(ptr)
+                self._pool_bytes += nbytes
+                return
+        self._lib.ipa_free(self.handle, ptr)
+
+    def trim(self):
+        """return every pooled device block to the driver"""
+        with self._pool_lock:
+            blocks = [p for lst in self._pool.values() for p in lst]
+            self._pool.clear()
+            self._pool_bytes = 0
+        for p in blocks:
+            self._lib.ipa_free(self.handle, p)
+
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
 
@@ -80,6 +121,7 @@ class Context(object):
 
     def close(self):
         if self.handle is not None:
+            self.trim()
             self._lib.ipa_ctx_destroy(self.handle)
             self.handle = None
 
@@ -125,9 +167,7 @@ class DeviceArray(object):
         self.dtype = np.dtype(dtype)
         dtype_id(self.dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        p = C.c_void_p()
-        ctx._check(ctx._lib.ipa_malloc(ctx.handle, self.nbytes, C.byref(p)), 'ipa_malloc')
-        self.ptr = p
+        self.ptr = ctx._alloc(self.nbytes)
         self._owner = True
 
     @property
@@ -178,7 +218,7 @@ class DeviceArray(object):
 
     def free(self):
         if getattr(self, '_owner', False) and self.ptr is not None and self.ctx.handle is not None:
-            self.ctx._lib.ipa_free(self.ctx.handle, self.ptr)
+            self.ctx._release(self.ptr, self.nbytes)
         self.ptr = None
 
     def __del__(self):

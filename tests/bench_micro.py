@@ -152,3 +152,30 @@ if __name__ == '__main__':
                 print('pipeline depth %d  %-7s -> f32 undistort + 7x7  %6.2f ms/frame  %6.2f Gpx/s'
                       % (depth, np.dtype(dt).name, t, h * w / t / 1e6))
                 del fin, fout
+    if what == 'stencils':
+        # the secondary stencils on ONE 4K frame (float32 and float64)
+        from imgprocessor_amd.filters import (standardDeviation2d, varYSizeGaussianFilter,
+                                              maskedFilter, nan_maximum_filter, medianThreshold)
+        from imgprocessor_amd.interpolate import interpolate2dStructuredIDW
+        for dt in (np.float32, np.float64):
+            img = ctx.to_device((0.2 + rng.random((h, w))).astype(dt))
+            blurred = ops.gaussian_filter(img, (5, 5))
+            m = ctx.to_device((rng.random((h, w)) < 0.05).astype(np.uint8))
+            one = h * w
+            t = timeit(ctx, lambda: ops.local_std(img, blurred, (5, 5)))
+            print('%-8s local_std k5            %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
+            t = timeit(ctx, lambda: ops.gaussian_filter(img, (5, 5)))
+            print('%-8s gaussian sigma 5 (41+41) %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
+            t = timeit(ctx, lambda: ops.median_threshold(img, 0.1))
+            print('%-8s medianThreshold 3x3      %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
+            t = timeit(ctx, lambda: ops.nan_max(img, 7))
+            print('%-8s nan_max k7               %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
+            work = ctx.empty((h, w), dt)
+
+            def fill():
+                work.copy_from(img)
+                ops.masked_mean(work, m, 30, True)
+            t = timeit(ctx, fill)
+            print('%-8s maskedFilter mean k30 5%%  %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
+            t = timeit(ctx, lambda: varYSizeGaussianFilter(img, (0, 4), 1), n=3, warm=1)
+            print('%-8s varYSizeGaussian (0,4),1 %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
