@@ -1,9 +1,11 @@
 """``varYSizeGaussianFilter`` — reference: imgProcessor/filters/varYSizeGaussianFilter.py:9-68.
 
 A Gaussian whose sigma along y changes from row to row.  The per-row k0 x k1
-coefficient tables are built on the host the way the reference builds them
-(``gaussian_filter`` of a centred delta, :40-46 — a few thousand tiny
-filters); the O(H·W·k0·k1) NaN-skipping correlation (:53-68) runs as a HIP
+coefficient tables are what the reference builds with one ``gaussian_filter``
+call per row on a centred delta (:40-46); the delta is separable, so here they
+are the outer products of vectorised 1-D responses (same weights, truncation
+and reflection; equal to the reference's tables to rounding).  The
+O(H·W·k0·k1) NaN-skipping correlation (:53-68) runs as a HIP
 kernel with the borders resolved on the fly (defaults modex='wrap',
 modey='reflect', like the reference's padding).
 
@@ -15,28 +17,38 @@ import numpy as np
 from .. import ops
 
 
-def _correlate1d_reflect(a, w, axis):
-    r = len(w) // 2
-    pad = [(0, 0)] * a.ndim
-    pad[axis] = (r, r)
-    p = np.pad(a, pad, mode='symmetric')
-    out = np.zeros_like(a, dtype=np.float64)
-    n = a.shape[axis]
-    for i, wi in enumerate(w):
-        sl = [slice(None)] * a.ndim
-        sl[axis] = slice(i, i + n)
-        out += wi * p[tuple(sl)]
-    return out
+def _fold_symmetric(k, n):
+    """index of np.pad(mode='symmetric') / scipy 'reflect' for any integer position"""
+    k = np.mod(k, 2 * n)
+    return np.where(k < n, k, 2 * n - 1 - k)
 
 
-def _gaussian_of_delta(shape, sigmas, truncate=4.0):
-    """scipy.ndimage.gaussian_filter(delta, sigmas) for a tiny centred delta image"""
-    out = np.zeros(shape)
-    out[shape[0] // 2, shape[1] // 2] = 1
-    for axis, s in enumerate(sigmas):
-        if s > 1e-15:
-            out = _correlate1d_reflect(out, ops.gaussian_kernel1d(s, truncate=truncate), axis)
-    return out
+def _delta_response(n, sigmas, truncate=4.0):
+    """scipy.ndimage.gaussian_filter1d(delta_n, sigma, mode='reflect') for EVERY sigma at once:
+    (len(sigmas), n).  delta_n is 1 at n // 2; sigma == 0 leaves it untouched.  The weights are
+    scipy's (exp(-x^2 / 2 sigma^2) over |x| <= int(truncate * sigma + 0.5), normalised); the
+    reflected delta can be hit by several taps, which are summed."""
+    sigmas = np.asarray(sigmas, dtype=np.float64)
+    radius = (truncate * sigmas + 0.5).astype(np.int64)
+    rmax = int(radius.max()) if sigmas.size else 0
+    m = np.arange(-rmax, rmax + 1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        w = np.exp(-0.5 * (m[None, :] / sigmas[:, None]) ** 2)
+    w[np.abs(m)[None, :] > radius[:, None]] = 0.0
+    w /= w.sum(axis=1, keepdims=True)
+    ident = ~(sigmas > 1e-15)
+    w[ident] = 0.0
+    w[ident, rmax] = 1.0
+    hits = (_fold_symmetric(np.arange(n)[:, None] + m[None, :], n) == n // 2)  # (n, taps)
+    return w @ hits.T.astype(np.float64)
+
+
+def _row_kernels(stdys, stdx, ky, kx):
+    """kernels[i] = gaussian_filter(delta_(ky,kx), (stdys[i], stdx)) of the reference (:40-46):
+    the delta is separable, so every table is the outer product of two 1-D responses."""
+    cols = _delta_response(ky, stdys)            # (s0, ky)
+    row = _delta_response(kx, [stdx])[0]         # (kx,)
+    return cols[:, :, None] * row[None, None, :]
 
 
 def varYSizeGaussianFilter(arr, stdyrange, stdx=0, modex='wrap', modey='reflect', ctx=None):
@@ -57,7 +69,5 @@ def varYSizeGaussianFilter(arr, stdyrange, stdx=0, modex='wrap', modey='reflect'
         raise Exception('modey not supported')
     if modex not in ('reflect', 'wrap'):
         raise Exception('modex not supported')
-    kernels = np.empty((s0, ky, kx))
-    for i in range(s0):
-        kernels[i] = _gaussian_of_delta((ky, kx), (stdys[i], stdx))
+    kernels = _row_kernels(stdys, stdx, ky, kx)
     return ops.conv_ydep(arr, kernels, modex=modex, modey=modey, ctx=ctx)

@@ -107,6 +107,24 @@ def test_weight_tables_match_reference(oracle):
     assert ops.gaussian_kernel1d(0.5).size == 5 and ops.gaussian_kernel1d(1.0).size == 9
 
 
+def test_var_y_kernel_tables_match_scipy():
+    """the vectorised per-row tables of varYSizeGaussianFilter == one gaussian_filter(delta) per
+    row, as the reference builds them (filters/varYSizeGaussianFilter.py:40-46)"""
+    from scipy.ndimage import gaussian_filter
+    from imgprocessor_amd.filters.varYSizeGaussianFilter import _row_kernels
+    for (mn, mx, stdx, s0) in ((0, 4, 1, 40), (1, 3, 2, 57), (0, 4, 0, 33), (3, 3, 0, 10),
+                               (0, 0.3, 0.2, 9), (2, 9, 3, 64)):
+        stdys = np.linspace(mn, mx, s0)
+        kx = int(stdx * 2.5)
+        kx += 1 - kx % 2
+        ky = int(mx * 2.5)
+        ky += 1 - ky % 2
+        inp = np.zeros((ky, kx))
+        inp[ky // 2, kx // 2] = 1
+        want = np.stack([gaussian_filter(inp, (sy, stdx)) for sy in stdys])
+        assert_close(_row_kernels(stdys, stdx, ky, kx), want, 1e-13, 1e-15)
+
+
 def test_names_and_argument_checks():
     from imgprocessor_amd import ops, _lib
     from imgprocessor_amd.filters import maskedConvolve, extendArrayForConvolution
