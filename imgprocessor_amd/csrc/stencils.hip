@@ -38,6 +38,38 @@ conv_ydep_kernel(const T* __restrict__ src, int h, int w, long spitch,
   dst[(long)r * dpitch + c] = (T)v;
 }
 
+// The same correlation with the source window of a 64 x 4 output block staged in LDS once:
+// the border mode is resolved per tile element ((4+k0-1) x (64+k1-1) of them) instead of twice
+// per tap and pixel, and the taps are LDS reads.  Summation order as above -> identical results.
+template <typename T>
+__global__ void __launch_bounds__(256)
+conv_ydep_tile_kernel(const T* __restrict__ src, int h, int w, long spitch,
+                      const double* __restrict__ kernels, int k0, int k1, int bx, int by,
+                      T* __restrict__ dst, long dpitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ydep_lds[];
+  T* tile = reinterpret_cast<T*>(ydep_lds);
+  const int tw = 64 + k1 - 1, th = 4 + k0 - 1;
+  const int x0 = blockIdx.x * 64 - k1 / 2, y0 = blockIdx.y * 4 - k0 / 2;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int e = tid; e < tw * th; e += 256) {
+    const int ty = e / tw, tx = e - ty * tw;
+    const int yy = resolve_idx(y0 + ty, h, by), xx = resolve_idx(x0 + tx, w, bx);
+    tile[e] = (yy < 0 || xx < 0) ? (T)0 : src[(long)yy * spitch + xx];
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 64 + threadIdx.x, r = blockIdx.y * 4 + threadIdx.y;
+  if (c >= w || r >= h) return;
+  const double* kr = kernels + (long)r * k0 * k1;  // wave-uniform
+  const T* tp = tile + threadIdx.y * tw + threadIdx.x;
+  double v = 0.0;
+  for (int ii = 0; ii < k0; ii++)
+    for (int jj = 0; jj < k1; jj++) {
+      const double a = (double)tp[ii * tw + jj];
+      if (a == a) v += kr[ii * k1 + jj] * a;  // NaN-aware: skip, no renormalisation
+    }
+  dst[(long)r * dpitch + c] = (T)v;
+}
+
 // window [i-hkx, min(i+hkx, gx)) x [j-hky, min(j+hky, gy)), clipped at 0;
 // divisor = (rows-1)*(cols-1): the reference divides by its last loop indices
 template <typename T>
@@ -296,7 +328,18 @@ int ipa_conv_ydep_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, 
     IPA_UNSUPPORTED(ctx, "conv_ydep supports float32/float64 (got dtype %d)", dtype);
   dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (dtype == IPA_F32)
+  const size_t esz = dtype == IPA_F32 ? 4 : 8;
+  const size_t lds = (size_t)(64 + k1 - 1) * (4 + k0 - 1) * esz;
+  if (lds <= 48 * 1024) {  // the window of a block fits in LDS: staged version
+    if (dtype == IPA_F32)
+      hipLaunchKernelGGL((conv_ydep_tile_kernel<float>), grid, block, lds, ctx->stream,
+                         (const float*)d_src, h, w, src_pitch, d_kernels, k0, k1, border_x,
+                         border_y, (float*)d_dst, dst_pitch);
+    else
+      hipLaunchKernelGGL((conv_ydep_tile_kernel<double>), grid, block, lds, ctx->stream,
+                         (const double*)d_src, h, w, src_pitch, d_kernels, k0, k1, border_x,
+                         border_y, (double*)d_dst, dst_pitch);
+  } else if (dtype == IPA_F32)
     hipLaunchKernelGGL((conv_ydep_kernel<float>), grid, block, 0, ctx->stream, (const float*)d_src,
                        h, w, src_pitch, d_kernels, k0, k1, border_x, border_y, (float*)d_dst,
                        dst_pitch);
