@@ -358,7 +358,16 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
         const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
         if constexpr (FAST) {  // FAST strips: whole 16-byte-aligned chunks inside the image
           float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
-          *reinterpret_cast<float4*>(rows_ + 4u * lane) = q;
+          if constexpr (Src::kHasQ5) {
+            // sampling sources: stream the output past the caches (nt), they are better spent
+            // on the source lines adjacent rows and waves re-read (-2.5 % on the 4K chain)
+            __builtin_nontemporal_store(q.x, rows_ + 4u * lane);
+            __builtin_nontemporal_store(q.y, rows_ + 4u * lane + 1);
+            __builtin_nontemporal_store(q.z, rows_ + 4u * lane + 2);
+            __builtin_nontemporal_store(q.w, rows_ + 4u * lane + 3);
+          } else {
+            *reinterpret_cast<float4*>(rows_ + 4u * lane) = q;
+          }
         } else if (p.vec_out && n == 4) {
           *reinterpret_cast<float4*>(row) = q;
         } else {
