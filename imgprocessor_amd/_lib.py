@@ -63,6 +63,8 @@ PROTOTYPES = {
     'ipa_local_std_dev': [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_masked_mean_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_nan_max_dev': [_vp, _vp, _i, _i, _i, _l, _i, _vp, _l],
+    'ipa_closest_distance_dev': [_vp, _vp, _i, _i, _l, _i, _vp, _i, _l],
+    'ipa_pos_intensity_unc_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _d, _d, _i, _vp, _l],
     'ipa_median_threshold_dev': [_vp, _vp, _i, _i, _i, _l, _d, _i, _vp, _l, _vp, _l],
     'ipa_calib_prefilter_dev': [_vp, _vp, _i, _vp, _vp, _i, _i, _l, _l, _l, _d, _vp, _l],
     'ipa_remap_conv2d_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _dp, _i, _i, _vp, _i, _i,

@@ -8,6 +8,8 @@
 //   ipa_masked_mean* filters/maskedFilter.py:43-72 (_calcMean): mean of the unmasked pixels of
 //                    the clipped window, for the masked (fill) or the unmasked pixels
 //   ipa_nan_max*     filters/nan_maximum_filter.py:17-37: NaN-ignoring window maximum
+//   ipa_closest_distance*  render/closestDirectDistance.py:17-41
+//   ipa_pos_intensity_unc* uncertainty/positionToIntensityUncertainty.py:7-49
 //
 // All are one-output-pixel-per-lane kernels: a wave covers 64 consecutive
 // pixels of one row, so the per-row coefficient table of conv_ydep is
@@ -177,6 +179,75 @@ nan_max_kernel(const T* __restrict__ src, int gx, int gy, long pitch, int k, T* 
   dst[(long)i * dpitch + j] = m;
 }
 
+// render/closestDirectDistance.py:17-41: distance to the closest non-zero pixel within the
+// +-ksize window (centre excluded), 2*ksize when there is none, 0 on non-zero pixels.  The
+// minimum is taken over the integer squared distances; one sqrt at the end gives the same
+// float64 as the reference's running minimum of sqrt values.
+template <typename OT>
+__global__ void __launch_bounds__(256)
+closest_distance_kernel(const unsigned char* __restrict__ arr, int s0, int s1, long pitch,
+                        int ksize, OT* __restrict__ out, long opitch) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= s0 || j >= s1) return;
+  double md = 0.0;
+  if (!arr[(long)i * pitch + j]) {
+    const int big = 0x7fffffff;
+    int best = big;
+    const int xmn = i - ksize < 0 ? 0 : i - ksize, xmx = i + ksize >= s0 ? s0 - 1 : i + ksize;
+    const int ymn = j - ksize < 0 ? 0 : j - ksize, ymx = j + ksize >= s1 ? s1 - 1 : j + ksize;
+    for (int xi = xmn; xi <= xmx; xi++)
+      for (int yi = ymn; yi <= ymx; yi++)
+        if (arr[(long)xi * pitch + yi]) {
+          const int d2 = (xi - i) * (xi - i) + (yi - j) * (yi - j);
+          best = d2 < best ? d2 : best;
+        }
+    md = 2.0 * (double)ksize;
+    if (best != big) {
+      const double d = sqrt((double)best);
+      if (d < md) md = d;
+    }
+  }
+  out[(long)i * opitch + j] = (OT)md;  // uint16: truncation, like numba's store
+}
+
+// uncertainty/positionToIntensityUncertainty.py:7-49: square root of the PSF-weighted mean of
+// the squared differences to the centre pixel.  The Gaussian is equations/numbaGaussian2d.py
+// as that file is called there (first sigma on the row axis), evaluated per pixel: the constant
+// case then simply repeats the same table.  Pixels closer than ksize to the frame stay 0, NaN
+// centres are skipped.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pos_intensity_unc_kernel(const T* __restrict__ img, int s0, int s1, long pitch,
+                         const double* __restrict__ sxm, const double* __restrict__ sym,
+                         long spitch, double sx0, double sy0, int ksize,
+                         double* __restrict__ sint, long opitch) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= s0 || j >= s1) return;
+  double res = 0.0;
+  const double cpx = (double)img[(long)i * pitch + j];
+  if (i >= ksize && i < s0 - ksize && j >= ksize && j < s1 - ksize && cpx == cpx) {
+    const double v0 = sxm ? sxm[(long)i * spitch + j] : sx0;
+    const double v1 = sym ? sym[(long)i * spitch + j] : sy0;
+    const double ss_row = 2 * v0 * v0, ss_col = 2 * v1 * v1;
+    const int a = 2 * ksize + 1, c = a / 2;
+    double tot = 0.0;
+    for (int ii = 0; ii < a; ii++)
+      for (int jj = 0; jj < a; jj++)
+        tot += exp(-((double)((ii - c) * (ii - c)) / ss_row +
+                     (double)((jj - c) * (jj - c)) / ss_col));
+    double sdev = 0.0;
+    for (int ii = 0; ii < a; ii++)
+      for (int jj = 0; jj < a; jj++) {
+        const double e = exp(-((double)((ii - c) * (ii - c)) / ss_row +
+                               (double)((jj - c) * (jj - c)) / ss_col));
+        const double d = (double)img[(long)(i - ii + c) * pitch + (j - jj + c)] - cpx;
+        sdev += (e / tot) * (d * d);
+      }
+    res = sqrt(sdev);
+  }
+  sint[(long)i * opitch + j] = res;
+}
+
 // ---------------------------------------------------------------------------
 // 3x3 median + relative threshold (filters/medianThreshold.py:7-30), optionally behind the
 // dark-current / flat-field stages of CameraCalibration.correct
@@ -306,6 +377,51 @@ int ipa_calib_prefilter_dev(ipa_ctx* ctx, const void* d_img, int dtype, const vo
   if (!ctx) return IPA_ERR_BAD_ARG;
   return median_threshold_launch(ctx, d_img, dtype, d_bg, d_ff, true, h, w, pitch, bg_pitch,
                                  ff_pitch, threshold, 0, d_out, out_pitch, nullptr, 0);
+}
+
+int ipa_closest_distance_dev(ipa_ctx* ctx, const unsigned char* d_arr, int h, int w, long pitch,
+                             int ksize, void* d_out, int out_dtype, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_arr && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && ksize >= 1 && ksize < 20000, "empty image or bad ksize");
+  IPA_REQUIRE(ctx, pitch >= w && out_pitch >= w, "pitch smaller than width");
+  if (out_dtype != IPA_U16 && out_dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "closest_distance writes uint16 or float64 (got dtype %d)", out_dtype);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (out_dtype == IPA_U16)
+    hipLaunchKernelGGL((closest_distance_kernel<unsigned short>), grid, block, 0, ctx->stream,
+                       d_arr, h, w, pitch, ksize, (unsigned short*)d_out, out_pitch);
+  else
+    hipLaunchKernelGGL((closest_distance_kernel<double>), grid, block, 0, ctx->stream, d_arr, h, w,
+                       pitch, ksize, (double*)d_out, out_pitch);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_pos_intensity_unc_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w, long pitch,
+                              const double* d_sx, const double* d_sy, long sigma_pitch, double sx,
+                              double sy, int ksize, double* d_sint, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_img && d_sint, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && ksize >= 1, "empty image or ksize < 1");
+  IPA_REQUIRE(ctx, pitch >= w && out_pitch >= w, "pitch smaller than width");
+  IPA_REQUIRE(ctx, (d_sx == nullptr) == (d_sy == nullptr), "give both sigma maps or neither");
+  IPA_REQUIRE(ctx, !d_sx || sigma_pitch >= w, "sigma map pitch smaller than width");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "pos_intensity_unc supports float32/float64 (got dtype %d)", dtype);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == IPA_F32)
+    hipLaunchKernelGGL((pos_intensity_unc_kernel<float>), grid, block, 0, ctx->stream,
+                       (const float*)d_img, h, w, pitch, d_sx, d_sy, sigma_pitch, sx, sy, ksize,
+                       d_sint, out_pitch);
+  else
+    hipLaunchKernelGGL((pos_intensity_unc_kernel<double>), grid, block, 0, ctx->stream,
+                       (const double*)d_img, h, w, pitch, d_sx, d_sy, sigma_pitch, sx, sy, ksize,
+                       d_sint, out_pitch);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
 }
 
 int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,

@@ -392,6 +392,54 @@ def nan_max(arr, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
+def closest_distance(arr, ksize=30, dtype=np.uint16, ctx=None):
+    """render/closestDirectDistance.py:17-41: distance to the closest non-zero pixel"""
+    dtype = np.dtype(dtype)
+    if dtype not in (np.uint16, np.float64):
+        raise NotImplementedError('closest_distance writes uint16 or float64')
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, ctx=ctx)
+    if dev:
+        if arr.dtype != np.uint8:
+            raise TypeError('device input must be uint8 (non-zero = set)')
+        d_arr = arr
+    else:
+        d_arr = ctx.to_device(np.ascontiguousarray(np.asarray(arr) != 0, dtype=np.uint8))
+    if d_arr.ndim != 2:
+        raise ValueError('closest_distance works on 2-D arrays')
+    h, w = d_arr.shape
+    d_out = DeviceArray(ctx, (h, w), dtype)
+    ctx._check(ctx._lib.ipa_closest_distance_dev(ctx.handle, d_arr.ptr, h, w, w, int(ksize),
+                                                 d_out.ptr, dtype_id(dtype), w), 'closest_distance')
+    return d_out if dev else d_out.get()
+
+
+def pos_intensity_unc(image, sx, sy, ksize, ctx=None):
+    """uncertainty/positionToIntensityUncertainty.py:7-49; ksize = half window.  sx / sy are
+    both scalars or both (H, W) maps; returns float64"""
+    maps = isinstance(sx, (np.ndarray, DeviceArray))
+    dev = _is_dev(image)
+    ctx = _ctx_of(image, sx if _is_dev(sx) else None, sy if _is_dev(sy) else None, ctx=ctx)
+    d_img = image if dev else ctx.to_device(_float_img(image))
+    if d_img.ndim != 2 or d_img.dtype not in (np.float32, np.float64):
+        raise TypeError('pos_intensity_unc needs a 2-D float32/float64 image')
+    h, w = d_img.shape
+    d_sx = d_sy = None
+    if maps:
+        d_sx = sx if _is_dev(sx) else ctx.to_device(np.ascontiguousarray(sx, dtype=np.float64))
+        d_sy = sy if _is_dev(sy) else ctx.to_device(np.ascontiguousarray(sy, dtype=np.float64))
+        if tuple(d_sx.shape) != (h, w) or tuple(d_sy.shape) != (h, w) or \
+                d_sx.dtype != np.float64 or d_sy.dtype != np.float64:
+            raise ValueError('sigma maps must be float64 arrays of the image shape')
+    d_out = DeviceArray(ctx, (h, w), np.float64)
+    ctx._check(ctx._lib.ipa_pos_intensity_unc_dev(
+        ctx.handle, d_img.ptr, dtype_id(d_img.dtype), h, w, w,
+        d_sx.ptr if maps else None, d_sy.ptr if maps else None, w,
+        0.0 if maps else float(sx), 0.0 if maps else float(sy), int(ksize), d_out.ptr, w),
+        'pos_intensity_unc')
+    return d_out if dev else d_out.get()
+
+
 def median_threshold(img, threshold=0.1, condition='>', want_indices=True, ctx=None):
     """filters/medianThreshold.py:7-30 (size=3): -> (out, indices) new arrays"""
     if condition not in ('>', '<'):

@@ -211,6 +211,23 @@ int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsign
 int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,
                     int ksize, void* d_out, long out_pitch);
 
+/* replaces render/closestDirectDistance.py:17-41 (_calc): for every zero pixel of d_arr (uint8,
+ * non-zero = set) the distance to the closest set pixel within the +-ksize window, 2*ksize when
+ * there is none; 0 on set pixels.  out_dtype IPA_U16 (the reference's default dtype, value
+ * truncated) or IPA_F64. */
+int ipa_closest_distance_dev(ipa_ctx* ctx, const unsigned char* d_arr, int h, int w, long pitch,
+                             int ksize, void* d_out, int out_dtype, long out_pitch);
+
+/* replaces uncertainty/positionToIntensityUncertainty.py:7-49 (_calc_constPSF / _calc_variPSF):
+ *   sint[i,j] = sqrt( sum psf[ii,jj] * (img[i-ii+c, j-jj+c] - img[i,j])^2 ),  psf a (2*ksize+1)^2
+ * Gaussian normalised to 1 with the FIRST sigma on the row axis (numbaGaussian2d as called at
+ * :14,:39), pixels within ksize of the frame and NaN centres left 0.  d_sx / d_sy: per-pixel
+ * float64 sigma maps, or both NULL to use the scalars sx / sy.  img float32/float64, d_sint
+ * float64. */
+int ipa_pos_intensity_unc_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w, long pitch,
+                              const double* d_sx, const double* d_sy, long sigma_pitch, double sx,
+                              double sy, int ksize, double* d_sint, long out_pitch);
+
 /* replaces filters/medianThreshold.py:7-30 with size=3:
  *   blur = scipy.ndimage.median_filter(img, size=3)   (mode 'reflect': edge pixel repeated)
  *   hit  = |(img - blur) / blur| > threshold           ('<' when cond_less != 0), float64, IEEE

@@ -16,6 +16,11 @@
  *   - imgProcessor/filters/standardDeviation.py:34-70          -> orc_std2d
  *   - imgProcessor/filters/maskedFilter.py:43-72 (mean)        -> orc_masked_mean
  *   - imgProcessor/filters/nan_maximum_filter.py:17-37         -> orc_nan_max
+ *   - imgProcessor/filters/medianThreshold.py:7-30, camera/CameraCalibration.py:416-437
+ *                                                              -> orc_median_threshold, orc_calib_prefilter
+ *   - imgProcessor/render/closestDirectDistance.py:17-41       -> orc_closest_distance
+ *   - imgProcessor/uncertainty/positionToIntensityUncertainty.py:7-49
+ *                                                              -> orc_pos_to_intensity_unc
  *   - imgProcessor/interpolate/interpolate2dStructuredIDW.py:26-65      -> orc_idw
  *   - imgProcessor/interpolate/interpolate2dStructuredFastIDW.py:29-63  -> orc_fast_idw
  *   - imgProcessor/camera/LensDistortion.py:316-330,342-358 (cv2.remap,
@@ -800,6 +805,73 @@ int orc_calib_prefilter(const void* img, int dt, const void* bg, const void* ff,
   else memcpy(out, tmp, (size_t)h * w * (dt == ORC_F32 ? 4 : 8));
   free(tmp);
   return rc;
+}
+
+/* render/closestDirectDistance.py:17-41 (_calc): distance to the closest non-zero pixel of
+ * `arr` (uint8 / bool) inside the +-ksize window (centre excluded), 2*ksize when there is none,
+ * 0 on the non-zero pixels; out is uint16 (numba stores the float by truncation) or float64 */
+int orc_closest_distance(const uint8_t* arr, long s0, long s1, long ksize, void* out, int out_dt) {
+  if (out_dt != ORC_U16 && out_dt != ORC_F64) return -2;
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (long i = 0; i < s0; i++)
+    for (long j = 0; j < s1; j++) {
+      double md = 0.0;
+      if (!arr[i * s1 + j]) {
+        md = 2.0 * (double)ksize;
+        for (long ii = -ksize; ii <= ksize; ii++)
+          for (long jj = -ksize; jj <= ksize; jj++) {
+            if (ii == 0 && jj == 0) continue;
+            long xi = i + ii, yi = j + jj;
+            if (xi >= 0 && xi < s0 && yi >= 0 && yi < s1 && arr[xi * s1 + yi]) {
+              double d = sqrt((double)(ii * ii + jj * jj));
+              if (d < md) md = d;
+            }
+          }
+      }
+      if (out_dt == ORC_U16) ((uint16_t*)out)[i * s1 + j] = (uint16_t)md; /* truncation */
+      else ((double*)out)[i * s1 + j] = md;
+    }
+  return 0;
+}
+
+/* uncertainty/positionToIntensityUncertainty.py:7-49 (_calc_constPSF / _calc_variPSF) with
+ * equations/numbaGaussian2d.py:10-23 as it is CALLED there: numbaGaussian2d(psf, sx, sy) binds
+ * its (sy, sx) parameters in that order, i.e. the first value scales the ROW axis.
+ *   sint[i,j] = sqrt( sum_{ii,jj} psf[ii,jj] * (image[i-ii+c, j-jj+c] - image[i,j])^2 ),  c = a/2
+ * for i, j in [ksize, n-ksize), NaN centres skipped, everything else stays 0.  a = 2*ksize+1.
+ * sx / sy: per-pixel float64 maps (vari != 0) or a single value each (vari == 0). */
+int orc_pos_to_intensity_unc(const void* image, int dt, long s0, long s1, const double* sx,
+                             const double* sy, int vari, long ksize, double* sint) {
+  const long a = 2 * ksize + 1, c = a / 2;
+  memset(sint, 0, (size_t)s0 * s1 * sizeof(double));
+#pragma omp parallel num_threads(g_threads)
+  {
+    double* psf = (double*)malloc((size_t)a * a * sizeof(double));
+#pragma omp for schedule(dynamic, 4)
+    for (long i = ksize; i < s0 - ksize; i++)
+      for (long j = ksize; j < s1 - ksize; j++) {
+        double cpx = load_px(image, dt, i * s1 + j);
+        if (cpx != cpx) continue;
+        double v0 = vari ? sx[i * s1 + j] : sx[0], v1 = vari ? sy[i * s1 + j] : sy[0];
+        double ss_row = 2 * v0 * v0, ss_col = 2 * v1 * v1, tot = 0.0;
+        for (long ii = 0; ii < a; ii++)
+          for (long jj = 0; jj < a; jj++) {
+            double e = exp(-((double)((ii - c) * (ii - c)) / ss_row +
+                             (double)((jj - c) * (jj - c)) / ss_col));
+            psf[ii * a + jj] = e;
+            tot += e;
+          }
+        double sdev = 0.0;
+        for (long ii = 0; ii < a; ii++)
+          for (long jj = 0; jj < a; jj++) {
+            double d = load_px(image, dt, (i - ii + c) * s1 + (j - jj + c)) - cpx;
+            sdev += (psf[ii * a + jj] / tot) * (d * d);
+          }
+        sint[i * s1 + j] = sqrt(sdev);
+      }
+    free(psf);
+  }
+  return 0;
 }
 
 /* headline chain for the CPU baseline: map-based undistort then K x K filter */

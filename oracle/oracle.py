@@ -48,7 +48,8 @@ def lib():
                      'orc_masked_convolve', 'orc_gaussian_kernel1d', 'orc_sepconv2d',
                      'orc_conv_ydep', 'orc_std2d', 'orc_idw', 'orc_fast_idw',
                      'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max',
-                     'orc_median_threshold', 'orc_calib_prefilter'):
+                     'orc_median_threshold', 'orc_calib_prefilter', 'orc_closest_distance',
+                     'orc_pos_to_intensity_unc'):
             getattr(_LIB, name).restype = C.c_int
     return _LIB
 
@@ -321,6 +322,34 @@ def calib_prefilter(img, bg=None, ff=None, threshold=0.1):
                                    C.c_long(img.shape[1]), C.c_double(threshold), _p(out)),
          'calib_prefilter')
     return out
+
+
+def closestDirectDistance(arr, ksize=30, dtype=np.uint16):
+    """render/closestDirectDistance.py:6-41"""
+    a = np.ascontiguousarray(np.asarray(arr) != 0, dtype=np.uint8)
+    out = np.zeros(a.shape, dtype=dtype)
+    _chk(lib().orc_closest_distance(_p(a), C.c_long(a.shape[0]), C.c_long(a.shape[1]),
+                                    C.c_long(ksize), _p(out), _dt(out)), 'closest_distance')
+    return out
+
+
+def positionToIntensityUncertainty(image, sx, sy, kernelSize=None):
+    """uncertainty/positionToIntensityUncertainty.py:52-89 (integer kernelSize)"""
+    vari = isinstance(sx, np.ndarray)
+    if kernelSize is None:
+        kernelSize = max(3, 4 * (max(sx.max(), sy.max()) if vari else max(sx, sy)) + 1)
+    size = max(1, int(kernelSize) // 2)
+    image = np.ascontiguousarray(image)
+    if image.dtype.kind in 'ui':
+        image = image.astype(np.float64)
+    sxa = np.ascontiguousarray(sx, dtype=np.float64).reshape(-1)
+    sya = np.ascontiguousarray(sy, dtype=np.float64).reshape(-1)
+    sint = np.zeros(image.shape)
+    _chk(lib().orc_pos_to_intensity_unc(_p(image), _dt(image), C.c_long(image.shape[0]),
+                                        C.c_long(image.shape[1]), _p(sxa), _p(sya),
+                                        C.c_int(int(vari)), C.c_long(size), _p(sint)),
+         'pos_to_intensity_unc')
+    return sint
 
 
 # ---------------------------------------------------------- interpolate ----

@@ -265,6 +265,32 @@ def gen_stencils():
         out['cal_out_thr%s' % str(thr).replace('.', 'p')] = image
     np.savez_compressed(os.path.join(HERE, 'median_threshold.npz'), **out)
 
+    # (f2) closestDirectDistance and positionToIntensityUncertainty --------------------------
+    from imgProcessor.render.closestDirectDistance import closestDirectDistance
+    from imgProcessor.uncertainty.positionToIntensityUncertainty import \
+        positionToIntensityUncertainty
+    out = {}
+    rng = np.random.default_rng(15)
+    arr = rng.random((48, 60)) > 0.985
+    arr[5, 5] = True
+    out['cdd_arr'] = arr
+    for ks in (4, 9):
+        out['cdd_k%d' % ks] = closestDirectDistance(arr, ksize=ks)
+    img = 100 * synth((40, 46), 11, np.float64)
+    img[12, 13] = np.nan          # NaN centre: skipped; NaN neighbour: propagates
+    out['piu_img'] = img
+    out['piu_const_1p5_0p7_k7'] = positionToIntensityUncertainty(img, 1.5, 0.7, 7)
+    out['piu_const_2_2_k5'] = positionToIntensityUncertainty(img, 2, 2, 5)
+    sxm = 0.5 + 1.5 * synth((40, 46), 12, np.float64)
+    sym = 0.4 + 1.0 * synth((40, 46), 13, np.float64)
+    out['piu_sx'], out['piu_sy'] = sxm, sym
+    out['piu_vari_k7'] = positionToIntensityUncertainty(img, sxm, sym, 7)
+    u16 = np.round(img.clip(0, 100) * 40).astype(np.uint16)
+    u16[12, 13] = 7
+    out['piu_u16'] = u16
+    out['piu_u16_const_1_1_k5'] = positionToIntensityUncertainty(u16, 1, 1, 5)
+    np.savez_compressed(os.path.join(HERE, 'render_uncertainty.npz'), **out)
+
 
 # ---------------------------------------------------------------------------
 def undistort_map_np(K, d, newK, h, w):

@@ -371,6 +371,36 @@ def test_median_threshold_golden(ia, oracle):
     assert np.array_equal(medianThreshold(one, 0.01)[0], oracle.medianThreshold(one, 0.01)[0])
 
 
+def test_closest_distance_and_position_uncertainty(ia, oracle):
+    from imgprocessor_amd.render import closestDirectDistance
+    from imgprocessor_amd.uncertainty import positionToIntensityUncertainty
+    g = load_golden('render_uncertainty.npz')
+    for ks in (4, 9):
+        got = closestDirectDistance(g['cdd_arr'], ks)
+        assert got.dtype == np.uint16 and np.array_equal(got, g['cdd_k%d' % ks])
+    big = np.random.default_rng(8).random((301, 517)) > 0.997
+    assert np.array_equal(closestDirectDistance(big, 30), oracle.closestDirectDistance(big, 30))
+    assert np.array_equal(closestDirectDistance(big, 12, np.float64),
+                          oracle.closestDirectDistance(big, 12, np.float64))
+
+    def same(got, want, rt=1e-12):
+        assert got.dtype == np.float64
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert_close(np.nan_to_num(got), np.nan_to_num(want), rt, rt)
+    img = g['piu_img']
+    same(positionToIntensityUncertainty(img, 1.5, 0.7, 7), g['piu_const_1p5_0p7_k7'])
+    same(positionToIntensityUncertainty(img, 2, 2, 5), g['piu_const_2_2_k5'])
+    same(positionToIntensityUncertainty(img, g['piu_sx'], g['piu_sy'], 7), g['piu_vari_k7'])
+    same(positionToIntensityUncertainty(g['piu_u16'], 1, 1, 5), g['piu_u16_const_1_1_k5'])
+    i32 = np.nan_to_num(img).astype(np.float32)   # float32 frames: differences in float64
+    same(positionToIntensityUncertainty(i32, 1.5, 0.7, 7),
+         oracle.positionToIntensityUncertainty(i32, 1.5, 0.7, 7))
+    same(positionToIntensityUncertainty(img, 1.0, 1.0), oracle.positionToIntensityUncertainty(
+        img, 1.0, 1.0, 5))  # kernelSize None -> max(3, 4*std+1)
+    with pytest.raises(AssertionError):
+        positionToIntensityUncertainty(img, g['piu_sx'], g['piu_sy'][:5], 7)
+
+
 def test_camera_calibration_correct(ia, oracle, capsys):
     """CameraCalibration.correct: stages 2-4 pinned by the golden chain, stage 5 = the lens remap"""
     from imgprocessor_amd.camera.CameraCalibration import CameraCalibration

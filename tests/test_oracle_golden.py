@@ -121,6 +121,25 @@ def test_median_threshold_and_calibration_stages(oracle):
     assert np.isnan(g['cal_out_thr0p0']).any() and np.isfinite(g['cal_out_thr0p1']).all()
 
 
+def test_closest_distance_and_position_uncertainty(oracle):
+    g = load_golden('render_uncertainty.npz')
+    for ks in (4, 9):
+        got = oracle.closestDirectDistance(g['cdd_arr'], ks)
+        assert got.dtype == np.uint16 and np.array_equal(got, g['cdd_k%d' % ks])
+    f = oracle.closestDirectDistance(g['cdd_arr'], 9, np.float64)
+    assert np.array_equal(f.astype(np.uint16), g['cdd_k9']) and (f[g['cdd_arr']] == 0).all()
+
+    def same(got, want):
+        assert np.array_equal(np.isnan(got), np.isnan(want))
+        assert_close(np.nan_to_num(got), np.nan_to_num(want), 1e-12, 1e-12)
+    same(oracle.positionToIntensityUncertainty(g['piu_img'], 1.5, 0.7, 7), g['piu_const_1p5_0p7_k7'])
+    same(oracle.positionToIntensityUncertainty(g['piu_img'], 2, 2, 5), g['piu_const_2_2_k5'])
+    same(oracle.positionToIntensityUncertainty(g['piu_img'], g['piu_sx'], g['piu_sy'], 7),
+         g['piu_vari_k7'])
+    same(oracle.positionToIntensityUncertainty(g['piu_u16'], 1, 1, 5), g['piu_u16_const_1_1_k5'])
+    assert np.isnan(g['piu_vari_k7']).any() and (g['piu_vari_k7'][:3] == 0).all()
+
+
 def test_idw(oracle):
     g = load_golden('idw.npz')
     grid = g['grid']
