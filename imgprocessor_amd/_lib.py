@@ -62,6 +62,7 @@ PROTOTYPES = {
     'ipa_conv_ydep_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _i, _i, _vp, _l],
     'ipa_local_std_dev': [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_masked_mean_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],
+    'ipa_masked_median_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_nan_max_dev': [_vp, _vp, _i, _i, _i, _l, _i, _vp, _l],
     'ipa_closest_distance_dev': [_vp, _vp, _i, _i, _l, _i, _vp, _i, _l],
     'ipa_pos_intensity_unc_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _d, _d, _i, _vp, _l],

@@ -161,6 +161,111 @@ masked_mean_fill_wave_kernel(T* grid, const unsigned char* __restrict__ mask, in
   }
 }
 
+// filters/maskedFilter.py:76-102 (_calcMedian): np.median of the mask == 0 pixels of the clipped
+// window, wave-cooperative like the fill above.  The wave collects the window values as
+// order-preserving integer keys in its LDS buffer (ballot-ranked append), then finds the middle
+// order statistic(s) by a most-significant-bit-first radix descent: per bit one counting pass
+// over the buffer and one shuffle reduction.  Pure selection: bit-identical to sorting.
+template <typename T> struct key_of;
+template <> struct key_of<float> {
+  using type = unsigned;
+  static __device__ __forceinline__ unsigned enc(float v) {
+    unsigned u = __float_as_uint(v);
+    return (u >> 31) ? ~u : (u | 0x80000000u);
+  }
+  static __device__ __forceinline__ float dec(unsigned k) {
+    return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k);
+  }
+};
+template <> struct key_of<double> {
+  using type = unsigned long long;
+  static __device__ __forceinline__ unsigned long long enc(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+  }
+  static __device__ __forceinline__ double dec(unsigned long long k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  }
+};
+
+template <typename K>
+__device__ __forceinline__ K wave_select(const K* keys, int n, int k, int lane) {
+  constexpr int BITS = sizeof(K) * 8;
+  K prefix = 0;
+  for (int b = BITS - 1; b >= 0; b--) {
+    const K hi = b == BITS - 1 ? (K)0 : (K)(~(K)0 << (b + 1));
+    int c = 0;
+    for (int t = lane; t < n; t += 64) {
+      const K x = keys[t];
+      c += ((x & hi) == prefix && !((x >> b) & 1)) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off, 64);
+    if (k >= c) {
+      k -= c;
+      prefix |= (K)1 << b;
+    }
+  }
+  return prefix;
+}
+
+template <typename T, bool FILL>
+__global__ void __launch_bounds__(256)
+masked_median_wave_kernel(const T* src, const unsigned char* __restrict__ mask, int gx, int gy,
+                          long pitch, long mpitch, int k, int cap, int segs_x, T* dst,
+                          long dpitch) {
+  using KT = typename key_of<T>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char median_lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  KT* keys = reinterpret_cast<KT*>(median_lds) + (long)wave * cap;
+  const long seg = (long)blockIdx.x * 4 + wave;
+  const int i = (int)(seg / segs_x);
+  if (i >= gx) return;
+  const int js = (int)(seg - (long)i * segs_x) * 64;
+  const int jl = js + lane;
+  const bool inside = jl < gy;
+  const bool masked = inside && mask[(long)i * mpitch + jl] != 0;
+  if (!FILL && masked) dst[(long)i * dpitch + jl] = (T)__builtin_nan("");
+  unsigned long long todo = __ballot(inside && masked == FILL);
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  const int xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+  while (todo) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int j = js + b;
+    const int ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+    const int ww = ymx - ymn, ntap = (xmx - xmn) * ww;
+    int n = 0;
+    bool has_nan = false;
+    for (int base = 0; base < ntap; base += 64) {
+      const int t = base + lane;
+      bool use = false;
+      T v = (T)0;
+      if (t < ntap) {
+        const int dy = t / ww, ii = xmn + dy, jj = ymn + (t - dy * ww);
+        use = mask[(long)ii * mpitch + jj] == 0;
+        if (use) v = src[(long)ii * pitch + jj];
+      }
+      const unsigned long long um = __ballot(use);
+      has_nan |= __ballot(use && v != v) != 0ull;
+      if (use) keys[n + __popcll(um & below)] = key_of<T>::enc(v);
+      n += __popcll(um);
+    }
+    if (n == 0) continue;
+    __builtin_amdgcn_wave_barrier();  // wave-private buffer: in-order ds_write / ds_read
+    T med;
+    if (has_nan) {
+      med = (T)__builtin_nan("");
+    } else {
+      const T a = key_of<T>::dec(wave_select<KT>(keys, n, (n - 1) / 2, lane));
+      const T c = (n & 1) ? a : key_of<T>::dec(wave_select<KT>(keys, n, n / 2, lane));
+      med = (a + c) * (T)0.5;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) dst[(long)i * dpitch + j] = med;
+  }
+}
+
 // filters/nan_maximum_filter.py:17-37: np.nanmax over the clipped window (NaN when all NaN)
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -456,6 +561,39 @@ int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsign
     if (fill_mask) IPA_MM(double, true); else IPA_MM(double, false);
   }
 #undef IPA_MM
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_masked_median_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,
+                          int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,
+                          void* d_out, long out_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_arr && d_mask && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && ksize >= 2, "empty image or ksize < 2");
+  IPA_REQUIRE(ctx, pitch >= w && mask_pitch >= w && out_pitch >= w, "pitch smaller than width");
+  IPA_REQUIRE(ctx, fill_mask || d_arr != d_out, "fill_mask=0 cannot run in place");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "masked_median supports float32/float64 (got dtype %d)", dtype);
+  const int k = ksize / 2, cap = 4 * k * k;
+  const size_t lds = (size_t)4 * cap * (dtype == IPA_F32 ? 4 : 8);
+  if (lds > 64 * 1024)
+    IPA_UNSUPPORTED(ctx, "masked_median: a %dx%d window does not fit the per-wave LDS buffer",
+                    2 * k, 2 * k);
+  const int segs_x = (w + 63) / 64;
+  const long segs = (long)segs_x * h;
+  dim3 grid((unsigned)((segs + 3) / 4)), block(256);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+#define IPA_MMED(T, FILL)                                                                       \
+  hipLaunchKernelGGL((masked_median_wave_kernel<T, FILL>), grid, block, lds, ctx->stream,       \
+                     (const T*)d_arr, d_mask, h, w, pitch, mask_pitch, k, cap, segs_x, (T*)d_out, \
+                     out_pitch)
+  if (dtype == IPA_F32) {
+    if (fill_mask) IPA_MMED(float, true); else IPA_MMED(float, false);
+  } else {
+    if (fill_mask) IPA_MMED(double, true); else IPA_MMED(double, false);
+  }
+#undef IPA_MMED
   IPA_HIP(ctx, hipGetLastError());
   return IPA_OK;
 }

@@ -347,9 +347,12 @@ def local_std(img, blurred, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
-def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None):
-    """filters/maskedFilter.py:43-72 (_calcMean).  fill_mask=True fills ``arr`` IN PLACE (host
-    arrays are copied back into ``arr``); fill_mask=False returns a new NaN-padded array."""
+def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None, fn='mean'):
+    """filters/maskedFilter.py:43-102 (_calcMean / _calcMedian by ``fn``).  fill_mask=True fills
+    ``arr`` IN PLACE (host arrays are copied back into ``arr``); fill_mask=False returns a new
+    NaN-padded array."""
+    if fn not in ('mean', 'median'):
+        raise ValueError("fn must be 'mean' or 'median'")
     dev = _is_dev(arr)
     ctx = _ctx_of(arr, mask, ctx=ctx)
     if dev:
@@ -367,9 +370,9 @@ def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None):
         raise ValueError('arr and mask must be 2-D arrays of equal shape (mask uint8/bool)')
     h, w = d_arr.shape
     d_out = d_arr if fill_mask else DeviceArray(ctx, (h, w), d_arr.dtype)
-    ctx._check(ctx._lib.ipa_masked_mean_dev(ctx.handle, d_arr.ptr, dtype_id(d_arr.dtype),
-                                            d_mask.ptr, h, w, w, w, int(ksize), int(bool(fill_mask)),
-                                            d_out.ptr, w), 'masked_mean')
+    f = ctx._lib.ipa_masked_mean_dev if fn == 'mean' else ctx._lib.ipa_masked_median_dev
+    ctx._check(f(ctx.handle, d_arr.ptr, dtype_id(d_arr.dtype), d_mask.ptr, h, w, w, w, int(ksize),
+                 int(bool(fill_mask)), d_out.ptr, w), 'masked_' + fn)
     if dev:
         return d_out
     if fill_mask:

@@ -206,6 +206,14 @@ int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsign
                         int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,
                         void* d_out, long out_pitch);
 
+/* replaces filters/maskedFilter.py:76-102 (_calcMedian, maskedFilter(fn='median')): as
+ * ipa_masked_mean_dev with np.median of the window's mask == 0 pixels (mean of the two middle
+ * values for an even count; NaN if any of them is NaN).  The window (ksize/2*2)^2 must fit the
+ * kernel's per-wave LDS buffer: ksize <= 126 for float32, 90 for float64. */
+int ipa_masked_median_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsigned char* d_mask,
+                          int h, int w, long pitch, long mask_pitch, int ksize, int fill_mask,
+                          void* d_out, long out_pitch);
+
 /* replaces filters/nan_maximum_filter.py:17-37 (_calc): np.nanmax over the same clipped
  * window; NaN where the whole window is NaN. */
 int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,

@@ -713,6 +713,51 @@ int orc_masked_mean(const void* arr, int dt, const uint8_t* sel, const uint8_t* 
   return 0;
 }
 
+static int cmp_double(const void* a, const void* b) {
+  double x = *(const double*)a, y = *(const double*)b;
+  return x < y ? -1 : (x > y ? 1 : 0);
+}
+
+/* filters/maskedFilter.py:76-102 (_calcMedian): as orc_masked_mean with np.median of the
+ * selected window values (mean of the two middle ones for an even count, formed in the array
+ * dtype; NaN if any value is NaN) */
+int orc_masked_median(const void* arr, int dt, const uint8_t* sel, const uint8_t* use, long gx,
+                      long gy, long k, void* out) {
+#pragma omp parallel num_threads(g_threads)
+  {
+    double* buf = (double*)malloc((size_t)(4 * k * k + 1) * sizeof(double));
+#pragma omp for schedule(dynamic, 4)
+    for (long i = 0; i < gx; i++)
+      for (long j = 0; j < gy; j++) {
+        if (!sel[i * gy + j]) continue;
+        long xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+        long ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+        long n = 0;
+        int has_nan = 0;
+        for (long ii = xmn; ii < xmx; ii++)
+          for (long jj = ymn; jj < ymx; jj++)
+            if (use[ii * gy + jj]) {
+              double v = load_px(arr, dt, ii * gy + jj);
+              has_nan |= v != v;
+              buf[n++] = v;
+            }
+        if (n == 0) continue;
+        double med;
+        if (has_nan) {
+          med = NAN;
+        } else {
+          qsort(buf, (size_t)n, sizeof(double), cmp_double);
+          double a = buf[(n - 1) / 2], b = buf[n / 2];
+          if (dt == ORC_F32) med = (double)(((float)a + (float)b) * 0.5f);
+          else med = (a + b) * 0.5;
+        }
+        store_px(out, dt, i * gy + j, med);
+      }
+    free(buf);
+  }
+  return 0;
+}
+
 /* filters/nan_maximum_filter.py:17-37: np.nanmax over [i-k, min(i+k,gx)) x [j-k, min(j+k,gy));
  * an all-NaN window gives NaN */
 int orc_nan_max(const void* arr, int dt, long gx, long gy, long k, void* out) {

@@ -48,6 +48,7 @@ def lib():
                      'orc_masked_convolve', 'orc_gaussian_kernel1d', 'orc_sepconv2d',
                      'orc_conv_ydep', 'orc_std2d', 'orc_idw', 'orc_fast_idw',
                      'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max',
+                     'orc_masked_median',
                      'orc_median_threshold', 'orc_calib_prefilter', 'orc_closest_distance',
                      'orc_pos_to_intensity_unc'):
             getattr(_LIB, name).restype = C.c_int
@@ -266,8 +267,8 @@ def standardDeviation2d(img, ksize=5, blurred=None):
 
 
 def maskedFilter(arr, mask, ksize=30, fill_mask=True, fn='mean'):
-    """filters/maskedFilter.py:12-37, fn='mean' (the median variant is not restated)"""
-    assert fn == 'mean'
+    """filters/maskedFilter.py:12-37, fn = 'mean' | 'median'"""
+    assert fn in ('mean', 'median')
     mask = np.ascontiguousarray(mask, dtype=bool)
     if fill_mask:
         sel, out = mask, arr
@@ -277,9 +278,9 @@ def maskedFilter(arr, mask, ksize=30, fill_mask=True, fn='mean'):
     use = np.ascontiguousarray(~mask, dtype=np.uint8)
     sel = np.ascontiguousarray(sel, dtype=np.uint8)
     arr = np.ascontiguousarray(arr)
-    _chk(lib().orc_masked_mean(_p(arr), _dt(arr), _p(sel), _p(use), C.c_long(arr.shape[0]),
-                               C.c_long(arr.shape[1]), C.c_long(ksize // 2), _p(out)),
-         'masked_mean')
+    f = lib().orc_masked_mean if fn == 'mean' else lib().orc_masked_median
+    _chk(f(_p(arr), _dt(arr), _p(sel), _p(use), C.c_long(arr.shape[0]), C.c_long(arr.shape[1]),
+           C.c_long(ksize // 2), _p(out)), 'masked_' + fn)
     return out
 
 

@@ -207,7 +207,13 @@ def gen_stencils():
         out['mean_fill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=True, fn='mean')
         out['mean_nofill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=False,
                                                    fn='mean')
+    for ks in (6, 11):
+        out['median_fill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=True,
+                                                   fn='median')
+        out['median_nofill_k%d' % ks] = maskedFilter(a.copy(), m, ksize=ks, fill_mask=False,
+                                                     fn='median')
     a32 = a.astype(np.float32)
+    out['median32_fill_k6'] = maskedFilter(a32.copy(), m, ksize=6, fill_mask=True, fn='median')
     out['mean32_fill_k6'] = maskedFilter(a32.copy(), m, ksize=6, fill_mask=True, fn='mean')
     an = a.copy()
     an[rng.random(a.shape) < 0.3] = np.nan

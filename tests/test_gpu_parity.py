@@ -337,8 +337,28 @@ def test_masked_filter_and_nan_max(ia, oracle):
     bn[m] = np.nan
     assert np.array_equal(nan_maximum_filter(bn.astype(np.float32), 7),
                           oracle.nan_maximum_filter(bn.astype(np.float32), 7), equal_nan=True)
+    # median: pure selection -> bit-identical to the reference fixtures and to the oracle
+    for ks in (6, 11):
+        a = g['arr'].copy()
+        assert maskedFilter(a, g['mask'], ks, fn='median') is a
+        assert np.array_equal(a, g['median_fill_k%d' % ks])
+        got = maskedFilter(g['arr'].copy(), g['mask'], ks, fill_mask=False, fn='median')
+        assert np.array_equal(got, g['median_nofill_k%d' % ks], equal_nan=True)
+    a32 = g['arr'].astype(np.float32)
+    assert np.array_equal(maskedFilter(a32, g['mask'], 6, fn='median'), g['median32_fill_k6'])
+    for dt in (np.float64, np.float32):
+        b = big.astype(dt)
+        want = oracle.maskedFilter(b.copy(), m, 30, True, 'median')
+        assert np.array_equal(maskedFilter(b, m, 30, fn='median'), want)
+    bn = big.copy()
+    bn[::9, ::13] = np.nan   # a NaN among the window values makes the median NaN (np.median)
+    want = oracle.maskedFilter(bn.copy(), m, 8, True, 'median')
+    assert np.isnan(want).any()
+    assert np.array_equal(maskedFilter(bn, m, 8, fn='median'), want, equal_nan=True)
     with pytest.raises(NotImplementedError):
-        maskedFilter(big, m, 5, fn='median')
+        maskedFilter(big, m, 200, fn='median')   # window larger than the per-wave LDS buffer
+    with pytest.raises(ValueError):
+        maskedFilter(big, m, 5, fn='mode')
 
 
 def test_median_threshold_golden(ia, oracle):

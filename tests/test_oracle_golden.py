@@ -80,6 +80,13 @@ def test_masked_filter_and_nan_max(oracle):
     got = oracle.maskedFilter(g['arr'].astype(np.float32), g['mask'], 6, True)
     assert got.dtype == np.float32
     assert_close(got, g['mean32_fill_k6'], 1e-6, 1e-7)
+    for ks in (6, 11):   # median: selection only -> bit-exact
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, True, 'median')
+        assert np.array_equal(got, g['median_fill_k%d' % ks])
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, False, 'median')
+        assert np.array_equal(got, g['median_nofill_k%d' % ks], equal_nan=True)
+    got = oracle.maskedFilter(g['arr'].astype(np.float32), g['mask'], 6, True, 'median')
+    assert got.dtype == np.float32 and np.array_equal(got, g['median32_fill_k6'])
     for ks in (3, 6, 9):
         got, want = oracle.nan_maximum_filter(g['arr_nan'], ks), g['nanmax_k%d' % ks]
         assert np.isnan(want).any() or ks > 3
