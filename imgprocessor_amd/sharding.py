@@ -122,3 +122,49 @@ class FramePipeline(object):
             if e is not None:
                 raise e
         return out
+
+
+# ----------------------------------------------------------------- one huge frame --
+def row_bands(height, world_size, halo=0):
+    """Split the OUTPUT rows of one frame into `world_size` contiguous bands (the
+    single-8K-frame alternative).  Returns per rank (out_start, out_stop, lo, hi): the band's
+    own rows and the rows [lo, hi) it has to compute so that a filter of half-size `halo`
+    sees true neighbours at the inner band edges (clipped at the frame, where the filter's
+    border mode applies as usual)."""
+    bands = []
+    for r in range(world_size):
+        a, b = frame_block(height, world_size, r)
+        bands.append((a, b, max(0, a - halo), min(height, b + halo)))
+    return bands
+
+
+def remap_filter_band(src, mapx, mapy, kernel, band, interpolation='linear',
+                      border_mode='constant', border_value=0.0, conv_mode='reflect'):
+    """rows [band[0], band[1]) of filter(remap(src)) for ONE frame, computed from the band's
+    own map rows plus a halo — what one GPU of a row-band split runs.  `src`, `mapx`, `mapy`
+    are DeviceArrays of that GPU (the source frame and the maps are replicated; only the
+    output is split, no collective).  Equal to the same rows of the whole-frame result."""
+    import numpy as np
+    from . import ops
+    a, b, lo, hi = band
+    if b <= a:
+        return None
+    mh, mw = mapx.shape
+    part = ops.remap(src, mapx, mapy, interpolation, border_mode, border_value,
+                     out_dtype=np.float32, map_roi=(0, lo, mw, hi - lo))
+    k = np.asarray(kernel, dtype=np.float64)
+    hk = k.shape[0] // 2
+    if (lo > 0 and a - lo < hk) or (hi < mh and hi - b < hk):
+        raise ValueError('the band needs a halo of %d rows for a %d-row kernel' % (hk, k.shape[0]))
+    if (lo > 0 or hi < mh) and conv_mode in ('wrap', 'grid-wrap'):
+        raise NotImplementedError('a wrapping filter border needs the whole frame')
+    full = ops.conv2d(part, k, conv_mode)
+    out = part.ctx.empty((b - a, mw), np.float32)
+    part.ctx._check(part.ctx._lib.ipa_memcpy_d2d(
+        part.ctx.handle, out.ptr, _offset_ptr(full, (a - lo) * mw), out.nbytes), 'memcpy_d2d')
+    return out
+
+
+def _offset_ptr(arr, elems):
+    import ctypes as C
+    return C.c_void_p(arr.ptr.value + elems * arr.dtype.itemsize)

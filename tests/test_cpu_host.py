@@ -284,6 +284,21 @@ dist.destroy_process_group()
 '''
 
 
+def test_row_bands():
+    """single-frame split (SURVEY §8e alternative): bands tile the rows, halos are clipped"""
+    from imgprocessor_amd.sharding import row_bands
+    for h, g, halo in ((4320, 8, 5), (10, 3, 2), (7, 8, 1), (1, 2, 3)):
+        bands = row_bands(h, g, halo)
+        assert len(bands) == g
+        rows = [r for (a, b, lo, hi) in bands for r in range(a, b)]
+        assert rows == list(range(h))
+        for (a, b, lo, hi) in bands:
+            assert 0 <= lo <= a <= b <= hi <= h
+            if b > a:
+                assert lo == max(0, a - halo) and hi == min(h, b + halo)
+    assert row_bands(4320, 8, 5)[1] == (540, 1080, 535, 1085)
+
+
 def test_two_rank_partition_gloo(tmp_path):
     """world_size-2 run on CPU (gloo): ranks own disjoint contiguous blocks that cover the
     batch, and the timing reduction bench.py uses (barrier + MAX) works"""
