@@ -1,0 +1,1 @@
+"""camera/ classes of the hot path: LensDistortion, PerspectiveCorrection, CameraCalibration."""

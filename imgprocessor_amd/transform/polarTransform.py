@@ -1,69 +1,66 @@
-"""Cartesian <-> polar maps — reference: imgProcessor/transform/polarTransform.py:26-105.
-The maps are built on the host exactly as the reference builds them; the remap runs on the
-GPU (the reference's default INTER_AREA degrades to bilinear inside cv2.remap; BORDER_REFLECT)."""
+"""Cartesian <-> polar resampling on the GPU remap kernel.
+
+Reference call surface: imgProcessor/transform/polarTransform.py:26-105
+(``linearToPolar``, ``polarToLinear`` and their ``*Maps`` builders).  Only the
+coordinate grids are made on the host (two small outer products); the
+resampling is ``ops.remap`` with BORDER_REFLECT.  The reference's default
+``INTER_AREA`` is treated by ``cv2.remap`` as bilinear, which is the default
+here.  Returned map pairs keep the reference's order: the first array is what
+the reference hands to ``cv2.remap`` as ``map1`` (source x), the second ``map2``.
+"""
 import numpy as np
 
 from .. import ops
 
-
-def _polar2cart(r, phi, center):
-    return r * np.cos(phi) + center[0], r * np.sin(phi) + center[1]
+_TWO_PI = 2.0 * np.pi
 
 
-def _cart2polar(x, y, center):
-    xx, yy = x - center[0], y - center[1]
-    return np.hypot(xx, yy), np.arctan2(yy, xx)
+def _f32(*arrays):
+    return tuple(np.asarray(a, dtype=np.float32) for a in arrays)
 
 
 def linearToPolarMaps(shape, center=None, final_radius=None, initial_radius=None,
                       phase_width=None):
-    s0, s1 = shape
-    if center is None:
-        center = (s0 - 1) / 2, (s1 - 1) / 2
-    if final_radius is None:
-        final_radius = ((0.5 * s0) ** 2 + (0.5 * s1) ** 2) ** 0.5
-    if initial_radius is None:
-        initial_radius = 0
-    if phase_width is None:
-        phase_width = 2 * np.pi * final_radius
-    # (np.linspace wants integer sample counts on current numpy; the reference passes floats)
-    phi, R = np.meshgrid(np.linspace(1.5 * np.pi, -0.5 * np.pi, int(phase_width)),
-                         np.linspace(initial_radius, final_radius,
-                                     int(final_radius - initial_radius)))
-    mapX, mapY = _polar2cart(R, phi, center)
-    return mapY.astype(np.float32), mapX.astype(np.float32)
+    """sampling grid of the unrolled image: rows = radius, columns = angle"""
+    rows, cols = shape
+    c0, c1 = ((rows - 1) / 2, (cols - 1) / 2) if center is None else center
+    r_out = ((0.5 * rows) ** 2 + (0.5 * cols) ** 2) ** 0.5 if final_radius is None else final_radius
+    r_in = 0 if initial_radius is None else initial_radius
+    n_phi = _TWO_PI * r_out if phase_width is None else phase_width
+    # sample counts are truncated to int (the reference passes the floats to np.linspace)
+    radii = np.linspace(r_in, r_out, int(r_out - r_in))
+    angles = np.linspace(0.75 * _TWO_PI, -0.25 * _TWO_PI, int(n_phi))
+    along_c0 = np.multiply.outer(radii, np.cos(angles)) + c0
+    along_c1 = np.multiply.outer(radii, np.sin(angles)) + c1
+    return _f32(along_c1, along_c0)
 
 
 def linearToPolar(img, center=None, final_radius=None, initial_radius=None, phase_width=None,
                   interpolation='linear', maps=None, borderValue=0, borderMode='reflect',
                   ctx=None):
-    if maps is None:
-        mapY, mapX = linearToPolarMaps(img.shape[:2], center, final_radius, initial_radius,
-                                       phase_width)
-    else:
-        mapY, mapX = maps
-    # the reference calls cv2.remap(img, mapY, mapX): its "mapY" is cv2's map1 (x coordinates)
-    return ops.remap(img, mapY, mapX, interpolation, borderMode, borderValue, ctx=ctx)
+    first, second = maps if maps is not None else linearToPolarMaps(
+        img.shape[:2], center, final_radius, initial_radius, phase_width)
+    return ops.remap(img, first, second, interpolation, borderMode, borderValue, ctx=ctx)
 
 
 def polarToLinearMaps(orig_shape, out_shape=None, center=None):
-    s0, s1 = orig_shape
+    """sampling grid that rolls an unrolled (radius, angle) image back up"""
+    n_r, n_phi = orig_shape
     if out_shape is None:
-        out_shape = (int(round(2 * s0 / 2 ** 0.5)) - (1 - s0 % 2),
-                     int(round(2 * s1 / (2 * np.pi) / 2 ** 0.5)))
-    ss0, ss1 = out_shape
-    if center is None:
-        center = ss1 // 2, ss0 // 2
-    yy, xx = np.mgrid[0:ss0:1., 0:ss1:1.]
-    r, phi = _cart2polar(xx, yy, center)
-    phi = (phi + np.pi) / (2 * np.pi) * (s1 - 2)  # -pi..pi -> 0..s1
-    return phi.astype(np.float32), r.astype(np.float32)
+        side = 2 * n_r / np.sqrt(2.0)
+        out_shape = (int(round(side)) - (1 - n_r % 2),
+                     int(round(2 * n_phi / _TWO_PI / np.sqrt(2.0))))
+    out_rows, out_cols = out_shape
+    c0, c1 = (out_cols // 2, out_rows // 2) if center is None else center
+    dx = np.arange(out_cols, dtype=np.float64)[None, :] - c0
+    dy = np.arange(out_rows, dtype=np.float64)[:, None] - c1
+    radius = np.hypot(dx, dy)
+    angle = np.arctan2(dy, dx)
+    column = (angle + np.pi) / _TWO_PI * (n_phi - 2)  # -pi..pi -> columns of the unrolled image
+    return _f32(column, radius)
 
 
 def polarToLinear(img, shape=None, center=None, maps=None, interpolation='linear', borderValue=0,
                   borderMode='reflect', ctx=None):
-    if maps is None:
-        mapY, mapX = polarToLinearMaps(img.shape[:2], shape, center)
-    else:
-        mapY, mapX = maps
-    return ops.remap(img, mapY, mapX, interpolation, borderMode, borderValue, ctx=ctx)
+    first, second = maps if maps is not None else polarToLinearMaps(img.shape[:2], shape, center)
+    return ops.remap(img, first, second, interpolation, borderMode, borderValue, ctx=ctx)
