@@ -103,13 +103,34 @@ template <> struct TapLoad<uint8_t, float> {
   }
 };
 
+// uint16 tap rows come in as ONE dword / dwordx2 / dwordx4 at the 2-byte-aligned byte offset of
+// the first tap (gfx950 serves buffer loads at any 2-byte offset: tools/unaligned_probe.hip);
+// per-tap ushort loads would double the gather instructions of a camera-frame remap.
 template <> struct TapLoad<uint16_t, float> {
   static __device__ __forceinline__ float one(const SrcView& s, int e) {
     return (float)__builtin_amdgcn_raw_buffer_load_b16(s.rsrc, e << 1, 0, 0);
   }
+  static __device__ __forceinline__ void unpack(unsigned r, float& lo, float& hi) {
+    lo = (float)(r & 0xffffu);
+    hi = (float)(r >> 16);
+  }
   template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, float (&v)[N]) {
+    if constexpr (N == 1) {
+      v[0] = one(s, e);
+    } else if constexpr (N == 2) {
+      unpack(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, e << 1, 0, 0), v[0], v[1]);
+    } else if constexpr (N == 4) {
+      auto r = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, e << 1, 0, 0);
+      unpack(r[0], v[0], v[1]);
+      unpack(r[1], v[2], v[3]);
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; k++) v[k] = one(s, e + k);
+      for (int k = 0; k < N; k += 8) {
+        auto r = __builtin_amdgcn_raw_buffer_load_b128(s.rsrc, (e + k) << 1, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) unpack(r[j], v[k + 2 * j], v[k + 2 * j + 1]);
+      }
+    }
   }
 };
 
