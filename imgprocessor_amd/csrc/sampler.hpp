@@ -97,9 +97,23 @@ template <> struct TapLoad<uint8_t, float> {
   static __device__ __forceinline__ float one(const SrcView& s, int e) {
     return (float)__builtin_amdgcn_raw_buffer_load_b8(s.rsrc, e, 0, 0);
   }
+  // tap rows as one ushort / dword / dwordx2 at the byte offset of the first tap (served at
+  // any alignment, tools/unaligned_probe.hip)
   template <int N> static __device__ __forceinline__ void row(const SrcView& s, int e, float (&v)[N]) {
+    if constexpr (N == 1) {
+      v[0] = one(s, e);
+    } else if constexpr (N == 2) {
+      const unsigned r = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(s.rsrc, e, 0, 0);
+      v[0] = (float)(r & 0xffu);
+      v[1] = (float)(r >> 8);
+    } else {
 #pragma unroll
-    for (int k = 0; k < N; k++) v[k] = one(s, e + k);
+      for (int k = 0; k < N; k += 4) {
+        const unsigned r = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, e + k, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[k + j] = (float)((r >> (8 * j)) & 0xffu);
+      }
+    }
   }
 };
 
@@ -397,15 +411,25 @@ __device__ __forceinline__ uint8_t sample_u8_fixed(const SrcView& s, C sx, C sy,
   int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
   int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
   int v[4];
+  if (ix >= 0 && iy >= 0 && ix + 2 <= s.w && iy + 2 <= s.h) {
+    // interior footprint: each tap row is one ushort load (any byte offset)
+    const unsigned r0 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+        s.rsrc, iy * s.pitch + ix, 0, 0);
+    const unsigned r1 = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+        s.rsrc, (iy + 1) * s.pitch + ix, 0, 0);
+    v[0] = (int)(r0 & 0xffu); v[1] = (int)(r0 >> 8);
+    v[2] = (int)(r1 & 0xffu); v[3] = (int)(r1 >> 8);
+  } else {
 #pragma unroll
-  for (int r = 0; r < 2; r++) {
-    int yy = resolve_idx(iy + r, s.h, s.border);
+    for (int r = 0; r < 2; r++) {
+      int yy = resolve_idx(iy + r, s.h, s.border);
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
-      int xx = resolve_idx(ix + c, s.w, s.border);
-      v[r * 2 + c] = (yy < 0 || xx < 0)
-                         ? (int)cv8
-                         : (int)__builtin_amdgcn_raw_buffer_load_b8(s.rsrc, yy * s.pitch + xx, 0, 0);
+      for (int c = 0; c < 2; c++) {
+        int xx = resolve_idx(ix + c, s.w, s.border);
+        v[r * 2 + c] = (yy < 0 || xx < 0) ? (int)cv8
+                                          : (int)__builtin_amdgcn_raw_buffer_load_b8(
+                                                s.rsrc, yy * s.pitch + xx, 0, 0);
+      }
     }
   }
   int acc = v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11;
