@@ -284,6 +284,50 @@ def test_transform_wrappers(ia, orc):
     assert back.shape == rings.shape
 
 
+def test_strip_geometry_sweep(ia, orc):
+    """ragged shapes around the strip geometry of the marching kernels (248-px strip step,
+    256-px strip width, 32-row strips, chunked rows): filter, separable filter and the fused
+    chains against the oracle, single frames and small batches"""
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(17)
+    widths = (1, 3, 247, 248, 249, 256, 257, 495, 496, 497, 505, 760)
+    heights = (1, 2, 5, 31, 32, 33, 37, 65)
+    cases = [(h, w) for h in heights for w in widths]
+    rng.shuffle(cases)
+    for n, (h, w) in enumerate(cases):
+        img = synth((h, w), n)
+        ksz = (3, 5, 7)[n % 3]
+        k = rng.random((ksz, ksz))
+        k /= k.sum()
+        mode = ('reflect', 'constant', 'wrap', 'mirror', 'nearest')[n % 5]
+        close32(ia.ops.conv2d(img, k, mode, 0.25), orc.conv2d(img, k, mode, 0.25),
+                'conv %dx%d k%d %s' % (h, w, ksz, mode))
+        g = rng.random(ksz)
+        g /= g.sum()
+        close32(ia.ops.sepconv2d(img, g, g, mode, 0.25), orc.sepconv2d(img, g, g, mode, 0.25),
+                'sep %dx%d k%d %s' % (h, w, ksz, mode))
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        mx = (xx + 1.7 * np.sin(yy / 9 + 0.3) - 0.4).astype(np.float32)
+        my = (yy + 1.3 * np.cos(xx / 11) + 0.2).astype(np.float32)
+        want_r = orc.remap(img, mx, my, orc.LINEAR, orc.CONSTANT, 0.1)
+        d_img, dmx, dmy = ctx.to_device(img), ctx.to_device(mx), ctx.to_device(my)
+        close32(ia.ops.remap_conv2d(d_img, dmx, dmy, k, 'linear', 'constant', 0.1, mode).get(),
+                orc.conv2d(want_r, k, mode), 'fused %dx%d k%d %s' % (h, w, ksz, mode))
+        close32(ia.ops.remap_sepconv2d(d_img, dmx, dmy, g, g, 'linear', 'constant', 0.1,
+                                       mode).get(),
+                orc.sepconv2d(want_r, g, g, mode), 'fused sep %dx%d k%d %s' % (h, w, ksz, mode))
+        close32(ia.ops.remap(img, mx, my, 'linear', 'constant', 0.1), want_r,
+                'remap %dx%d' % (h, w), scale=1.0)
+    # batches of odd sizes through the frame-inner dispatch order
+    for nb, (h, w) in ((3, (37, 505)), (5, (65, 760)), (2, (33, 256))):
+        batch = np.stack([synth((h, w), 50 + i) for i in range(nb)])
+        k = rng.random((5, 5))
+        k /= k.sum()
+        got = ia.ops.conv2d(batch, k)
+        for i in range(nb):
+            close32(got[i], orc.conv2d(batch[i], k), 'batch conv %d' % i)
+
+
 def test_single_frame_row_bands(ia, orc):
     """C5 alternative: one frame split into output row bands, one band per GPU,
     no collective — the concatenated bands equal the whole-frame chain bit for bit"""
