@@ -120,9 +120,8 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   // addresser per dwordx2 gather, tools/ta_micro.hip), and the map values are four coalesced
   // dword loads.  A wave-private LDS row puts the results back into 4-px-per-lane order for
   // the 16-byte store.  Same samples, same arithmetic: identical results.
-  // (map-based remaps only: the analytic coordinate sources measured 13 % slower this way)
-  constexpr bool kIlv = !FIXED && sizeof(DT) == 4 && INTERP != kLanczos4 &&
-                        std::is_same<Coord, MapCoord>::value;
+  // (map-based remaps only: the analytic coordinate sources measured 3-13 % slower this way)
+  constexpr bool kIlv = !FIXED && sizeof(DT) == 4 && std::is_same<Coord, MapCoord>::value;
   if constexpr (kIlv) {
     __shared__ __attribute__((aligned(16))) DT xpose[4][256];
     const int xw = (int)(txi * 256u);  // wave-uniform (threadIdx.y = wave)
