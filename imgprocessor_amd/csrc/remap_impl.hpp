@@ -103,6 +103,13 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     frame = t % (unsigned)p.frames_inner;
     t /= (unsigned)p.frames_inner;
   }
+  // Lanczos4: the 32 x 8 weight table is read four float4 per sample - from LDS, not through
+  // the vector-memory path the 16 tap-row gathers of the sample already load
+  __shared__ __attribute__((aligned(16))) float lz_tab[INTERP == kLanczos4 ? 256 : 4];
+  if constexpr (INTERP == kLanczos4) {
+    lz_tab[threadIdx.y * 64 + threadIdx.x] = p.lanczos[threadIdx.y * 64 + threadIdx.x];
+    __syncthreads();
+  }
   unsigned tyi = t / p.tiles_x, txi = t - tyi * p.tiles_x;
   int x0 = (int)((txi * 64 + threadIdx.x) * 4);
   int y = (int)(tyi * 4 + threadIdx.y);
@@ -112,7 +119,8 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   SrcView s;
   s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
   s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
-  s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a; s.lanczos = p.lanczos;
+  s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a;
+  s.lanczos = INTERP == kLanczos4 ? lz_tab : p.lanczos;
 
   // Row segments that lie wholly inside the output row sample in LANE-INTERLEAVED order
   // (footprint k of lane L = segment pixel L + 64 k): the 64 gathers of one instruction then
