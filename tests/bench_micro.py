@@ -1,6 +1,11 @@
 """micro-benchmark helper (GPU box): times single entry points with HIP events.
 
-    python tests/bench_micro.py conv|copy|strip|remap|fused
+    python tests/bench_micro.py conv|copy|strip|remap|configs|stencils|host|pipeline
+
+conv / remap / strip: the filter, remap and fused kernels on 16 x 4K float32 frames
+(IPA_STRIP_H, IPA_FRAMES_INNER, IMGPROC_HIP_LIB select variants); configs: the BASELINE
+configurations C3..C5 kernel-only; stencils: the secondary stencils on one 4K frame;
+host / pipeline: PCIe-inclusive host-to-host paths.  Results: profiles/r01_micro.txt.
 """
 import os
 import sys
