@@ -131,7 +131,12 @@ struct LoadRowSrc {
 #define IPA_LOAD_DEPTH 8
 #endif
   // K = 7 holds 9 window pairs + 14 sum pairs per lane: a shallow chunk keeps occupancy 5
-  template <int K> struct depth { static constexpr int value = K >= 7 ? 2 : IPA_LOAD_DEPTH; };
+#ifndef IPA_K7_DEPTH
+#define IPA_K7_DEPTH 2
+#endif
+  template <int K> struct depth {
+    static constexpr int value = K >= 7 ? IPA_K7_DEPTH : IPA_LOAD_DEPTH;
+  };
   template <int D> struct Chunk { float v[D][4]; };
   const float* base;   // frame 0
   long frame_elems, pitch;
