@@ -92,6 +92,40 @@ local_std_kernel(const T* __restrict__ img, const T* __restrict__ blurred, int g
   out[(long)i * opitch + j] = (T)sqrt(val / npx);
 }
 
+// The same reduction with the (4 + 2 hkx) x (64 + 2 hky) source window of a 64 x 4 output block
+// staged in LDS; the loops still visit exactly the clipped window, in the same order.
+template <typename T>
+__global__ void __launch_bounds__(256)
+local_std_tile_kernel(const T* __restrict__ img, const T* __restrict__ blurred, int gx, int gy,
+                      long pitch, long bpitch, int hkx, int hky, T* __restrict__ out,
+                      long opitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char std_lds[];
+  T* tile = reinterpret_cast<T*>(std_lds);
+  const int tw = 64 + 2 * hky, th = 4 + 2 * hkx;
+  const int j0 = blockIdx.x * 64 - hky, i0 = blockIdx.y * 4 - hkx;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int e = tid; e < tw * th; e += 256) {
+    const int ty = e / tw, tx = e - ty * tw;
+    int ii = i0 + ty, jj = j0 + tx;
+    ii = ii < 0 ? 0 : (ii >= gx ? gx - 1 : ii);  // outside the image: never read back
+    jj = jj < 0 ? 0 : (jj >= gy ? gy - 1 : jj);
+    tile[e] = img[(long)ii * pitch + jj];
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= gx || j >= gy) return;
+  int xmn = i - hkx < 0 ? 0 : i - hkx, xmx = i + hkx > gx ? gx : i + hkx;
+  int ymn = j - hky < 0 ? 0 : j - hky, ymx = j + hky > gy ? gy : j + hky;
+  double mean = (double)blurred[(long)i * bpitch + j], val = 0.0;
+  for (int ii = xmn; ii < xmx; ii++)
+    for (int jj = ymn; jj < ymx; jj++) {
+      double d = (double)tile[(ii - i0) * tw + (jj - j0)] - mean;
+      val += d * d;
+    }
+  double npx = (double)((xmx - xmn - 1) * (ymx - ymn - 1));
+  out[(long)i * opitch + j] = (T)sqrt(val / npx);
+}
+
 // filters/maskedFilter.py:43-72 (_calcMean).  FILL: pixels with mask != 0 get the mean of the
 // mask == 0 pixels in the clipped window (left untouched when there are none) — dst may be
 // src, written pixels are never read.  !FILL: pixels with mask == 0 get that mean, the others
@@ -668,7 +702,18 @@ int ipa_local_std_dev(ipa_ctx* ctx, const void* d_img, const void* d_blurred, in
     IPA_UNSUPPORTED(ctx, "local_std supports float32/float64 (got dtype %d)", dtype);
   dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (dtype == IPA_F32)
+  const int hkx = ksize_x / 2, hky = ksize_y / 2;
+  const size_t lds = (size_t)(64 + 2 * hky) * (4 + 2 * hkx) * (dtype == IPA_F32 ? 4 : 8);
+  if (lds <= 48 * 1024) {  // the block's window fits in LDS: staged version
+    if (dtype == IPA_F32)
+      hipLaunchKernelGGL((local_std_tile_kernel<float>), grid, block, lds, ctx->stream,
+                         (const float*)d_img, (const float*)d_blurred, h, w, pitch, blurred_pitch,
+                         hkx, hky, (float*)d_out, out_pitch);
+    else
+      hipLaunchKernelGGL((local_std_tile_kernel<double>), grid, block, lds, ctx->stream,
+                         (const double*)d_img, (const double*)d_blurred, h, w, pitch,
+                         blurred_pitch, hkx, hky, (double*)d_out, out_pitch);
+  } else if (dtype == IPA_F32)
     hipLaunchKernelGGL((local_std_kernel<float>), grid, block, 0, ctx->stream, (const float*)d_img,
                        (const float*)d_blurred, h, w, pitch, blurred_pitch, ksize_x / 2,
                        ksize_y / 2, (float*)d_out, out_pitch);
