@@ -126,8 +126,11 @@ def pmc_traffic(variant, batch, h, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    # defaults: ~0.5 s of device work.  Short runs under-report by ~10 %: the GPU clocks are
+    # still ramping up from idle during the first ~100 ms (20 steps: 0.445 ms/step, 200: 0.407,
+    # 2000: 0.403 on the same box)
+    ap.add_argument('--steps', type=int, default=1000)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--batch', type=int, default=16, help='4K frames per step per GPU')
     ap.add_argument('--variant', default='fused_map',
                     choices=['fused_map', 'fused_analytic', 'two_kernel', 'two_kernel_analytic'])
