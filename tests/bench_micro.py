@@ -18,6 +18,9 @@ from imgprocessor_amd import ops  # noqa: E402
 
 
 def timeit(ctx, fn, n=10, warm=2):
+    # IPA_MICRO_SCALE=30 times 30x more launches after 30x more warm-up: steady-state clocks
+    scale = int(os.environ.get('IPA_MICRO_SCALE', '1'))
+    n, warm = n * scale, warm * scale
     for _ in range(warm):
         fn()
     ctx.synchronize()
