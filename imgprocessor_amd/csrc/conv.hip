@@ -52,17 +52,27 @@ __device__ __forceinline__ void fill_tile_global(T* __restrict__ tile, const T* 
   const int wave = tid >> 6;
   const int lane = tid & 63;
   const T cval = (T)p.cval;
-  // one tile row per wave per trip (measured faster on MI355X than dealing the
-  // tile's chunks linearly over all 256 lanes with every load issued up front:
-  // 312 vs 421 us for 16 4K frames, 5x5)
-  for (int lr = wave; lr < ROWS; lr += 4) {
-    int yy = resolve_idx(y0 - KH / 2 + lr, p.h, p.by);
+  // One tile row per wave per trip; the trips are unrolled and the LDS writes follow the loads
+  // of all rows, so the scheduler keeps several row loads in flight (9x9: 436 -> 386 us for
+  // 16 4K frames).  Measured slower: a branch-free variant with every load issued strictly up
+  // front (681 us), and dealing the tile's chunks linearly over all 256 lanes (421 vs 312 us,
+  // 5x5).
+  constexpr int NR = (ROWS + 3) / 4;          // rows per wave
+  constexpr int NC = (CHUNKS + 63) / 64;      // 16-byte chunks per lane and row
+  V v[NR][NC];
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int lr = wave + 4 * q;
+    if (lr >= ROWS) break;
+    const int yy = resolve_idx(y0 - KH / 2 + lr, p.h, p.by);
     const T* srow = src + (long)(yy < 0 ? 0 : yy) * p.spitch;
-    for (int c = lane; c < CHUNKS; c += 64) {
-      int gx = x0 - G::HX + c * VN;
-      V v;
+#pragma unroll
+    for (int cc = 0; cc < NC; cc++) {
+      const int c = lane + 64 * cc;
+      if (c >= CHUNKS) break;
+      const int gx = x0 - G::HX + c * VN;
       if (yy >= 0 && p.vec_in && gx >= 0 && gx + VN <= p.w) {
-        v = *reinterpret_cast<const V*>(srow + gx);
+        v[q][cc] = *reinterpret_cast<const V*>(srow + gx);
       } else {
         T e[VN];
 #pragma unroll
@@ -70,10 +80,20 @@ __device__ __forceinline__ void fill_tile_global(T* __restrict__ tile, const T* 
           int xx = resolve_idx(gx + k, p.w, p.bx);
           e[k] = (yy < 0 || xx < 0) ? cval : srow[xx];
         }
-        if constexpr (VN == 4) v = V{e[0], e[1], e[2], e[3]};
-        else v = V{e[0], e[1]};
+        if constexpr (VN == 4) v[q][cc] = V{e[0], e[1], e[2], e[3]};
+        else v[q][cc] = V{e[0], e[1]};
       }
-      *reinterpret_cast<V*>(tile + lr * G::LW + c * VN) = v;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NR; q++) {
+    const int lr = wave + 4 * q;
+    if (lr >= ROWS) break;
+#pragma unroll
+    for (int cc = 0; cc < NC; cc++) {
+      const int c = lane + 64 * cc;
+      if (c >= CHUNKS) break;
+      *reinterpret_cast<V*>(tile + lr * G::LW + c * VN) = v[q][cc];
     }
   }
 }
