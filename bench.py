@@ -137,6 +137,8 @@ def main():
     ap.add_argument('--height', type=int, default=H4K)
     ap.add_argument('--width', type=int, default=W4K)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
+    ap.add_argument('--no-settle', action='store_true',
+                    help='skip the untimed clock-settling launches of the setup phase')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -198,6 +200,14 @@ def main():
             ops.conv2d(d_tmp, k5, out=d_dst)
         bytes_per_px, launches, kname = 16, 2, 'remap_kernel<float,float,linear,UndistortCoord> + wave_stencil_kernel<LoadRowSrc,5>'
 
+    # Setup, not measurement: let the GPU clocks settle.  From idle they ramp up over the first
+    # ~100 ms of load; a short run (e.g. --steps 20 --warmup 3) would otherwise time the ramp
+    # (0.445 vs 0.403 ms/step).  Reported as config.clock_settle_launches.
+    settle = 0 if args.no_settle else 300
+    for _ in range(settle):
+        step()
+    ctx.synchronize()
+
     for _ in range(args.warmup):
         step()
     ctx.synchronize()
@@ -227,6 +237,7 @@ def main():
                                    'border) + 5x5 Gaussian (reflect), %d frames/step/GPU, '
                                    'variant=%s' % (w, h, B, args.variant),
                        'frames_per_step_per_gpu': B, 'variant': args.variant,
+                       'clock_settle_launches': settle,
                        'sharding': 'independent frames, %d rank(s), no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
