@@ -172,7 +172,10 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+    for (int k = 0; k < 4; k++) {
+      c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+      c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
+    }
     wave_sep_strip<false, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
   }
 }

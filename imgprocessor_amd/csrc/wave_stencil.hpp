@@ -114,6 +114,7 @@ struct Cols {
   int xs;       // first column of the strip (lane 0) - wave-uniform, lives in an SGPR
   int xo;       // first column of the lane = xs + 4*lane (may be < 0 or >= dw at the rim)
   int uu[4];    // border-resolved column per pixel, -1 = constant border
+  int uq[4];    // the same for the lane-interleaved pixels xs + lane + 64 k (sampling sources)
 };
 
 // ---------------------------------------------------------------- row sources --
@@ -210,10 +211,11 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
   }
   __device__ __forceinline__ bool vectors_ok() const { return !kMap || map_vec != 0; }
 
-  // FAST strips sample in LANE-INTERLEAVED order: footprint k of lane L is strip pixel
-  // L + 64 k, so the 64 gathers of one instruction walk along the source row (neighbouring
-  // lanes hit the same cache lines) instead of striding 4 px; stage_rows writes the blended
-  // samples to the wave's LDS row at their pixel positions.
+  // Strips sample in LANE-INTERLEAVED order: footprint k of lane L is strip pixel L + 64 k,
+  // so the 64 gathers of one instruction walk along the source row (neighbouring lanes hit
+  // the same cache lines) instead of striding 4 px; stage_rows writes the blended samples to
+  // the wave's LDS row at their pixel positions.  Rim strips do the same through the
+  // border-resolved columns c.uq (a constant filter border substitutes its value afterwards).
   template <bool FAST>
   __device__ __forceinline__ void coords_of_row(const Cols& c, int vv, C (&sx)[4],
                                                 C (&sy)[4]) const {
@@ -221,7 +223,7 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if constexpr (FAST) coord.get(c.xs + lane + 64 * k, vv, sx[k], sy[k]);
-      else coord.get(c.uu[k] < 0 ? 0 : c.uu[k], vv < 0 ? 0 : vv, sx[k], sy[k]);
+      else coord.get(c.uq[k] < 0 ? 0 : c.uq[k], vv < 0 ? 0 : vv, sx[k], sy[k]);
     }
   }
 
@@ -242,6 +244,19 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
         for (int k = 0; k < 4; k++) {
           sx[d][k] = rx[lane + 64u * k];
           sy[d][k] = ry[lane + 64u * k];
+        }
+      }
+    } else if constexpr (kMap) {
+      // rim strips: the same interleaved dword loads through the resolved columns
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const float* rx = coord.mx + (long)(vv[d] < 0 ? 0 : vv[d]) * coord.pitch;  // scalar
+        const float* ry = coord.my + (long)(vv[d] < 0 ? 0 : vv[d]) * coord.pitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned u = (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]);
+          sx[d][k] = rx[u];
+          sy[d][k] = ry[u];
         }
       }
     } else {
@@ -273,14 +288,13 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
             cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
       }
       float* row = xp + d * kRowStride + kRowPad;
-      if constexpr (FAST) {  // lane-interleaved samples: pixel L + 64 k
+      // lane-interleaved samples: pixel L + 64 k
+      if constexpr (!FAST) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) row[64u * k + lane] = cur[k];
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) cur[k] = (vv[d] < 0 || c.uu[k] < 0) ? ccval : cur[k];
-        *reinterpret_cast<float4*>(row + 4u * lane) = float4{cur[0], cur[1], cur[2], cur[3]};
+        for (int k = 0; k < 4; k++) cur[k] = (vv[d] < 0 || c.uq[k] < 0) ? ccval : cur[k];
       }
+#pragma unroll
+      for (int k = 0; k < 4; k++) row[64u * k + lane] = cur[k];
     }
   }
 };
@@ -445,7 +459,10 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+    for (int k = 0; k < 4; k++) {
+      c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
+      c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
+    }
     wave_run_strip<false, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst);
   }
 }
