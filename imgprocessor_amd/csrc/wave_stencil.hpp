@@ -38,7 +38,9 @@
 //         coordinate rule (exact / 1/32-px) is a compile-time parameter here;
 //   rim   strips touching the image border: columns / rows are resolved
 //         through the FILTER's border mode (per lane once, per row on the
-//         scalar unit), element accesses with selects instead of branches.
+//         scalar unit), element accesses with selects instead of branches.  The
+//         sampling source keeps its lane-interleaved order here too (resolved
+//         columns Cols::uq): 15 % of a 4K frame's strips are rim strips.
 //
 // Dispatch order: the frames of one strip block are neighbours in the
 // XCD-contiguous block order (wave_grid / frames_inner), so a batch's frames
