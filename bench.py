@@ -5,9 +5,10 @@
 
 A "step" is one pass of the hot path (LensDistortion-style undistort, bilinear,
 BORDER_CONSTANT, then a 5x5 Gaussian given as an explicit kernel, 'reflect'
-border) over one batch of synthetic 4K (3840x2160) float32 frames that are
-already resident in HBM.  The batch is larger than the 256 MiB Infinity Cache,
-so source and destination really stream from/to HBM.
+border) over one batch of synthetic 4K (3840x2160) float32 frames (128 by
+default: 4.2 GB in, 4.2 GB out) that are already resident in HBM.  The batch
+is far larger than the 256 MiB Infinity Cache, so source and destination
+really stream from/to HBM.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); frames
 are independent, every rank processes its own batch (weak scaling), no
@@ -38,9 +39,13 @@ def synth_frames(n, h, w, seed0=0):
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
     base = 0.5 + 0.25 * np.sin(2 * np.pi * x / 97) + 0.25 * np.cos(2 * np.pi * y / 61)
     out = np.empty((n, h, w), np.float32)
+    # 16 seeded noise fields; frame i takes field i % 16 shifted by 37 columns per reuse, so
+    # every frame of a large batch is distinct without drawing 8 Mpx of normals per frame
+    fields = [np.random.default_rng(seed0 + j).standard_normal((h, w), dtype=np.float32)
+              for j in range(min(n, 16))]
     for i in range(n):
-        rng = np.random.default_rng(seed0 + i)
-        out[i] = np.clip(base + 0.05 * rng.standard_normal((h, w), dtype=np.float32), 0, 1)
+        noise = np.roll(fields[i % 16], 37 * (i // 16), axis=1)
+        out[i] = np.clip(base + 0.05 * noise, 0, 1)
     return out
 
 
@@ -126,12 +131,15 @@ def pmc_traffic(variant, batch, h, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults: ~0.5 s of device work.  Short runs under-report by ~10 %: the GPU clocks are
-    # still ramping up from idle during the first ~100 ms (20 steps: 0.445 ms/step, 200: 0.407,
-    # 2000: 0.403 on the same box)
-    ap.add_argument('--steps', type=int, default=1000)
-    ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--batch', type=int, default=16, help='4K frames per step per GPU')
+    # defaults: ~0.6 s of timed device work.  Very short runs under-report by ~10 %: the GPU
+    # clocks are still ramping up from idle during the first ~100 ms of load (16-frame launches,
+    # 20 steps: 0.445 ms/step, 200: 0.407, 2000: 0.403 on the same box)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    # 128 frames = 4.2 GB in + 4.2 GB out of the 288 GB: launches of 16 / 32-64 / 128 frames reach
+    # 0.67 / 0.70 / 0.72-0.77 of the HBM peak (the per-launch ramp and drain
+    # and the map rows are shared by more frames)
+    ap.add_argument('--batch', type=int, default=128, help='4K frames per step per GPU')
     ap.add_argument('--variant', default='fused_map',
                     choices=['fused_map', 'fused_analytic', 'two_kernel', 'two_kernel_analytic'])
     ap.add_argument('--height', type=int, default=H4K)
@@ -203,7 +211,7 @@ def main():
     # Setup, not measurement: let the GPU clocks settle.  From idle they ramp up over the first
     # ~100 ms of load; a short run (e.g. --steps 20 --warmup 3) would otherwise time the ramp
     # (0.445 vs 0.403 ms/step).  Reported as config.clock_settle_launches.
-    settle = 0 if args.no_settle else 300
+    settle = 0 if args.no_settle else max(20, 4800 // B)
     for _ in range(settle):
         step()
     ctx.synchronize()

@@ -476,15 +476,17 @@ static inline int wave_strip_height(int dh, int dw, int n_frames, int K) {
     if (atoi(e) > 0) return atoi(e);
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
   long sx = (dw + ow - 1) / ow;
-  // measured on 16 x 4K frames (MI355X): 16-32 rows best, 64 within 3 %, 128+ and 8 clearly
-  // slower -> 32 rows when that still gives >= 8192 waves, else shorter strips
-  int best = 8;
-  for (int sh : {32, 16, 8}) {
-    long waves = sx * ((dh + sh - 1) / sh) * n_frames;
-    best = sh;
-    if (waves >= 8192) break;
+  // measured on 4K frames (MI355X, 4096 resident waves): with 16 frames 16-48 rows are within
+  // noise of each other and 8 / 128+ clearly slower; with 64-128 frames per launch 48 rows
+  // beat 32 by 2.3 % and 72 by 2.9 % (fewer halo rows sampled per output row), 90-135 fall
+  // back -> the tallest strip that still leaves about 6 / 4 / 2 rounds of waves
+  const int cand[5] = {72, 48, 32, 16, 8};
+  const long need[5] = {24576, 16384, 8192, 8192, 0};
+  for (int i = 0; i < 5; i++) {
+    long waves = sx * ((dh + cand[i] - 1) / cand[i]) * n_frames;
+    if (waves >= need[i]) return cand[i];
   }
-  return best;
+  return 8;
 }
 
 }  // namespace ipa
