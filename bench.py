@@ -39,13 +39,13 @@ def synth_frames(n, h, w, seed0=0):
     y, x = np.mgrid[0:h, 0:w].astype(np.float32)
     base = 0.5 + 0.25 * np.sin(2 * np.pi * x / 97) + 0.25 * np.cos(2 * np.pi * y / 61)
     out = np.empty((n, h, w), np.float32)
-    # 16 seeded noise fields; frame i takes field i % 16 shifted by 37 columns per reuse, so
-    # every frame of a large batch is distinct without drawing 8 Mpx of normals per frame
-    fields = [np.random.default_rng(seed0 + j).standard_normal((h, w), dtype=np.float32)
-              for j in range(min(n, 16))]
-    for i in range(n):
-        noise = np.roll(fields[i % 16], 37 * (i // 16), axis=1)
-        out[i] = np.clip(base + 0.05 * noise, 0, 1)
+    # 16 seeded frames; frame i >= 16 is frame i % 16 rolled down by 37 rows per reuse, so every
+    # frame of a large batch is distinct without drawing 8 Mpx of normals for each
+    for i in range(min(n, 16)):
+        rng = np.random.default_rng(seed0 + i)
+        out[i] = np.clip(base + 0.05 * rng.standard_normal((h, w), dtype=np.float32), 0, 1)
+    for i in range(16, n):
+        out[i] = np.roll(out[i % 16], 37 * (i // 16), axis=0)
     return out
 
 
