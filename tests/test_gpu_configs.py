@@ -328,6 +328,41 @@ def test_strip_geometry_sweep(ia, orc):
             close32(got[i], orc.conv2d(batch[i], k), 'batch conv %d' % i)
 
 
+def test_tall_strips_of_large_launches(ia, orc):
+    """launches of many frames march in 48- and 72-row strips (wave_strip_height); the same
+    geometry forced on small frames through the library's IPA_STRIP_H knob, against the oracle"""
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(23)
+    try:
+        for sh in (48, 72):
+            os.environ['IPA_STRIP_H'] = str(sh)
+            for n, (h, w) in enumerate(((sh - 1, 249), (sh, 505), (sh + 1, 256), (2 * sh + 3, 760))):
+                img = synth((h, w), 70 + n)
+                ksz = (3, 5, 7)[n % 3]
+                k = rng.random((ksz, ksz))
+                k /= k.sum()
+                g = rng.random(ksz)
+                g /= g.sum()
+                mode = ('reflect', 'constant', 'wrap', 'nearest')[n]
+                close32(ia.ops.conv2d(img, k, mode, 0.25), orc.conv2d(img, k, mode, 0.25),
+                        'conv strip %d %dx%d' % (sh, h, w))
+                close32(ia.ops.sepconv2d(img, g, g, mode, 0.25), orc.sepconv2d(img, g, g, mode, 0.25),
+                        'sep strip %d %dx%d' % (sh, h, w))
+                yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+                mx = (xx + 1.7 * np.sin(yy / 9 + 0.3) - 0.4).astype(np.float32)
+                my = (yy + 1.3 * np.cos(xx / 11) + 0.2).astype(np.float32)
+                want_r = orc.remap(img, mx, my, orc.LINEAR, orc.CONSTANT, 0.1)
+                d_img, dmx, dmy = ctx.to_device(img), ctx.to_device(mx), ctx.to_device(my)
+                close32(ia.ops.remap_conv2d(d_img, dmx, dmy, k, 'linear', 'constant', 0.1,
+                                            mode).get(),
+                        orc.conv2d(want_r, k, mode), 'fused strip %d %dx%d' % (sh, h, w))
+                close32(ia.ops.remap_sepconv2d(d_img, dmx, dmy, g, g, 'linear', 'constant', 0.1,
+                                               mode).get(),
+                        orc.sepconv2d(want_r, g, g, mode), 'fused sep strip %d %dx%d' % (sh, h, w))
+    finally:
+        os.environ.pop('IPA_STRIP_H', None)
+
+
 def test_single_frame_row_bands(ia, orc):
     """C5 alternative: one frame split into output row bands, one band per GPU,
     no collective — the concatenated bands equal the whole-frame chain bit for bit"""
