@@ -19,6 +19,8 @@
 int ipa_wave_conv_launch_k3(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
 int ipa_wave_conv_launch_k5(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
 int ipa_wave_conv_launch_k7(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
+int ipa_wave_conv_launch_k9(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
+int ipa_wave_conv_launch_k11(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double*, int);
 // float32 separable K+K filter on the same skeleton (wave_sep.hip); returns 1 if not covered
 int ipa_wave_sep_launch(ipa_ctx*, const ipa::WaveParams&, const ipa::LoadRowSrc&, const double* ky,
                         int nky, const double* kx, int nkx, int n_frames, float xcval);
@@ -358,8 +360,10 @@ static int conv_typed(ipa_ctx* ctx, ConvParams& p, const double* kernel, int kh,
   if (fast && sizeof(T) == 8 && kh > 7) fast = false;  // f64: tuned path instantiated to 7x7
   if constexpr (sizeof(T) == 4) {
     // float32: the wave-marching stencil (wave_stencil.hpp)
-    // (masked filtering and K >= 9 stay on the LDS-tiled kernel, which is faster there)
-    if (fast && kh <= 7 && !p.mask) {
+    // (masked filtering stays on the LDS-tiled kernel; so do 9x9 / 11x11 with IPA_BIG_WAVE=0,
+    // the tuning knob that A/Bs wave_conv_big.hip against it: 334 vs 375 us, 428 vs 487 us)
+    static const bool big_wave = !(getenv("IPA_BIG_WAVE") && atoi(getenv("IPA_BIG_WAVE")) == 0);
+    if (fast && (kh <= 7 || big_wave) && !p.mask) {
       WaveParams wp;
       wp.dst = p.dst; wp.dst_frame_elems = p.dst_frame_elems;
       wp.dh = p.h; wp.dw = p.w; wp.dpitch = p.dpitch;
@@ -371,7 +375,9 @@ static int conv_typed(ipa_ctx* ctx, ConvParams& p, const double* kernel, int kh,
       switch (kh) {
         case 3: ipa_wave_conv_launch_k3(ctx, wp, src, kernel, n_frames); break;
         case 5: ipa_wave_conv_launch_k5(ctx, wp, src, kernel, n_frames); break;
-        default: ipa_wave_conv_launch_k7(ctx, wp, src, kernel, n_frames); break;
+        case 7: ipa_wave_conv_launch_k7(ctx, wp, src, kernel, n_frames); break;
+        case 9: ipa_wave_conv_launch_k9(ctx, wp, src, kernel, n_frames); break;
+        default: ipa_wave_conv_launch_k11(ctx, wp, src, kernel, n_frames); break;
       }
       IPA_HIP(ctx, hipGetLastError());
       return IPA_OK;

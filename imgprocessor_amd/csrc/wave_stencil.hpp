@@ -310,13 +310,19 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 // unchanged (rows i, taps j ascending).
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// Coefficients: K <= 7 keeps all K*K in SGPRs (kernel arguments loaded once).  81 / 121 do not
+// fit the scalar register file; wave_stencil_big_kernel re-reads them for every input row from
+// its kernel-argument segment, one kernel row (12 SGPRs) at a time (`wk` = the padded rows of
+// WaveBigArgs; the scalar cache serves them and the scalar unit is idle anyway).
+typedef const float __attribute__((address_space(4)))* kernarg_f32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
 template <bool FAST, typename Src, int K, int QM = -1>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                    const Weights<float, K * K>& wts, float* xp,
                                                    const Cols& c, int y0, int nrows, bool writer,
-                                                   float* dst) {
+                                                   float* dst, kernarg_f32 wk = nullptr) {
   using G = wave_geom<K>;
-  static_assert(K <= 7, "coefficients live in SGPRs");
   constexpr int D = Src::template depth<K>::value;
   const int T = nrows + K - 1;  // input rows of this strip
   const unsigned lane = threadIdx.x & 63u;
@@ -352,11 +358,44 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #pragma unroll
       for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
 
+      // K > 7: kernel row i (padded to 12 floats, 16-byte aligned) arrives in 12 SGPRs while
+      // row i + 1 is being accumulated: load(i - 1) is issued before the fmas of row i, the
+      // wait for it stands in front of the fmas of row i - 1.  The asm statements carry the
+      // running sums as in/out operands, which pins them between the fma groups (left to the
+      // compiler, all K*K scalar loads are issued up front and spilled to VGPR lanes).
+#define IPA_LOAD_COEF_ROW(r)                                                                  \
+  asm volatile("s_load_dwordx4 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\t"                    \
+               "s_load_dwordx4 %2, %3, %6"                                                     \
+               : "=&s"(cc[r][0]), "=&s"(cc[r][1]), "=&s"(cc[r][2])                             \
+               : "s"(wk), "n"((r) * 48), "n"((r) * 48 + 16), "n"((r) * 48 + 32))
+      v4f cc[K][3];
+      if constexpr (K > 7) IPA_LOAD_COEF_ROW(K - 1);
+#undef IPA_LOAD_COEF_ROW
+
       static_for<0, K>([&](auto Ii) {
         constexpr int i = K - 1 - decltype(Ii)::value;
+        if constexpr (K > 7) {
+          if constexpr (i == K - 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]));
+          else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]), "+v"(acc[i + 1][0]),
+                           "+v"(acc[i + 1][1]));
+          if constexpr (i > 0) {
+            // in front of row i's fmas (they read acc[i - 1]): a row of fmas covers the latency
+            asm volatile("s_load_dwordx4 %0, %5, %6\n\ts_load_dwordx4 %1, %5, %7\n\t"
+                         "s_load_dwordx4 %2, %5, %8"
+                         : "=&s"(cc[i - 1][0]), "=&s"(cc[i - 1][1]), "=&s"(cc[i - 1][2]),
+                           "+v"(acc[i - 1][0]), "+v"(acc[i - 1][1])
+                         : "s"(wk), "n"((i - 1) * 48), "n"((i - 1) * 48 + 16),
+                           "n"((i - 1) * 48 + 32));
+          }
+        }
 #pragma unroll
         for (int j = 0; j < K; j++) {
-          const float w = wts.w[i * K + j];
+          float w;
+          if constexpr (K > 7) w = cc[i][j >> 2][j & 3];
+          else w = wts.w[i * K + j];
           const v2f w2 = v2f{w, w};
 #pragma unroll
           for (int h = 0; h < 2; h++) {
@@ -369,6 +408,8 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
             }
           }
         }
+        // keep the next kernel row's scalar loads below this row's fmas
+        if constexpr (K > 7) __builtin_amdgcn_sched_barrier(0);
       });
 
       // output row t - (K-1) is complete
@@ -406,12 +447,13 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #ifndef IPA_WAVE_MIN_WAVES
 #define IPA_WAVE_MIN_WAVES 1
 #endif
-template <typename Src, int K>
 #ifndef IPA_WPB
 #define IPA_WPB 4   // waves per workgroup
 #endif
-__global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
-wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
+template <typename Src, int K>
+__device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
+                                                  const Weights<float, K * K>& wts,
+                                                  kernarg_f32 wk) {
   using G = wave_geom<K>;
   constexpr int D = Src::template depth<K>::value;
   const int lane = threadIdx.x & 63;
@@ -429,8 +471,10 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned sid = b * IPA_WPB + wave;
   constexpr int kXp = kRowStride * D;  // LDS floats per wave
-  __shared__ __attribute__((aligned(16))) float xpose[IPA_WPB * kXp];
-  float* xp = xpose + wave * kXp;
+  // the windows of lane 0 start H px left of the row: H - kRowPad floats of lead-in for K = 11
+  constexpr int kLead = G::H > kRowPad ? 4 : 0;
+  __shared__ __attribute__((aligned(16))) float xpose[kLead + IPA_WPB * kXp + kLead];
+  float* xp = xpose + kLead + wave * kXp;
   if (sid >= p.strips) return;  // whole wave
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
   src.set_frame(frame);
@@ -454,10 +498,10 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
     if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
-      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst);
-      else wave_run_strip<true, Src, K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst);
+      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+      else wave_run_strip<true, Src, K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
     } else {
-      wave_run_strip<true, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst);
+      wave_run_strip<true, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
     }
   } else {
 #pragma unroll
@@ -465,13 +509,38 @@ wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
     }
-    wave_run_strip<false, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst);
+    wave_run_strip<false, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
   }
+}
+
+template <typename Src, int K>
+__global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
+wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
+  wave_stencil_body<Src, K>(p, src, wts, nullptr);
+}
+
+// K = 9, 11: one argument struct, so that the coefficients' place in the kernel-argument
+// segment is offsetof(WaveBigArgs, wts) whatever the argument layout rules are
+template <typename Src, int K> struct WaveBigArgs {
+  WaveParams p;
+  Src src;
+  alignas(16) float wrows[K][12];  // kernel row i, taps 0..K-1, zero padded
+};
+template <typename Src, int K>
+__global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
+wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
+  static_assert(K > 7 && K <= 12, "padded coefficient rows of 12");
+  typedef const char __attribute__((address_space(4)))* kernarg_bytes;
+  kernarg_bytes base = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
+  using Args = WaveBigArgs<Src, K>;
+  kernarg_f32 wk = (kernarg_f32)(base + offsetof(Args, wrows));
+  Weights<float, K * K> unused;  // the K <= 7 form of the coefficients, never read here
+  wave_stencil_body<Src, K>(a.p, a.src, unused, wk);
 }
 
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
 // problems enough waves to fill 256 CUs
-static inline int wave_strip_height(int dh, int dw, int n_frames, int K) {
+static inline int wave_strip_height(int dh, int dw, int n_frames, int K, bool fma_bound = false) {
   if (const char* e = getenv("IPA_STRIP_H"))  // tuning knob (tests/bench_micro.py strip)
     if (atoi(e) > 0) return atoi(e);
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
@@ -480,8 +549,10 @@ static inline int wave_strip_height(int dh, int dw, int n_frames, int K) {
   // noise of each other and 8 / 128+ clearly slower; with 64-128 frames per launch 48 rows
   // beat 32 by 2.3 % and 72 by 2.9 % (fewer halo rows sampled per output row), 90-135 fall
   // back -> the tallest strip that still leaves about 6 / 4 / 2 rounds of waves
-  const int cand[5] = {72, 48, 32, 16, 8};
-  const long need[5] = {24576, 16384, 8192, 8192, 0};
+  // 9x9 / 11x11 are bound by their K*K fmas per sample, halo rows included: 64 rows as soon
+  // as they give two rounds of waves (16 x 4K: 11x11 461 -> 428 us, 9x9 334 -> 322)
+  const int cand[5] = {fma_bound ? 64 : 72, 48, 32, 16, 8};
+  const long need[5] = {fma_bound ? 8192 : 24576, fma_bound ? 8192 : 16384, 8192, 8192, 0};
   for (int i = 0; i < 5; i++) {
     long waves = sx * ((dh + cand[i] - 1) / cand[i]) * n_frames;
     if (waves >= need[i]) return cand[i];

@@ -334,11 +334,11 @@ def test_tall_strips_of_large_launches(ia, orc):
     ctx = ia.default_context(0)
     rng = np.random.default_rng(23)
     try:
-        for sh in (48, 72):
+        for sh in (48, 64, 72):
             os.environ['IPA_STRIP_H'] = str(sh)
             for n, (h, w) in enumerate(((sh - 1, 249), (sh, 505), (sh + 1, 256), (2 * sh + 3, 760))):
                 img = synth((h, w), 70 + n)
-                ksz = (3, 5, 7)[n % 3]
+                ksz = {48: (3, 5, 7, 9), 64: (9, 11, 9, 11), 72: (7, 3, 5, 11)}[sh][n]
                 k = rng.random((ksz, ksz))
                 k /= k.sum()
                 g = rng.random(ksz)
