@@ -10,6 +10,7 @@ void ipa_fused_sep_launch_b(ipa_ctx*, const FusedCall&, const FusedSep&);  // 7,
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
+int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
 static int inv3f(const double* m, double* o) {
@@ -24,9 +25,10 @@ static int inv3f(const double* m, double* o) {
   return 0;
 }
 
-// K >= 9: the register-resident wave stencil does not fit (81 / 121 coefficients
-// + 9 / 11 running rows); run the chain as two launches through the context
-// workspace: remap kernel -> LDS-tiled filter.
+// K = 9, 11: map-based bilinear remaps of float32 frames run in one kernel (fused_big.hip);
+// for the rest (bicubic, analytic coordinates, uint16 frames) the sampling source plus 9 / 11
+// running rows exceed the VGPR budget that pays: the chain runs as two launches through the
+// context workspace: remap kernel -> 9x9 / 11x11 filter.
 static int big_kernel_tmp(ipa_ctx* ctx, int kh, int kw, int dst_dtype, int dh, int dw, int n_frames,
                           void** tmp) {
   if (kh != kw || !(kh == 9 || kh == 11)) return 1;  // not the two-launch case
@@ -229,6 +231,27 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
                          int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  // 9x9 / 11x11 on float32 frames: one kernel (fused_big.hip); IPA_BIG_FUSED=0 is the tuning
+  // knob that sends them through the two launches below instead
+  static const bool big_fused = !(getenv("IPA_BIG_FUSED") && atoi(getenv("IPA_BIG_FUSED")) == 0);
+  if (big_fused && kh == kw && (kh == 9 || kh == 11) && src_dtype == IPA_F32 &&
+      dst_dtype == IPA_F32 && kernel) {
+    FusedCall f;
+    f.coord_kind = 0;
+    f.map = MapCoord{d_mapx, d_mapy, map_pitch};
+    int rc = fused_fill(ctx, f, d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw,
+                        dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
+                        border_mode, border_value, conv_border_x, conv_border_y);
+    if (rc) return rc;
+    f.kernel = kernel;
+    IPA_HIP(ctx, hipSetDevice(ctx->device));
+    rc = ipa_fused_big_launch(ctx, f, kh);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      IPA_HIP(ctx, hipGetLastError());
+      return IPA_OK;
+    }
+  }
   void* tmp = nullptr;
   int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;

@@ -134,6 +134,14 @@ if __name__ == '__main__':
         t = timeit(ctx, lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k11, 'cubic', out=dst))
         print('C5-like 4K bicubic warp + 11x11 (2 launches) %8.1f us  %7.1f Gpx/s'
               % (t, px / t / 1e3))
+        # map-based: one kernel (fused_big.hip) unless IPA_BIG_FUSED=0
+        dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
+        k9 = np.random.default_rng(322).random((9, 9))
+        k9 /= k9.sum()
+        for interp, kk in (('linear', k9), ('linear', k11), ('cubic', k9), ('cubic', k11)):
+            t = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, kk, interp, out=dst))
+            print('map remap %-6s + %2dx%-2d %8.1f us  %7.1f Gpx/s'
+                  % (interp, len(kk), len(kk), t, px / t / 1e3))
     if what == 'pipeline':
         # end to end, host to host, with page-locked arrays and overlapped workers (C4 style)
         import time

@@ -363,6 +363,27 @@ def test_tall_strips_of_large_launches(ia, orc):
         os.environ.pop('IPA_STRIP_H', None)
 
 
+def test_big_kernels_on_the_marching_wave(ia, orc):
+    """9x9 / 11x11: the plain filter and the map-based bilinear remap -> filter chain in one
+    kernel (coefficient rows streamed through SGPRs), batches through the frame-inner order"""
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(29)
+    h, w = 150, 700
+    batch = np.stack([synth((h, w), 90 + i) for i in range(3)])
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    mx = (xx + 2.1 * np.sin(yy / 13 + 0.3) - 0.6).astype(np.float32)
+    my = (yy + 1.6 * np.cos(xx / 17) + 0.4).astype(np.float32)
+    d_b, dmx, dmy = ctx.to_device(batch), ctx.to_device(mx), ctx.to_device(my)
+    for ksz, mode in ((9, 'reflect'), (11, 'constant'), (11, 'wrap'), (9, 'nearest')):
+        k = rng.random((ksz, ksz)) - 0.2
+        got_c = ia.ops.conv2d(d_b, k, mode, 0.5).get()
+        got_f = ia.ops.remap_conv2d(d_b, dmx, dmy, k, 'linear', 'constant', 0.1, mode).get()
+        for i in range(3):
+            close32(got_c[i], orc.conv2d(batch[i], k, mode, 0.5), 'conv %d %s #%d' % (ksz, mode, i))
+            want_r = orc.remap(batch[i], mx, my, orc.LINEAR, orc.CONSTANT, 0.1)
+            close32(got_f[i], orc.conv2d(want_r, k, mode), 'fused %d %s #%d' % (ksz, mode, i))
+
+
 def test_single_frame_row_bands(ia, orc):
     """C5 alternative: one frame split into output row bands, one band per GPU,
     no collective — the concatenated bands equal the whole-frame chain bit for bit"""
