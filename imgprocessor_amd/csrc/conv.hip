@@ -375,6 +375,7 @@ static int conv_typed(ipa_ctx* ctx, ConvParams& p, const double* kernel, int kh,
       switch (kh) {
         case 3: ipa_wave_conv_launch_k3(ctx, wp, src, kernel, n_frames); break;
         case 5: ipa_wave_conv_launch_k5(ctx, wp, src, kernel, n_frames); break;
+        // (7x7 with streamed coefficients measured slower here: 285 vs 278 us)
         case 7: ipa_wave_conv_launch_k7(ctx, wp, src, kernel, n_frames); break;
         case 9: ipa_wave_conv_launch_k9(ctx, wp, src, kernel, n_frames); break;
         default: ipa_wave_conv_launch_k11(ctx, wp, src, kernel, n_frames); break;

@@ -234,8 +234,15 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
   // 9x9 / 11x11 on float32 frames: one kernel (fused_big.hip); IPA_BIG_FUSED=0 is the tuning
   // knob that sends them through the two launches below instead
   static const bool big_fused = !(getenv("IPA_BIG_FUSED") && atoi(getenv("IPA_BIG_FUSED")) == 0);
-  if (big_fused && kh == kw && (kh == 9 || kh == 11) && src_dtype == IPA_F32 &&
-      dst_dtype == IPA_F32 && kernel) {
+  // 7x7 as well: with the sampling source's scalar state, 49 resident coefficients overflow
+  // the SGPR file (331 spills); streamed, the 4K chain measured 489 -> 449 us (float32) and
+  // 493 -> 460 us (uint16 frames); 5x5 measured slower streamed (0.427 vs 0.399 ms, 16 frames).
+  // IPA_STREAM_K=9 is the tuning knob that puts 7x7 back on the resident form.
+  static const int stream_k = getenv("IPA_STREAM_K") ? atoi(getenv("IPA_STREAM_K")) : 7;
+  const bool streamed = kh >= stream_k && kh >= 7 && kh <= 11;
+  if (big_fused && kh == kw && streamed &&
+      (src_dtype == IPA_F32 || (kh == 7 && src_dtype == IPA_U16)) && dst_dtype == IPA_F32 &&
+      kernel) {
     FusedCall f;
     f.coord_kind = 0;
     f.map = MapCoord{d_mapx, d_mapy, map_pitch};

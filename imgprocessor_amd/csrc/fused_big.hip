@@ -5,15 +5,18 @@
 // image never exists in HBM: 16 x 4K, 9x9 673 -> 501 us, 11x11 748 -> 591 us against two
 // launches.  Bicubic was built and measured slower in one kernel (185-193 VGPRs, occupancy 2:
 // 858 vs 768 us, 953 vs 880 us) and stays on two launches.
+// 7x7 (float32 and uint16 frames, BASELINE configuration C4) runs here too: next to the
+// sampling source's scalar state 49 resident coefficients overflow the SGPR file (331 spills
+// in wave_stencil_kernel); streamed, the 4K chain measured 489 -> 449 us / 493 -> 460 us.
 // Reference call chain: camera/PerspectiveCorrection.py:401-405 / camera/LensDistortion.py:323-326
 // followed by filters/maskedConvolve.py:24-43.
 #include "fused_impl.hpp"
 
 namespace ipa {
 
-template <int INTERP, int K>
+template <typename ST, int INTERP, int K>
 static void fused_big_launch_one(ipa_ctx* ctx, const FusedCall& f) {
-  using Src = SampleRowSrc<float, INTERP, MapCoord>;
+  using Src = SampleRowSrc<ST, INTERP, MapCoord>;
   WaveBigArgs<Src, K> a;
   for (int i = 0; i < K; i++)
     for (int j = 0; j < 12; j++) a.wrows[i][j] = j < K ? (float)f.kernel[i * K + j] : 0.f;
@@ -37,10 +40,15 @@ static void fused_big_launch_one(ipa_ctx* ctx, const FusedCall& f) {
 // returns 1 when the call is not covered (the caller then runs remap and filter as two launches)
 int ipa_fused_big_launch(ipa_ctx* ctx, const ipa::FusedCall& f, int K) {
   using namespace ipa;
-  if (f.src_dt != IPA_F32 || f.dst_dt != IPA_F32 || f.coord_kind != 0) return 1;
-  if (f.interp_base != IPA_INTER_LINEAR) return 1;
-  if (K == 9) fused_big_launch_one<kLinear, 9>(ctx, f);
-  else if (K == 11) fused_big_launch_one<kLinear, 11>(ctx, f);
+  if (f.dst_dt != IPA_F32 || f.coord_kind != 0 || f.interp_base != IPA_INTER_LINEAR) return 1;
+  if (K == 7 && f.src_dt == IPA_U16) {
+    fused_big_launch_one<uint16_t, kLinear, 7>(ctx, f);
+    return 0;
+  }
+  if (f.src_dt != IPA_F32) return 1;
+  if (K == 7) fused_big_launch_one<float, kLinear, 7>(ctx, f);
+  else if (K == 9) fused_big_launch_one<float, kLinear, 9>(ctx, f);
+  else if (K == 11) fused_big_launch_one<float, kLinear, 11>(ctx, f);
   else return 1;
   return 0;
 }

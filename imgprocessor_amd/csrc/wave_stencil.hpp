@@ -317,7 +317,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4)))* kernarg_f32;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <bool FAST, typename Src, int K, int QM = -1>
+template <bool FAST, typename Src, int K, int QM = -1, bool STREAM = false>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                    const Weights<float, K * K>& wts, float* xp,
                                                    const Cols& c, int y0, int nrows, bool writer,
@@ -358,7 +358,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #pragma unroll
       for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
 
-      // K > 7: kernel row i (padded to 12 floats, 16-byte aligned) arrives in 12 SGPRs while
+      // STREAM: kernel row i (padded to 12 floats, 16-byte aligned) arrives in 12 SGPRs while
       // row i + 1 is being accumulated: load(i - 1) is issued before the fmas of row i, the
       // wait for it stands in front of the fmas of row i - 1.  The asm statements carry the
       // running sums as in/out operands, which pins them between the fma groups (left to the
@@ -369,12 +369,12 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
                : "=&s"(cc[r][0]), "=&s"(cc[r][1]), "=&s"(cc[r][2])                             \
                : "s"(wk), "n"((r) * 48), "n"((r) * 48 + 16), "n"((r) * 48 + 32))
       v4f cc[K][3];
-      if constexpr (K > 7) IPA_LOAD_COEF_ROW(K - 1);
+      if constexpr (STREAM) IPA_LOAD_COEF_ROW(K - 1);
 #undef IPA_LOAD_COEF_ROW
 
       static_for<0, K>([&](auto Ii) {
         constexpr int i = K - 1 - decltype(Ii)::value;
-        if constexpr (K > 7) {
+        if constexpr (STREAM) {
           if constexpr (i == K - 1)
             asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]));
           else
@@ -394,7 +394,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #pragma unroll
         for (int j = 0; j < K; j++) {
           float w;
-          if constexpr (K > 7) w = cc[i][j >> 2][j & 3];
+          if constexpr (STREAM) w = cc[i][j >> 2][j & 3];
           else w = wts.w[i * K + j];
           const v2f w2 = v2f{w, w};
 #pragma unroll
@@ -409,7 +409,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
           }
         }
         // keep the next kernel row's scalar loads below this row's fmas
-        if constexpr (K > 7) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
       });
 
       // output row t - (K-1) is complete
@@ -450,7 +450,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
 #ifndef IPA_WPB
 #define IPA_WPB 4   // waves per workgroup
 #endif
-template <typename Src, int K>
+template <typename Src, int K, bool STREAM = false>
 __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
                                                   const Weights<float, K * K>& wts,
                                                   kernarg_f32 wk) {
@@ -498,10 +498,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
     if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
-      if (src.q5) wave_run_strip<true, Src, K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
-      else wave_run_strip<true, Src, K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+      if (src.q5) wave_run_strip<true, Src, K, 1, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+      else wave_run_strip<true, Src, K, 0, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
     } else {
-      wave_run_strip<true, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+      wave_run_strip<true, Src, K, -1, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
     }
   } else {
 #pragma unroll
@@ -509,7 +509,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
     }
-    wave_run_strip<false, Src, K>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+    wave_run_strip<false, Src, K, -1, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
   }
 }
 
@@ -529,13 +529,13 @@ template <typename Src, int K> struct WaveBigArgs {
 template <typename Src, int K>
 __global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
 wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
-  static_assert(K > 7 && K <= 12, "padded coefficient rows of 12");
+  static_assert(K <= 12, "padded coefficient rows of 12");
   typedef const char __attribute__((address_space(4)))* kernarg_bytes;
   kernarg_bytes base = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
   using Args = WaveBigArgs<Src, K>;
   kernarg_f32 wk = (kernarg_f32)(base + offsetof(Args, wrows));
   Weights<float, K * K> unused;  // the K <= 7 form of the coefficients, never read here
-  wave_stencil_body<Src, K>(a.p, a.src, unused, wk);
+  wave_stencil_body<Src, K, true>(a.p, a.src, unused, wk);
 }
 
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
