@@ -189,7 +189,11 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #define IPA_SAMPLE_DEPTH 2
 #endif
   template <int K> struct depth {
-    static constexpr int value = INTERP == kLinear ? IPA_SAMPLE_DEPTH : 1;
+#ifndef IPA_SAMPLE_DEPTH_BIG
+#define IPA_SAMPLE_DEPTH_BIG IPA_SAMPLE_DEPTH
+#endif
+    static constexpr int value =
+        INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : IPA_SAMPLE_DEPTH) : 1;
   };
   template <int D> struct Chunk { BatchTaps<ST, INTERP, 4> t[D]; };
 
