@@ -28,6 +28,8 @@ PROTOTYPES = {
     'ipa_ctx_create': [_i, C.POINTER(_vp)],
     'ipa_ctx_destroy': [_vp],
     'ipa_ctx_synchronize': [_vp],
+    'ipa_ctx_set_tuning': [_vp, C.c_char_p, _i],
+    'ipa_ctx_get_tuning': [_vp, C.c_char_p, C.POINTER(_i)],
     'ipa_ctx_device_info': [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
     'ipa_malloc': [_vp, _sz, C.POINTER(_vp)],
     'ipa_free': [_vp, _vp],

@@ -12,7 +12,22 @@
 
 #include "../../include/imgproc_hip.h"
 
+// Launch-shape knobs of a context.  Defaults are the measured optima;
+// ipa_ctx_create() reads the IPA_* environment variables ONCE into this struct and
+// ipa_ctx_set_tuning() changes a field afterwards - nothing in a launch path calls getenv().
+struct ipa_tuning {
+  int strip_h = 0;        // rows per strip of the marching kernels (0: by launch size)
+  int frames_inner = 1;   // batches dispatched strip by strip (frames of a strip adjacent)
+  int big_wave = 1;       // 9x9 / 11x11 filter on the marching wave (0: LDS-tiled kernel)
+  int big_fused = 1;      // remap -> 7x7 / 9x9 / 11x11 in one kernel
+  int stream_k = 7;       // smallest K whose coefficients are streamed through SGPRs
+  int group = 0;          // 1: batches of >= group_min frames on the frame-group kernel
+  int group_min = 2;
+  int group_ring = 1;     // frame-group kernel samples from its LDS ring of source rows
+};
+
 struct ipa_ctx {
+  ipa_tuning tune;
   int device = -1;
   hipStream_t stream = nullptr;
   int cu_count = 0;

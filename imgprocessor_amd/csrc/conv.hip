@@ -360,9 +360,9 @@ static int conv_typed(ipa_ctx* ctx, ConvParams& p, const double* kernel, int kh,
   if (fast && sizeof(T) == 8 && kh > 7) fast = false;  // f64: tuned path instantiated to 7x7
   if constexpr (sizeof(T) == 4) {
     // float32: the wave-marching stencil (wave_stencil.hpp)
-    // (masked filtering stays on the LDS-tiled kernel; so do 9x9 / 11x11 with IPA_BIG_WAVE=0,
+    // (masked filtering stays on the LDS-tiled kernel; so do 9x9 / 11x11 with the context knob big_wave = 0,
     // the tuning knob that A/Bs wave_conv_big.hip against it: 334 vs 375 us, 428 vs 487 us)
-    static const bool big_wave = !(getenv("IPA_BIG_WAVE") && atoi(getenv("IPA_BIG_WAVE")) == 0);
+    const bool big_wave = ctx->tune.big_wave != 0;
     if (fast && (kh <= 7 || big_wave) && !p.mask) {
       WaveParams wp;
       wp.dst = p.dst; wp.dst_frame_elems = p.dst_frame_elems;

@@ -11,6 +11,8 @@ int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
+// fused_group.hip: batches, one workgroup per strip of 4 frames; 1 = not covered
+int ipa_fused_group_launch(ipa_ctx*, const FusedCall&, int K, int use_ring);
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
 static int inv3f(const double* m, double* o) {
@@ -98,6 +100,14 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   if (rc) return rc;
   f.kernel = kernel;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (ctx->tune.group && n_frames >= ctx->tune.group_min) {
+    rc = ipa_fused_group_launch(ctx, f, kh, ctx->tune.group_ring);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      IPA_HIP(ctx, hipGetLastError());
+      return IPA_OK;
+    }
+  }
   switch (kh) {
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;
     case 5: rc = ipa_fused_launch_k5(ctx, f); break;
@@ -231,14 +241,14 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
                          int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
-  // 9x9 / 11x11 on float32 frames: one kernel (fused_big.hip); IPA_BIG_FUSED=0 is the tuning
+  // 9x9 / 11x11 on float32 frames: one kernel (fused_big.hip); big_fused = 0 is the tuning
   // knob that sends them through the two launches below instead
-  static const bool big_fused = !(getenv("IPA_BIG_FUSED") && atoi(getenv("IPA_BIG_FUSED")) == 0);
+  const bool big_fused = ctx->tune.big_fused != 0;
   // 7x7 as well: with the sampling source's scalar state, 49 resident coefficients overflow
   // the SGPR file (331 spills); streamed, the 4K chain measured 489 -> 449 us (float32) and
   // 493 -> 460 us (uint16 frames); 5x5 measured slower streamed (0.427 vs 0.399 ms, 16 frames).
-  // IPA_STREAM_K=9 is the tuning knob that puts 7x7 back on the resident form.
-  static const int stream_k = getenv("IPA_STREAM_K") ? atoi(getenv("IPA_STREAM_K")) : 7;
+  // stream_k = 9 is the tuning knob that puts 7x7 back on the resident form.
+  const int stream_k = ctx->tune.stream_k;
   const bool streamed = kh >= stream_k && kh >= 7 && kh <= 11;
   if (big_fused && kh == kw && streamed &&
       (src_dtype == IPA_F32 || (kh == 7 && src_dtype == IPA_U16)) && dst_dtype == IPA_F32 &&

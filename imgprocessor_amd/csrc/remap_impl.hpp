@@ -314,7 +314,7 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   bool inner = a.n_frames > 1 && (unsigned long)p.tiles * a.n_frames < (1ul << 31) &&
                std::is_same<Coord, MapCoord>::value &&
                (base == IPA_INTER_NEAREST || base == IPA_INTER_LINEAR);
-  if (const char* e = getenv("IPA_FRAMES_INNER")) inner = inner && atoi(e) != 0;  // tuning knob
+  inner = inner && ctx->tune.frames_inner != 0;  // tuning knob
   p.frames_inner = inner ? a.n_frames : 0;
   dim3 grid = inner ? dim3(p.tiles * (unsigned)a.n_frames, 1) : dim3(p.tiles, (unsigned)a.n_frames);
   IPA_HIP(ctx, hipSetDevice(ctx->device));

@@ -50,6 +50,46 @@ int ipa_device_count(int* count) {
   return IPA_OK;
 }
 
+namespace {
+struct TuneName {
+  const char* name;
+  const char* env;
+  int ipa_tuning::*field;
+};
+const TuneName kTuneNames[] = {
+    {"strip_h", "IPA_STRIP_H", &ipa_tuning::strip_h},
+    {"frames_inner", "IPA_FRAMES_INNER", &ipa_tuning::frames_inner},
+    {"big_wave", "IPA_BIG_WAVE", &ipa_tuning::big_wave},
+    {"big_fused", "IPA_BIG_FUSED", &ipa_tuning::big_fused},
+    {"stream_k", "IPA_STREAM_K", &ipa_tuning::stream_k},
+    {"group", "IPA_GROUP", &ipa_tuning::group},
+    {"group_min", "IPA_GROUP_MIN", &ipa_tuning::group_min},
+    {"group_ring", "IPA_GROUP_RING", &ipa_tuning::group_ring},
+};
+}  // namespace
+
+int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return IPA_ERR_BAD_ARG;
+  for (const TuneName& t : kTuneNames)
+    if (strcmp(t.name, name) == 0) {
+      ctx->tune.*(t.field) = value;
+      return IPA_OK;
+    }
+  ipa_set_error(ctx, "unknown tuning knob '%s'", name);
+  return IPA_ERR_BAD_ARG;
+}
+
+int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
+  if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
+  for (const TuneName& t : kTuneNames)
+    if (strcmp(t.name, name) == 0) {
+      *value = ctx->tune.*(t.field);
+      return IPA_OK;
+    }
+  ipa_set_error(ctx, "unknown tuning knob '%s'", name);
+  return IPA_ERR_BAD_ARG;
+}
+
 int ipa_ctx_create(int device_id, ipa_ctx** out) {
   if (!out) return IPA_ERR_BAD_ARG;
   *out = nullptr;
@@ -73,6 +113,9 @@ int ipa_ctx_create(int device_id, ipa_ctx** out) {
     return IPA_ERR_NO_DEVICE;
   }
   ipa_ctx* c = new ipa_ctx();
+  // environment defaults of the tuning knobs: read here, once per context
+  for (const TuneName& t : kTuneNames)
+    if (const char* e = getenv(t.env)) c->tune.*(t.field) = atoi(e);
   c->device = device_id;
   c->cu_count = prop.multiProcessorCount;
   if (hipSetDevice(device_id) != hipSuccess ||

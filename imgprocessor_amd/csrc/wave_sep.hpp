@@ -189,9 +189,9 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
     w.kx[i] = (float)kx[i];
   }
   p.strips_x = (p.dw + 247) / 248;
-  p.strip_h = wave_strip_height(p.dh, p.dw, n_frames, K);
+  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid = wave_grid(p, n_frames, 4, true), block(256);
+  dim3 grid = wave_grid(ctx, p, n_frames, 4, true), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 

@@ -100,9 +100,10 @@ struct WaveParams {
 };
 
 // grid for a launch over n_frames; fills p.frames_inner
-static inline dim3 wave_grid(WaveParams& p, int n_frames, int waves_per_block, bool frames_inner) {
+static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, int waves_per_block,
+                             bool frames_inner) {
   unsigned blocks = (p.strips + waves_per_block - 1) / waves_per_block;
-  if (const char* e = getenv("IPA_FRAMES_INNER")) frames_inner = atoi(e) != 0;  // tuning knob
+  frames_inner = frames_inner && ctx->tune.frames_inner != 0;
   if (frames_inner && n_frames > 1 && (unsigned long)blocks * n_frames < (1ul << 31)) {
     p.frames_inner = n_frames;
     return dim3(blocks * (unsigned)n_frames, 1);
@@ -544,9 +545,9 @@ wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
 
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
 // problems enough waves to fill 256 CUs
-static inline int wave_strip_height(int dh, int dw, int n_frames, int K, bool fma_bound = false) {
-  if (const char* e = getenv("IPA_STRIP_H"))  // tuning knob (tests/bench_micro.py strip)
-    if (atoi(e) > 0) return atoi(e);
+static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_frames, int K,
+                                    bool fma_bound = false) {
+  if (ctx->tune.strip_h > 0) return ctx->tune.strip_h;  // tuning knob
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
   long sx = (dw + ow - 1) / ow;
   // measured on 4K frames (MI355X, 4096 resident waves): with 16 frames 16-48 rows are within

@@ -58,6 +58,22 @@ class Context(object):
     def synchronize(self):
         self._check(self._lib.ipa_ctx_synchronize(self.handle), 'synchronize')
 
+    # -- launch-shape knobs ----------------------------
+    def set_tuning(self, **knobs):
+        """e.g. ctx.set_tuning(strip_h=48, group=0); returns the previous values"""
+        old = {k: self.get_tuning(k) for k in knobs}
+        for k, v in knobs.items():
+            self._check(self._lib.ipa_ctx_set_tuning(self.handle, k.encode(), int(v)),
+                        'set_tuning')
+        return old
+
+    def get_tuning(self, name):
+        import ctypes
+        v = ctypes.c_int(0)
+        self._check(self._lib.ipa_ctx_get_tuning(self.handle, name.encode(), ctypes.byref(v)),
+                    'get_tuning')
+        return v.value
+
     # -- memory -----------------------------------------------------------
     def _alloc(self, nbytes):
         with self._pool_lock:

@@ -77,6 +77,12 @@ int ipa_device_count(int* count);
 int ipa_ctx_create(int device_id, ipa_ctx** ctx);
 int ipa_ctx_destroy(ipa_ctx* ctx);
 int ipa_ctx_synchronize(ipa_ctx* ctx);
+/* Launch-shape knobs of a context ("strip_h", "frames_inner", "big_wave", "big_fused",
+ * "stream_k", "group", "group_min", "group_ring").  ipa_ctx_create reads
+ * their IPA_* environment defaults once; no launch path consults the environment.  The
+ * reference has no counterpart (its numba / cv2 calls take no launch parameters). */
+int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value);
+int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value);
 /* name (e.g. "gfx950...") and compute-unit count of the context's device */
 int ipa_ctx_device_info(ipa_ctx* ctx, char* name, size_t name_len, int* cu_count,
                         size_t* total_mem_bytes);

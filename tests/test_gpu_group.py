@@ -1,0 +1,181 @@
+"""GPU: the frame-group kernel (csrc/group_stencil.hpp: one workgroup per strip of 4 frames,
+shared footprint records, bilinear taps from an LDS ring of source rows) against the per-frame
+marching kernel - the same arithmetic, so the results must agree BIT FOR BIT - and against the
+oracle.  Geometries are chosen to exercise every branch: ring rows, rows that do not fit the
+ring (rotation), footprints on the source border, constant / reflect filter borders, rim
+strips, ragged sizes, batches that do not fill the last group.
+"""
+import numpy as np
+import pytest
+
+from .conftest import assert_close, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)
+    return imgprocessor_amd
+
+
+def frames(n, h, w, dtype=np.float32):
+    out = np.stack([synth((h, w), 100 + i) for i in range(n)])
+    if dtype == np.uint16:
+        return np.round(out * 4095).astype(np.uint16)
+    return out.astype(dtype)
+
+
+def radial_maps(h, w, k1=-0.12, shift=0.0):
+    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([k1, 0.03, 1e-3, -5e-4, 0.0])
+    from imgprocessor_amd import ops
+    mx, my = ops.build_undistort_map(K, dist, K, h, w)
+    return (mx + np.float32(shift)).astype(np.float32), my.astype(np.float32), K, dist
+
+
+def rot_maps(h, w, deg):
+    a = np.deg2rad(deg)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    mx = np.cos(a) * (x - cx) - np.sin(a) * (y - cy) + cx
+    my = np.sin(a) * (x - cx) + np.cos(a) * (y - cy) + cy
+    return mx.astype(np.float32), my.astype(np.float32)
+
+
+def kern(K, seed=5):
+    k = np.random.default_rng(seed).random((K, K))
+    return k / k.sum()
+
+
+def run_three(ia, src, mx, my, k, **kw):
+    """per-frame kernel, group kernel with gathers only, group kernel with the ring"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    old = ctx.set_tuning(group=0)
+    try:
+        ref = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
+        ctx.set_tuning(group=1, group_min=1, group_ring=0)
+        gat = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
+        ctx.set_tuning(group_ring=1)
+        ring = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
+    finally:
+        ctx.set_tuning(**old)
+    return ref, gat, ring
+
+
+def same_bits(a, b, what):
+    assert a.shape == b.shape
+    bad = a.view(np.uint32) != b.view(np.uint32)
+    bad &= ~(np.isnan(a) & np.isnan(b))
+    assert not bad.any(), '%s: %d of %d values differ, first at %s (%r vs %r)' % (
+        what, bad.sum(), a.size, np.argwhere(bad)[0], a[bad][0], b[bad][0])
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 6])
+@pytest.mark.parametrize('shape', [(96, 300), (131, 517), (200, 1030)])
+def test_group_matches_per_frame_radial(ia, oracle, n, shape):
+    h, w = shape
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    k = kern(5)
+    ref, gat, ring = run_three(ia, src, mx, my, k)
+    same_bits(gat, ref, 'gather mode')
+    same_bits(ring, ref, 'ring mode')
+    want = oracle.conv2d(oracle.remap(src[n - 1], mx, my), k)
+    assert_close(ring[n - 1], want, 1e-5, 1e-5 * np.abs(want).max(), 'vs oracle')
+
+
+@pytest.mark.parametrize('case', ['rot3', 'rot20', 'rot90', 'rot180', 'shift_out', 'pincushion',
+                                  'flipx', 'zoom_out', 'zoom_in'])
+def test_group_geometries(ia, oracle, case):
+    h, w, n = 150, 700, 5
+    src = frames(n, h, w)
+    if case.startswith('rot'):
+        mx, my = rot_maps(h, w, float(case[3:]))
+    elif case == 'shift_out':
+        mx, my, _, _ = radial_maps(h, w, shift=-40.5)
+    elif case == 'pincushion':
+        mx, my, _, _ = radial_maps(h, w, k1=0.25)
+    elif case == 'flipx':
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        mx, my = (w - 1 - x + 0.25).astype(np.float32), (y + 0.5).astype(np.float32)
+    elif case == 'zoom_out':
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        mx, my = (x * 1.7 - 100).astype(np.float32), (y * 1.7 - 30).astype(np.float32)
+    else:
+        y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+        mx, my = (x * 0.31 + 7.3).astype(np.float32), (y * 0.31 + 3.1).astype(np.float32)
+    k = kern(5, 9)
+    for kw in ({}, {'conv_mode': 'constant'}, {'border_mode': 'reflect', 'conv_mode': 'wrap'}):
+        ref, gat, ring = run_three(ia, src, mx, my, k, **kw)
+        same_bits(gat, ref, '%s gather %r' % (case, kw))
+        same_bits(ring, ref, '%s ring %r' % (case, kw))
+    want = oracle.conv2d(oracle.remap(src[2], mx, my), k)
+    ref, gat, ring = run_three(ia, src, mx, my, k)
+    assert_close(ring[2], want, 1e-5, 1e-5 * np.abs(want).max(), case + ' vs oracle')
+
+
+def test_group_nan_and_far_coordinates(ia):
+    h, w, n = 80, 600, 4
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    mx = mx.copy(); my = my.copy()
+    mx[10, 50:60] = np.nan
+    my[20, 300:310] = np.inf
+    mx[30, 400:420] = 3e7
+    mx[40:44, :] = -5.0
+    ref, gat, ring = run_three(ia, src, mx, my, kern(5), border_value=0.25)
+    same_bits(gat, ref, 'gather')
+    same_bits(ring, ref, 'ring')
+
+
+def test_group_q5(ia):
+    from imgprocessor_amd import ops
+    h, w, n = 120, 520, 4
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    ref, gat, ring = run_three(ia, src, mx, my, kern(5), interpolation='linear_cv_q5')
+    same_bits(gat, ref, 'gather q5')
+    same_bits(ring, ref, 'ring q5')
+
+
+def test_group_analytic_sources(ia, oracle):
+    """undistort (lens model in the kernel) and homography coordinate sources"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 140, 900, 6
+    src = frames(n, h, w)
+    _, _, K, dist = radial_maps(h, w)
+    k = kern(5, 3)
+    d_src = ctx.to_device(src)
+    M = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
+    old = ctx.set_tuning(group=0)
+    try:
+        ref_u = ops.undistort_conv2d(d_src, K, dist, K, k).get()
+        ref_h = ops.warp_perspective_conv2d(d_src, M, (h, w), k).get()
+        for ring in (0, 1):
+            ctx.set_tuning(group=1, group_min=1, group_ring=ring)
+            same_bits(ops.undistort_conv2d(d_src, K, dist, K, k).get(), ref_u,
+                      'undistort ring=%d' % ring)
+            same_bits(ops.warp_perspective_conv2d(d_src, M, (h, w), k).get(), ref_h,
+                      'homography ring=%d' % ring)
+    finally:
+        ctx.set_tuning(**old)
+
+
+def test_group_4k_strip_geometry(ia, oracle):
+    """4K frames: tall strips, many chunks per strip, all interior strips on the fast path"""
+    h, w, n = 2160, 3840, 5
+    base = synth((h, w), 7)
+    src = np.stack([np.roll(base, 11 * i, axis=0) for i in range(n)])
+    mx, my, _, _ = radial_maps(h, w)
+    k = kern(5, 1)
+    ref, gat, ring = run_three(ia, src, mx, my, k)
+    same_bits(gat, ref, '4K gather')
+    same_bits(ring, ref, '4K ring')
+    sub = slice(1000, 1200)
+    want = oracle.conv2d(oracle.remap(src[4], mx, my), k)
+    assert_close(ring[4][sub], want[sub], 1e-5, 1e-5 * np.abs(want).max(), '4K vs oracle')

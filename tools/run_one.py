@@ -1,0 +1,51 @@
+"""Run the 4K fused headline a few times with given context knobs (for rocprofv3 passes).
+
+    python3 tools/run_one.py [--batch 16] [--steps 3] [--analytic] knob=value ...
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import imgprocessor_amd as ia  # noqa: E402
+from imgprocessor_amd import ops  # noqa: E402
+
+
+def main():
+    args = sys.argv[1:]
+    batch, steps, analytic, knobs = 16, 3, False, {}
+    i = 0
+    while i < len(args):
+        a = args[i]
+        if a == '--batch':
+            batch = int(args[i + 1]); i += 1
+        elif a == '--steps':
+            steps = int(args[i + 1]); i += 1
+        elif a == '--analytic':
+            analytic = True
+        elif '=' in a:
+            k, v = a.split('=')
+            knobs[k] = int(v)
+        i += 1
+    ctx = ia.default_context(0)
+    ctx.set_tuning(**knobs)
+    h, w = 2160, 3840
+    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
+    g /= g.sum()
+    k5 = np.outer(g, g)
+    dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
+    src = ctx.to_device(np.random.default_rng(0).random((batch, h, w), dtype=np.float32))
+    dst = ctx.empty((batch, h, w), np.float32)
+    for _ in range(steps):
+        if analytic:
+            ops.undistort_conv2d(src, K, dist, K, k5, out=dst)
+        else:
+            ops.remap_conv2d(src, dmx, dmy, k5, out=dst)
+    ctx.synchronize()
+
+
+if __name__ == '__main__':
+    main()
