@@ -9,8 +9,13 @@
 
 namespace ipa {
 
+// waves per SIMD the register budget is cut for (LDS allows 3 workgroups per CU)
+#ifndef IPA_GROUP_MINW
+#define IPA_GROUP_MINW 3
+#endif
+
 template <typename ST, typename Coord, int K>
-__global__ void __launch_bounds__(64 * kGW)
+__global__ void __launch_bounds__(64 * kGW, IPA_GROUP_MINW)
 group_stencil_kernel(WaveParams p, GroupSrc<ST, Coord> g, Weights<float, K * K> wts) {
   GroupKernel<ST, Coord, K, false>::body(p, g, wts, nullptr);
 }
@@ -21,7 +26,7 @@ template <typename ST, typename Coord, int K> struct GroupBigArgs {
   alignas(16) float wrows[K][12];  // kernel row i, taps 0..K-1, zero padded
 };
 template <typename ST, typename Coord, int K>
-__global__ void __launch_bounds__(64 * kGW)
+__global__ void __launch_bounds__(64 * kGW, IPA_GROUP_MINW)
 group_stencil_big_kernel(GroupBigArgs<ST, Coord, K> a) {
   typedef const char __attribute__((address_space(4)))* kernarg_bytes;
   kernarg_bytes base = (kernarg_bytes)__builtin_amdgcn_kernarg_segment_ptr();
@@ -44,9 +49,11 @@ static void group_fill(const FusedCall& f, const Coord& c, GroupSrc<ST, Coord>& 
 
 template <int K>
 static dim3 group_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, bool fma_bound) {
-  using G = wave_geom<K>;
+  using G = group_geom<K>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
-  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, fma_bound);
+  // same rule as the per-frame kernels (tallest strip that still leaves enough waves), counted
+  // with this kernel's 128-px strips: pretend the image is twice as wide
+  p.strip_h = wave_strip_height(ctx, p.dh, 2 * p.dw, n_frames, K, fma_bound);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   p.frames_inner = 0;
   const unsigned groups = ((unsigned)n_frames + kGW - 1) / kGW;
@@ -90,7 +97,8 @@ static int group_launch_coord(ipa_ctx* ctx, const FusedCall& f, int use_ring) {
 // returns 1 when the call is not covered (the caller then uses the per-frame kernels)
 int ipa_fused_group_launch(ipa_ctx* ctx, const ipa::FusedCall& f, int K, int use_ring) {
   using namespace ipa;
-  if (f.dst_dt != IPA_F32 || f.interp_base != IPA_INTER_LINEAR) return 1;
+  // exact-coordinate bilinear only (the 1/32-px rule of cv2 stays on the per-frame kernels)
+  if (f.dst_dt != IPA_F32 || f.interp_base != IPA_INTER_LINEAR || f.q5) return 1;
   if (f.src_dt == IPA_F32) {
     switch (K) {
       case 5: return group_launch_coord<float, 5>(ctx, f, use_ring);

@@ -3,25 +3,27 @@
 // wave_stencil.hpp pays once per frame are paid once per GROUP here, and the bilinear taps stop
 // going through the vector-memory path altogether:
 //
-//   * the frames of a batch share their geometry (one map / one lens model / one homography,
+//   * the frames of a batch share their geometry (one map / one lens model / one homography;
 //     reference: LensDistortion.py:344-345 caches the maps, PerspectiveCorrection keeps one
-//     homography).  For a chunk of kGW rows each wave turns ONE row of coordinates into
-//     footprint records (first-tap address, x/y fraction) and puts them into LDS; after a
-//     barrier all waves read every row's records.  Map loads, the f64 lens model, floor /
-//     fraction / bounds arithmetic: 1/kGW per frame.
-//   * the footprints of a 256-px output row cover a few, nearly contiguous source rows.  Each
-//     wave keeps the last kRR source rows of ITS frame (kRW px from a window origin xlo) in a
-//     wave-private LDS ring, filled with coalesced 16-byte row loads that are issued one chunk
-//     ahead (the producing waves also publish the row span of every output row, so all waves
-//     know which source rows the next chunk needs).  A bilinear sample is then four
-//     ds_read_b32 at immediate offsets from ONE address (slot 8 of the ring mirrors slot 0, so
-//     the row below is always +kRW) instead of four 64-lane gathers through the texture
-//     addresser - the unit that bounds the per-frame kernel (profiles/r01_micro.txt).
-//     Rows whose footprints do not fit the ring (span > kRR - 2 rows or > kRW - 8 columns,
-//     e.g. strong rotations) carry global element offsets in their records instead and are
-//     gathered as before; footprints touching the source border are redone tap by tap through
-//     sample().  Same arithmetic and summation order as wave_stencil.hpp / sampler.hpp:
-//     results are bit-identical to the per-frame kernels.
+//     homography).  A strip is 128 px wide and is walked in STEPS of two rows (256 samples,
+//     four per lane).  For a chunk of kGW steps each wave turns ONE step of coordinates into
+//     footprint records (first-tap address, x / y fraction) in LDS; after a barrier all waves
+//     read every step's records.  Map loads, the f64 lens model, floor / fraction / bounds
+//     arithmetic: 1/kGW per frame.
+//   * the footprints of a step cover a few, nearly contiguous source rows.  Each wave keeps
+//     the last kRR source rows of ITS frame (kRW px from a window origin xlo) in a wave-
+//     private LDS ring, filled by coalesced row loads that are issued a chunk ahead (the
+//     producers publish the row / column span of every step; lanes 0..3 of every wave turn
+//     the four spans of a chunk into the ring schedule).  A bilinear sample is then two
+//     ds_read2_b32 from ONE computed address (slot kRR mirrors slot 0, so the row below is
+//     always + kRW) instead of four 64-lane gathers through the texture addresser - the unit
+//     that bounds the per-frame kernel (profiles/r01_micro.txt).
+//     Steps whose footprints do not fit the ring (row span > kRR - 2, column span > kRW - 8:
+//     strong rotations, large magnification) carry global element offsets in their records and
+//     are gathered as before; steps the ring cannot serve at that moment (rows running
+//     backwards) rebuild the element offsets from the ring addresses; footprints touching the
+//     source border are redone tap by tap through sample().  Same arithmetic and summation
+//     order as wave_stencil.hpp / sampler.hpp: bit-identical to the per-frame kernels.
 //
 // Reference semantics: camera/LensDistortion.py:323-326 (cv2.remap INTER_LINEAR,
 // BORDER_CONSTANT), camera/PerspectiveCorrection.py:377-378 followed by a dense K x K filter
@@ -35,17 +37,35 @@
 
 namespace ipa {
 
-constexpr int kGW = 4;                    // waves (= frames) per workgroup = rows per chunk
-constexpr int kRR = 8;                    // ring rows (power of two)
-constexpr int kRW = 320;                  // ring row length (pixels)
+constexpr int kGW = 4;                        // waves (= frames) per workgroup = steps per chunk
+constexpr int kSW = 128;                      // strip width (2 px per lane in the filter stage)
+constexpr int kRR = 8;                        // ring rows (power of two)
+constexpr int kRW = 160;                      // ring row length (pixels)
 constexpr int kRingFloats = (kRR + 1) * kRW;  // slot kRR mirrors slot 0
-constexpr int kRecFloats = 3 * 256;       // per row: 256 slots, 256 x-fractions, 256 y-fractions
+constexpr int kRecFloats = 3 * 256;           // per step: 256 slots, x fractions, y fractions
+constexpr int kXRow = kSW + 2 * kRowPad;      // staged sample row (+ pad on both sides)
 #ifndef IPA_GROUP_PEND
-#define IPA_GROUP_PEND 5
+#define IPA_GROUP_PEND 10
 #endif
-constexpr int kPend = IPA_GROUP_PEND;     // source rows prefetched per chunk (registers)
+constexpr int kPend = IPA_GROUP_PEND;         // source rows prefetched per chunk (registers)
 
-enum : int { kRowSkip = 1, kRowConst = 2, kRowRing = 4, kRowSlow = 8, kRowAny = 16 };
+// step flags (meta word 0)
+enum : int {
+  kStepSkip = 1,     // past the strip
+  kStepRing = 4,     // records hold ring addresses (else element offsets)
+  kStepSlow = 8,     // some footprints touch the source border
+  kStepAny = 16,     // some footprint lies wholly inside the source
+  kRow0Const = 32,   // row 0 / 1 of the step is a constant filter-border row
+  kRow1Const = 64,
+  kRow1Skip = 128,   // odd number of input rows: row 1 of the last step does not exist
+  kStepServ = 256    // (planner) the ring serves this step
+};
+
+template <int K> struct group_geom {
+  static constexpr int H = K / 2;
+  static constexpr int HL = (H + 1) / 2;      // halo lanes per side (2 px per lane)
+  static constexpr int OW = kSW - 4 * HL;     // output pixels per strip row
+};
 
 template <typename ST, typename Coord> struct GroupSrc {
   Coord coord;
@@ -57,7 +77,7 @@ template <typename ST, typename Coord> struct GroupSrc {
   float cval;            // remap border value
   float ccval;           // filter border value
   int n_frames;
-  int use_ring;          // 0: every row gathers (tuning / A-B knob)
+  int use_ring;          // 0: every step gathers (tuning / A-B knob)
 };
 
 // min / max over the 64 lanes (all active), result wave-uniform
@@ -73,6 +93,32 @@ template <bool MAX> __device__ __forceinline__ int wave_minmax(int v) {
 #undef IPA_MM
   return __builtin_amdgcn_readlane(v, 63);
 }
+__device__ __forceinline__ void wave_span(int& xmn, int& xmx, int& ymn, int& ymx) {
+  xmn = wave_minmax<false>(xmn);
+  xmx = wave_minmax<true>(xmx);
+  ymn = wave_minmax<false>(ymn);
+  ymx = wave_minmax<true>(ymx);
+}
+
+// v_pk_fma_f32 / v_pk_mul_f32 with ONE coefficient of an SGPR pair broadcast to both halves
+// (op_sel): the K * K coefficients then take K * K scalar registers, not 2 * K * K as the
+// {w, w} pairs the compiler forms on its own
+template <int HI> __device__ __forceinline__ v2f pk_fma_coef(v2f wp, v2f x, v2f c) {
+  v2f d;
+  if constexpr (HI)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
+  return d;
+}
+template <int HI> __device__ __forceinline__ v2f pk_mul_coef(v2f wp, v2f x) {
+  v2f d;
+  if constexpr (HI)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "s"(wp), "v"(x));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(wp), "v"(x));
+  return d;
+}
 
 // LDS-only workgroup barrier: __syncthreads() would also drain the vector-memory counter,
 // i.e. wait for the prefetched source rows and the output stores at every chunk
@@ -80,73 +126,41 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// one source row of the ring window (kRW px from element offset eo) in registers
+// one source row of the ring window (kRW px from element offset eo) in registers:
+// 2 px per lane (128 px) + 1 px (32 px; lanes 32..63 duplicate the lanes 0..31)
 template <typename ST> struct PendRow;
 template <> struct PendRow<float> {
-  float a[4];
+  float a[2];
   float b;
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int eo, unsigned lane) {
     // range-checked per dword: columns left / right of the frame read neighbouring rows or 0,
     // never used (only footprints wholly inside the frame sample from the ring)
-    auto r = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (eo + 4 * (int)lane) << 2, 0, 0);
-    a[0] = u2f(r[0]); a[1] = u2f(r[1]); a[2] = u2f(r[2]); a[3] = u2f(r[3]);
-    b = u2f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (eo + 256 + (int)lane) << 2, 0, 0));
+    auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (eo + 2 * (int)lane) << 2, 0, 0);
+    a[0] = u2f(r[0]); a[1] = u2f(r[1]);
+    b = u2f(__builtin_amdgcn_raw_buffer_load_b32(rsrc, (eo + 128 + (int)(lane & 31u)) << 2, 0, 0));
   }
   __device__ __forceinline__ void write(float* row, unsigned lane) const {
-    *reinterpret_cast<float4*>(row + 4u * lane) = float4{a[0], a[1], a[2], a[3]};
-    row[256u + lane] = b;
+    *reinterpret_cast<float2*>(row + 2u * lane) = float2{a[0], a[1]};
+    row[128u + (lane & 31u)] = b;  // both halves of the wave store the same value
   }
 };
 template <> struct PendRow<uint16_t> {
-  unsigned a[2];
+  unsigned a;
   unsigned b;
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, int eo, unsigned lane) {
-    auto r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (eo + 4 * (int)lane) << 1, 0, 0);
-    a[0] = r[0]; a[1] = r[1];
-    b = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (eo + 256 + 2 * (int)(lane & 31u)) << 1, 0, 0);
+    a = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (eo + 2 * (int)lane) << 1, 0, 0);
+    b = (unsigned short)__builtin_amdgcn_raw_buffer_load_b16(
+        rsrc, (eo + 128 + (int)(lane & 31u)) << 1, 0, 0);
   }
   __device__ __forceinline__ void write(float* row, unsigned lane) const {
-    *reinterpret_cast<float4*>(row + 4u * lane) =
-        float4{(float)(a[0] & 0xffffu), (float)(a[0] >> 16), (float)(a[1] & 0xffffu),
-               (float)(a[1] >> 16)};
-    if (lane < 32u)
-      *reinterpret_cast<float2*>(row + 256u + 2u * lane) =
-          float2{(float)(b & 0xffffu), (float)(b >> 16)};
+    *reinterpret_cast<float2*>(row + 2u * lane) = float2{(float)(a & 0xffffu), (float)(a >> 16)};
+    row[128u + (lane & 31u)] = (float)b;
   }
 };
-
-// state of a wave's ring: rows [lo, hi) of the frame are resident, columns [xlo, xlo + kRW)
-struct RingState {
-  int xlo, lo, hi;
-};
-
-// The ring rule, shared by the consumer and by the planner that runs one chunk ahead of it:
-// a row needs source rows [ymin, ymax + 2) and columns [xmin, xmax + 1].  Returns the first row
-// that has to be loaded (rows [first, ymax + 2) are then appended).
-__device__ __forceinline__ int ring_advance(RingState& r, int xmin, int xmax, int ymin, int ymax,
-                                            bool& restarted) {
-  restarted = false;
-  if (r.lo == r.hi || xmin < r.xlo || xmax + 2 > r.xlo + kRW) {
-    // new column window (16-byte aligned origin, 4-7 px of slack on the left): start over
-    r.xlo = (xmin & ~3) - 4;
-    r.lo = r.hi = ymin;
-    restarted = true;
-  } else if (ymin < r.lo || ymin > r.hi) {
-    r.lo = r.hi = ymin;
-    restarted = true;
-  }
-  const int first = r.hi;
-  const int need_hi = ymax + 2;
-  if (need_hi > r.hi) {
-    r.hi = need_hi;
-    r.lo = r.lo > r.hi - kRR ? r.lo : r.hi - kRR;
-  }
-  return first;
-}
 
 template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
   using C = typename Coord::coord_t;
-  using G = wave_geom<K>;
+  using G = group_geom<K>;
   using Src = GroupSrc<ST, Coord>;
   static constexpr bool kMap = std::is_same<Coord, MapCoord>::value;
   static constexpr int kLead = G::H > kRowPad ? 4 : 0;
@@ -155,56 +169,64 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
     float rec[2][kGW][kRecFloats];
     int meta[2][kGW][8];
     float ring[kGW][kRingFloats];
-    float xrow[kLead + kGW * kRowStride + kLead];
+    float xrow[kLead + kGW * 2 * kXRow + kLead];
   };
 
-  // ---- coordinates of the 4 lane-interleaved samples of one row -------------------------
+  // columns of the strip a lane samples (lane-interleaved: xs + lane + 64 q), border-resolved
+  struct SCols {
+    int xs;       // first column of the strip (scalar)
+    int uq[2];    // resolved sample columns, -1 = constant filter border (rim strips only)
+  };
+
+  // ---- coordinates of the 4 samples of a step (k = 2 * row + column group) ---------------
   template <bool FAST>
-  static __device__ __forceinline__ void coords_of_row(const Src& g, const Cols& c, int vv,
-                                                       C (&sx)[4], C (&sy)[4]) {
+  static __device__ __forceinline__ void coords_of_step(const Src& g, const SCols& c, int vv0,
+                                                        int vv1, C (&sx)[4], C (&sy)[4]) {
     const int lane = threadIdx.x & 63;
-    const int v = (!FAST && vv < 0) ? 0 : vv;
+    const int v[2] = {vv0 < 0 ? 0 : vv0, vv1 < 0 ? 0 : vv1};
     if constexpr (kMap) {
-      if constexpr (FAST) {
-        const long o = (long)v * g.coord.pitch + c.xs;  // scalar
-        const float* rx = g.coord.mx + o;
-        const float* ry = g.coord.my + o;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          sx[k] = rx[(unsigned)lane + 64u * k];
-          sy[k] = ry[(unsigned)lane + 64u * k];
-        }
-      } else {
-        const float* rx = g.coord.mx + (long)v * g.coord.pitch;
-        const float* ry = g.coord.my + (long)v * g.coord.pitch;
+      for (int r = 0; r < 2; r++) {
+        if constexpr (FAST) {
+          const long o = (long)v[r] * g.coord.pitch + c.xs;  // scalar
+          const float* rx = g.coord.mx + o;
+          const float* ry = g.coord.my + o;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const unsigned u = (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]);
-          sx[k] = rx[u];
-          sy[k] = ry[u];
+          for (int q = 0; q < 2; q++) {
+            sx[2 * r + q] = rx[(unsigned)lane + 64u * q];
+            sy[2 * r + q] = ry[(unsigned)lane + 64u * q];
+          }
+        } else {
+          const float* rx = g.coord.mx + (long)v[r] * g.coord.pitch;
+          const float* ry = g.coord.my + (long)v[r] * g.coord.pitch;
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            const unsigned u = (unsigned)(c.uq[q] < 0 ? 0 : c.uq[q]);
+            sx[2 * r + q] = rx[u];
+            sy[2 * r + q] = ry[u];
+          }
         }
       }
     } else {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if constexpr (FAST) g.coord.get(c.xs + lane + 64 * k, v, sx[k], sy[k]);
-        else g.coord.get(c.uq[k] < 0 ? 0 : c.uq[k], v, sx[k], sy[k]);
+        const int r = k >> 1, q = k & 1;
+        if constexpr (FAST) g.coord.get(c.xs + lane + 64 * q, v[r], sx[k], sy[k]);
+        else g.coord.get(c.uq[q] < 0 ? 0 : c.uq[q], v[r], sx[k], sy[k]);
       }
     }
   }
 
-  // ---- producer: one row of coordinates -> footprint records + row span ------------------
+  // ---- producer: one step of coordinates -> footprint records + span -----------------------
+  // rowflags: kStepSkip / kRow0Const / kRow1Const / kRow1Skip of this step
   template <bool FAST>
-  static __device__ __forceinline__ void produce_row(const Src& g, const SrcView& s, const Cols& c,
-                                                     int vv, bool skip, const C (&sx)[4],
-                                                     const C (&sy)[4], float* rec, int* meta) {
+  static __device__ __forceinline__ void produce_step(const Src& g, const SrcView& s,
+                                                      const SCols& c, int rowflags,
+                                                      const C (&sx)[4], const C (&sy)[4],
+                                                      float* rec, int* meta) {
     const unsigned lane = threadIdx.x & 63u;
-    if (skip) {
-      if (lane == 0) meta[0] = kRowSkip;
-      return;
-    }
-    if (!FAST && vv < 0) {  // constant filter border: the whole row is the border value
-      if (lane == 0) meta[0] = kRowConst;
+    if (rowflags & kStepSkip) {
+      if (lane == 0) meta[0] = kStepSkip;
       return;
     }
     int ix0[4], iy0[4];
@@ -214,26 +236,25 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
     bool slow = false;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+      const int r = k >> 1, q = k & 1;
       const bool ok = sx[k] > (C)-kCoordLimit && sx[k] < (C)kCoordLimit &&
                       sy[k] > (C)-kCoordLimit && sy[k] < (C)kCoordLimit;
-      axis_frac<kLinear, float, C, -1>(s, ok ? sx[k] : (C)0, ix0[k], tx[k]);
-      axis_frac<kLinear, float, C, -1>(s, ok ? sy[k] : (C)0, iy0[k], ty[k]);
+      axis_frac<kLinear, float, C, 0>(s, ok ? sx[k] : (C)0, ix0[k], tx[k]);
+      axis_frac<kLinear, float, C, 0>(s, ok ? sy[k] : (C)0, iy0[k], ty[k]);
       const bool inside = ok && ix0[k] >= 0 && iy0[k] >= 0 && ix0[k] + 2 <= s.w && iy0[k] + 2 <= s.h;
-      // columns of a constant filter border are replaced by the consumer: not sampled at all
-      const bool live = FAST ? true : c.uq[k] >= 0;
+      // constant filter-border rows / columns are replaced by the consumer: not sampled
+      bool live = !(rowflags & (r == 0 ? kRow0Const : (kRow1Const | kRow1Skip)));
+      if constexpr (!FAST) live = live && c.uq[q] >= 0;
       in[k] = inside && live;
       slow = slow || (!inside && live);
-      if (in[k]) {
-        xmn = ix0[k] < xmn ? ix0[k] : xmn;
-        xmx = ix0[k] > xmx ? ix0[k] : xmx;
-        ymn = iy0[k] < ymn ? iy0[k] : ymn;
-        ymx = iy0[k] > ymx ? iy0[k] : ymx;
-      }
+      const int xl = in[k] ? ix0[k] : INT_MAX, xh = in[k] ? ix0[k] : INT_MIN;
+      const int yl = in[k] ? iy0[k] : INT_MAX, yh = in[k] ? iy0[k] : INT_MIN;
+      xmn = xl < xmn ? xl : xmn;
+      xmx = xh > xmx ? xh : xmx;
+      ymn = yl < ymn ? yl : ymn;
+      ymx = yh > ymx ? yh : ymx;
     }
-    xmn = wave_minmax<false>(xmn);
-    xmx = wave_minmax<true>(xmx);
-    ymn = wave_minmax<false>(ymn);
-    ymx = wave_minmax<true>(ymx);
+    wave_span(xmn, xmx, ymn, ymx);
     const bool any = xmn <= xmx;
     const bool any_slow = __builtin_amdgcn_ballot_w64(slow) != 0;
     const bool ring = g.use_ring &&
@@ -251,22 +272,19 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
     *reinterpret_cast<float4*>(rec + 256 + 4u * lane) = float4{tx[0], tx[1], tx[2], tx[3]};
     *reinterpret_cast<float4*>(rec + 512 + 4u * lane) = float4{ty[0], ty[1], ty[2], ty[3]};
     if (lane == 0) {
-      meta[0] = (ring ? kRowRing : 0) | (any ? kRowAny : 0) | (any_slow ? kRowSlow : 0);
+      meta[0] = rowflags | (ring ? kStepRing : 0) | (any ? kStepAny : 0) | (any_slow ? kStepSlow : 0);
       meta[1] = xmn; meta[2] = xmx; meta[3] = ymn; meta[4] = ymx;
     }
   }
 
-  // ---- K x K step on one staged row (same chain as wave_run_strip) -------------------------
-  static __device__ __forceinline__ void filter_step(v2f (&acc)[K][2], const float* xp,
-                                                     unsigned lane, unsigned lane4_opaque,
-                                                     const Weights<float, K * K>& wts,
-                                                     kernarg_f32 wk) {
-    const float* wp = xp + kRowPad - G::H + 4u * lane;
-    const float* wq = xp + kRowPad - G::H + lane4_opaque;
-    v2f pair[K + 2];
+  // ---- K x K step on one staged row of 128 px: the chain of wave_run_strip, one pair / lane ----
+  static __device__ __forceinline__ void filter_row(v2f (&acc)[K], const float* xr, unsigned lane,
+                                                    const Weights<float, K * K>& wts,
+                                                    kernarg_f32 wk) {
+    const float* wp = xr + kRowPad - G::H + 2u * lane;
+    v2f pair[K];
 #pragma unroll
-    for (int m = 0; m < K + 2; m++)
-      pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+    for (int m = 0; m < K; m++) pair[m] = v2f{wp[m], wp[m + 1]};
 
 #define IPA_LOAD_COEF_ROW(r)                                                                  \
   asm volatile("s_load_dwordx4 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\t"                    \
@@ -284,200 +302,238 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
           asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]));
         else
           asm volatile("s_waitcnt lgkmcnt(0)"
-                       : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]), "+v"(acc[i + 1][0]),
-                         "+v"(acc[i + 1][1]));
+                       : "+s"(cc[i][0]), "+s"(cc[i][1]), "+s"(cc[i][2]), "+v"(acc[i + 1]));
         if constexpr (i > 0) {
-          asm volatile("s_load_dwordx4 %0, %5, %6\n\ts_load_dwordx4 %1, %5, %7\n\t"
-                       "s_load_dwordx4 %2, %5, %8"
+          asm volatile("s_load_dwordx4 %0, %4, %5\n\ts_load_dwordx4 %1, %4, %6\n\t"
+                       "s_load_dwordx4 %2, %4, %7"
                        : "=&s"(cc[i - 1][0]), "=&s"(cc[i - 1][1]), "=&s"(cc[i - 1][2]),
-                         "+v"(acc[i - 1][0]), "+v"(acc[i - 1][1])
+                         "+v"(acc[i - 1])
                        : "s"(wk), "n"((i - 1) * 48), "n"((i - 1) * 48 + 16),
                          "n"((i - 1) * 48 + 32));
         }
       }
+      if constexpr (STREAM) {
 #pragma unroll
-      for (int j = 0; j < K; j++) {
-        float w;
-        if constexpr (STREAM) w = cc[i][j >> 2][j & 3];
-        else w = wts.w[i * K + j];
-        const v2f w2 = v2f{w, w};
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int j = 0; j < K; j++) {
+          const float w = cc[i][j >> 2][j & 3];
+          const v2f w2 = v2f{w, w};
           if constexpr (i == 0) {
-            acc[0][h] = j == 0 ? w2 * pair[2 * h]
-                               : __builtin_elementwise_fma(w2, pair[j + 2 * h], acc[0][h]);
+            acc[0] = j == 0 ? w2 * pair[0] : __builtin_elementwise_fma(w2, pair[j], acc[0]);
           } else {
-            acc[i][h] = __builtin_elementwise_fma(w2, pair[j + 2 * h],
-                                                  j == 0 ? acc[i - 1][h] : acc[i][h]);
+            acc[i] = __builtin_elementwise_fma(w2, pair[j], j == 0 ? acc[i - 1] : acc[i]);
           }
         }
+      } else {
+        static_for<0, K>([&](auto Jj) {
+          constexpr int j = decltype(Jj)::value;
+          constexpr int n = i * K + j;
+          constexpr int n0 = n & ~1, n1 = n0 + 1 < K * K ? n0 + 1 : n0;
+          const v2f wp2 = v2f{wts.w[n0], wts.w[n1]};
+          if constexpr (i == 0 && j == 0) acc[0] = pk_mul_coef<(n & 1)>(wp2, pair[0]);
+          else if constexpr (j == 0) acc[i] = pk_fma_coef<(n & 1)>(wp2, pair[0], acc[i - 1]);
+          else acc[i] = pk_fma_coef<(n & 1)>(wp2, pair[j], acc[i]);
+        });
       }
       if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
     });
   }
 
   // ---- one strip of one group ---------------------------------------------------------------
-  struct RowMeta {
-    int flags, xmin, xmax, ymin, ymax;
-  };
-
-  // Pipeline of a strip (chunk = kGW rows, ci = chunk being consumed):
-  //   a. produce the records of chunk ci + 1 (this wave: one row; coordinates were loaded
-  //      during the previous iteration)                                      | barrier X
-  //   b. read the spans of chunk ci + 1, plan its ring traffic, ISSUE those source-row loads
-  //      and the coordinate loads of chunk ci + 2 - nothing waits for them here
-  //   c. consume chunk ci: rows software-pipelined by one (taps of row d + 1 are issued
-  //      before row d is blended and filtered); needs no vector-memory result of b.
-  //   d. the prefetched rows / spans become the current ones                 | barrier Y
-  // The loop starts at ci = -1 (nothing to consume) so that the rows a chunk consumes always
-  // come out of step d: no vector-memory wait lands inside step c.
+  // Pipeline (chunk = kGW steps of 2 rows, ci = chunk being consumed):
+  //   a. produce the records of chunk ci + 1 (this wave: one step; its coordinates were loaded
+  //      two iterations ago)                                                   | barrier X
+  //   b. consume chunk ci: steps software-pipelined by one (the taps of step d + 1 are issued
+  //      before step d is blended and filtered); waits for no vector-memory result issued in
+  //      this iteration
+  //   c. plan: lanes 0..3 turn the spans of chunk ci + 1 into the ring schedule (which
+  //      prefetched row goes in before which step)
+  //   d. issue the coordinate loads of chunk ci + 3 and the source-row loads of chunk ci + 1
+  //      (in this order: waiting for the rows never waits for younger loads)    | barrier Y
   template <bool FAST>
   static __device__ __forceinline__ void run_strip(const WaveParams& p, const Src& g,
                                                    const SrcView& s,
                                                    const Weights<float, K * K>& wts, kernarg_f32 wk,
-                                                   const Cols& c, int y0, int nrows, bool writer,
-                                                   bool active, float* dst, Shared& sh,
-                                                   unsigned wave) {
-    const int T = nrows + K - 1;  // input rows of the strip
-    const int nchunks = (T + kGW - 1) / kGW;
+                                                   const SCols& c, int xo, int y0, int nrows,
+                                                   bool writer, bool active, float* dst,
+                                                   Shared& sh, unsigned wave) {
+    const int T = nrows + K - 1;            // input rows of the strip
+    const int nsteps = (T + 1) / 2;
+    const int nchunks = (nsteps + kGW - 1) / kGW;
     const unsigned lane = threadIdx.x & 63u;
-    unsigned lane4_opaque = 4u * lane;
-    asm volatile("" : "+v"(lane4_opaque));
-    float* xp = sh.xrow + kLead + wave * kRowStride;
+    float* xp = sh.xrow + kLead + wave * 2 * kXRow;
     float* ringw = sh.ring[wave];
 
     auto row_of = [&](int t) -> int {
       if constexpr (FAST) return y0 - G::H + t;
       else return resolve_idx(y0 - G::H + t, p.dh, p.cby);
     };
-    // the row this wave turns into records in chunk ci (clamped: rows past the strip are skipped)
-    auto prod_row = [&](int ci) -> int {
-      int t = kGW * ci + (int)wave;
-      return row_of(t < T ? t : T - 1);
+    // rows / flags of step st (clamped to the strip)
+    auto step_rows = [&](int st, int& vv0, int& vv1) -> int {
+      int flags = 0;
+      if (st >= nsteps) {
+        flags = kStepSkip;
+        st = nsteps - 1;
+      }
+      const int t0 = 2 * st;
+      vv0 = row_of(t0);
+      if (t0 + 1 < T) {
+        vv1 = row_of(t0 + 1);
+      } else {
+        vv1 = vv0;
+        flags |= kRow1Skip;
+      }
+      if constexpr (!FAST) {
+        if (vv0 < 0) flags |= kRow0Const;
+        if (vv1 < 0) flags |= kRow1Const;
+      }
+      return flags;
     };
 
-    C cx[4], cy[4];          // coordinates of the row this wave produces next
-    RingState rs{0, 0, 0};   // what the ring holds now
-    RingState ps{0, 0, 0};   // the same state one chunk ahead (planner)
+    C cxa[4], cya[4];  // coordinates of the step this wave produces next
+    C cxb[4], cyb[4];  // ... and of the one after it (in flight)
     PendRow<ST> pend[kPend];
-    int pbase = 0, pn = 0, pxlo = 0;
-    RowMeta mcur[kGW];
+    // ring state (uniform): rows [max(ringL, ringH - kRR), ringH) resident with window xlo
+    int xlo = 0, ringH = 0, ringL = 0;
+    bool ring_empty = true;
+    // schedule of the chunk being consumed / of the next one
+    int wmC[kGW], flC[kGW];
+    int pbaseC = 0, pnC = 0;
 #pragma unroll
-    for (int d = 0; d < kGW; d++) mcur[d] = RowMeta{kRowSkip, 0, 0, 0, 0};
+    for (int d = 0; d < kGW; d++) { wmC[d] = 0; flC[d] = kStepSkip; }
 
+    auto load_coords = [&](int ci, C (&ox)[4], C (&oy)[4]) {
+      int vv0, vv1;
+      step_rows(kGW * ci + (int)wave, vv0, vv1);
+      coords_of_step<FAST>(g, c, vv0, vv1, ox, oy);
+    };
     auto produce = [&](int ci) {
-      const int t = kGW * ci + (int)wave;
-      const int vv = prod_row(ci);
-      if constexpr (!kMap) coords_of_row<FAST>(g, c, vv, cx, cy);
-      produce_row<FAST>(g, s, c, vv, t >= T, cx, cy, sh.rec[ci & 1][wave], sh.meta[ci & 1][wave]);
+      int vv0, vv1;
+      const int rf = step_rows(kGW * ci + (int)wave, vv0, vv1);
+      if constexpr (!kMap) coords_of_step<FAST>(g, c, vv0, vv1, cxa, cya);
+      produce_step<FAST>(g, s, c, rf, cxa, cya, sh.rec[ci & 1][wave], sh.meta[ci & 1][wave]);
     };
-    // spans of chunk ci (its records are visible) -> scalars; plan the ring traffic and issue
-    // the row loads
-    auto plan = [&](int ci, PendRow<ST> (&pr)[kPend], RowMeta (&mm)[kGW], int& nbase, int& nn,
-                    int& nxlo) {
-      nn = 0; nbase = 0; nxlo = 0;
-      bool stop = false;
+    // lanes 0..3 = the steps of chunk ci: spans -> ring schedule (all waves compute the same)
+    auto plan = [&](int ci) {
+      const unsigned dl = lane < (unsigned)kGW ? lane : (unsigned)kGW - 1u;
+      const int* m = sh.meta[ci & 1][dl];
+      const int f = m[0], xmin = m[1], xmax = m[2], ymin = m[3], ymax = m[4];
+      const bool ring = (f & (kStepRing | kStepAny | kStepSkip)) == (kStepRing | kStepAny);
+      bool fit = xmin >= xlo && xmax + 2 <= xlo + kRW;
+      const unsigned rmask = (unsigned)__builtin_amdgcn_ballot_w64(ring) & 0xfu;
+      const unsigned bad = (unsigned)__builtin_amdgcn_ballot_w64(ring && !fit) & 0xfu;
+      if (rmask && (bad || ring_empty)) {
+        // new column window (16-byte aligned origin, 4-7 px of slack on the left) and a fresh
+        // start at the first ring step of this chunk
+        int xm = INT_MAX;
 #pragma unroll
-      for (int d = 0; d < kGW; d++) {
-        const int* m = sh.meta[ci & 1][d];
-        mm[d].flags = __builtin_amdgcn_readfirstlane(m[0]);
-        mm[d].xmin = __builtin_amdgcn_readfirstlane(m[1]);
-        mm[d].xmax = __builtin_amdgcn_readfirstlane(m[2]);
-        mm[d].ymin = __builtin_amdgcn_readfirstlane(m[3]);
-        mm[d].ymax = __builtin_amdgcn_readfirstlane(m[4]);
-      }
-#pragma unroll
-      for (int d = 0; d < kGW; d++) {
-        if ((mm[d].flags & (kRowRing | kRowAny | kRowSkip)) == (kRowRing | kRowAny)) {
-          bool restarted;
-          const int first = ring_advance(ps, mm[d].xmin, mm[d].xmax, mm[d].ymin, mm[d].ymax,
-                                         restarted);
-          if (restarted && nn > 0) stop = true;
-          const int add = mm[d].ymax + 2 - first;
-          if (add > 0 && !stop) {
-            if (nn == 0) { nbase = first; nxlo = ps.xlo; }
-            if (nbase + nn == first && nxlo == ps.xlo) {
-              const int take = add < kPend - nn ? add : kPend - nn;
-              nn += take;
-              if (take < add) stop = true;
-            } else {
-              stop = true;
-            }
-          }
+        for (int d = 0; d < kGW; d++) {
+          const int v = __builtin_amdgcn_readlane(xmin, d);
+          if ((rmask >> d) & 1u) xm = v < xm ? v : xm;
         }
-      }
+        xlo = (xm & ~3) - 4;
+        const int fd = __builtin_ctz(rmask);
+        int y = 0;
 #pragma unroll
-      for (int j = 0; j < kPend; j++)
-        if (j < nn) pr[j].load(s.rsrc, __mul24(nbase + j, s.pitch) + nxlo, lane);
+        for (int d = 0; d < kGW; d++) {
+          const int v = __builtin_amdgcn_readlane(ymin, d);
+          if (d == fd) y = v;
+        }
+        ringH = ringL = y;
+        ring_empty = false;
+        fit = xmin >= xlo && xmax + 2 <= xlo + kRW;
+      }
+      // rows each step needs up to (exclusive), running maximum over the chunk
+      const int need = (ring && fit) ? ymax + 2 : INT_MIN;
+      int hd = need > ringH ? need : ringH;
+      int t;
+      t = __builtin_amdgcn_update_dpp(hd, hd, 0x111 /*row_shr:1*/, 0xf, 0xf, false);
+      hd = t > hd ? t : hd;
+      t = __builtin_amdgcn_update_dpp(hd, hd, 0x112 /*row_shr:2*/, 0xf, 0xf, false);
+      hd = t > hd ? t : hd;
+      int hprev = __builtin_amdgcn_update_dpp(hd, hd, 0x111, 0xf, 0xf, false);
+      hprev = lane == 0 ? ringH : hprev;
+      const int first = hprev > hd - kRR ? hprev : hd - kRR;  // a jump ahead loads the last kRR only
+      const int cnt = hd - first;
+      const int shift = first - ringH;
+      const int lowest = ringL > hd - kRR ? ringL : hd - kRR;
+      const bool serv = ring && fit && ymin >= lowest && hd - ringH <= 24;
+      const int wm = (cnt > 0 && shift < 24) ? (int)(((1u << cnt) - 1u) << shift) : 0;
+      const int fl = f | (serv ? kStepServ : 0);
+      pbaseC = ringH;
+#pragma unroll
+      for (int d = 0; d < kGW; d++) {
+        wmC[d] = __builtin_amdgcn_readlane(wm, d);
+        flC[d] = __builtin_amdgcn_readlane(fl, d);
+      }
+      const int hnew = __builtin_amdgcn_readlane(hd, kGW - 1);
+      if (hnew - ringH > 24) ring_empty = true;  // absurd jump: served by gathers, start over
+      pnC = hnew - ringH < kPend ? hnew - ringH : kPend;
+      ringH = hnew;
     };
+    auto ring_slot = [&](int y) -> float* { return ringw + (y & (kRR - 1)) * kRW; };
 
-    if constexpr (kMap) coords_of_row<FAST>(g, c, prod_row(0), cx, cy);
+    if constexpr (kMap) {
+      load_coords(0, cxa, cya);
+      if (nchunks > 1) load_coords(1, cxb, cyb);
+    }
 
-    v2f acc[K][2];
+    v2f acc[K];
 #pragma unroll 1
     for (int ci = -1; ci < nchunks; ci++) {
       // a. records of the next chunk (other buffer)
       if (ci + 1 < nchunks) produce(ci + 1);
-      lds_barrier();  // X: records of chunk ci + 1 visible
+      lds_barrier();  // X: records + spans of chunk ci + 1 visible
 
-      // b. spans + ring rows of the next chunk, coordinates of the one after it: in flight
-      //    while this chunk is consumed
-      PendRow<ST> pnext[kPend];
-      RowMeta mnext[kGW];
-#pragma unroll
-      for (int d = 0; d < kGW; d++) mnext[d] = RowMeta{kRowSkip, 0, 0, 0, 0};
-      int nbase = 0, nn = 0, nxlo = 0;
-      if (active && ci + 1 < nchunks) plan(ci + 1, pnext, mnext, nbase, nn, nxlo);
-      if constexpr (kMap)
-        if (ci + 2 < nchunks) coords_of_row<FAST>(g, c, prod_row(ci + 2), cx, cy);
-
-      // c. consume chunk ci
+      // b. consume chunk ci (window xlo, rows pend[j] = pbaseC + j)
       if (active && ci >= 0) {
         const int cb = ci & 1;
-        float4 rs4[kGW], rx4[kGW], ry4[kGW];  // records of the rows in flight
-        float v[2][4][2][2];                  // taps of two rows (even / odd d)
+        float4 rs4[kGW], rx4[kGW], ry4[kGW];  // records of the steps in flight
+        float v[2][4][2][2];                  // taps of two steps (even / odd d)
 
         auto load_rec = [&](auto Dd) {
           constexpr int d = decltype(Dd)::value;
-          if (mcur[d].flags & (kRowSkip | kRowConst)) return;
+          if (flC[d] & kStepSkip) return;
           const float* r = sh.rec[cb][d];
           rs4[d] = *reinterpret_cast<const float4*>(r + 4u * lane);
           rx4[d] = *reinterpret_cast<const float4*>(r + 256 + 4u * lane);
           ry4[d] = *reinterpret_cast<const float4*>(r + 512 + 4u * lane);
         };
-        // stage A of a row: make its source rows resident, issue its taps
+        // stage A of a step: make its source rows resident, issue its taps
         auto stage_a = [&](auto Dd) {
           constexpr int d = decltype(Dd)::value;
-          const RowMeta m = mcur[d];
-          if (m.flags & (kRowSkip | kRowConst)) return;
-          const int sl[4] = {__float_as_int(rs4[d].x), __float_as_int(rs4[d].y),
-                             __float_as_int(rs4[d].z), __float_as_int(rs4[d].w)};
-          if (m.flags & kRowRing) {
-            if (m.flags & kRowAny) {
-              bool restarted;
-              int y = ring_advance(rs, m.xmin, m.xmax, m.ymin, m.ymax, restarted);
-              const int need_hi = m.ymax + 2;
-              // rows prefetched for this chunk, in order
+          const int fl = flC[d];
+          if (fl & kStepSkip) return;
+          int sl[4] = {__float_as_int(rs4[d].x), __float_as_int(rs4[d].y),
+                       __float_as_int(rs4[d].z), __float_as_int(rs4[d].w)};
+          // source rows scheduled in front of this step (also when it is not served itself:
+          // later steps count on them)
+          const int wm = wmC[d];
+          if (wm) {
 #pragma unroll
-              for (int j = 0; j < kPend; j++) {
-                if (j < pn && pxlo == rs.xlo && pbase + j == y && y < need_hi) {
-                  pend[j].write(ringw + (y & (kRR - 1)) * kRW, lane);
-                  if ((y & (kRR - 1)) == 0) pend[j].write(ringw + kRR * kRW, lane);
-                  y++;
-                }
-              }
-              // whatever the prefetch did not cover (restarts, tall spans)
-#pragma unroll 1
-              for (; y < need_hi; y++) {
-                PendRow<ST> q;
-                q.load(s.rsrc, __mul24(y, s.pitch) + rs.xlo, lane);
-                q.write(ringw + (y & (kRR - 1)) * kRW, lane);
-                if ((y & (kRR - 1)) == 0) q.write(ringw + kRR * kRW, lane);
+            for (int j = 0; j < kPend; j++) {
+              if ((wm >> j) & 1) {
+                const int y = pbaseC + j;
+                pend[j].write(ring_slot(y), lane);
+                if ((y & (kRR - 1)) == 0) pend[j].write(ringw + kRR * kRW, lane);
               }
             }
-            // taps: 4 reads at immediate offsets from one address; reads beyond the
-            // allocation return 0, so unused (-1) slots need no guard
-            const char* rb = reinterpret_cast<const char*>(ringw) - 4 * rs.xlo;
+            if (wm >> kPend) {  // more rows than the prefetch holds: load them now
+#pragma unroll 1
+              for (int j = kPend; (wm >> j) != 0; j++) {
+                if ((wm >> j) & 1) {
+                  const int y = pbaseC + j;
+                  PendRow<ST> q;
+                  q.load(s.rsrc, __mul24(y, s.pitch) + xlo, lane);
+                  q.write(ring_slot(y), lane);
+                  if ((y & (kRR - 1)) == 0) q.write(ringw + kRR * kRW, lane);
+                }
+              }
+            }
+          }
+          if (fl & kStepServ) {
+            // taps: two 2-dword reads per footprint row from one computed address; reads beyond
+            // the allocation return 0, so unused (-1) slots need no guard
+            const char* rb = reinterpret_cast<const char*>(ringw) - 4 * xlo;
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const float* tp = reinterpret_cast<const float*>(rb + sl[k]);
@@ -487,6 +543,21 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
               v[d & 1][k][1][1] = tp[kRW + 1];
             }
           } else {
+            if (fl & kStepRing) {
+              // ring addresses the ring cannot serve now: back to element offsets
+              const int* m = sh.meta[cb][d];
+              const int xmin = __builtin_amdgcn_readfirstlane(m[1]);
+              const int ymin = __builtin_amdgcn_readfirstlane(m[3]);
+#pragma unroll
+              for (int k = 0; k < 4; k++) {
+                const unsigned u = (unsigned)((sl[k] >> 2) - xmin);   // slot * kRW + ix0 - xmin
+                static_assert(kRW == 160, "the reciprocal below is 1 / kRW");
+                const unsigned slot = (unsigned)(((unsigned long)u * 52429ul) >> 23);  // u / 160
+                const int ix = (int)(u - slot * kRW) + xmin;
+                const int iy = ymin + (int)((slot - (unsigned)ymin) & (kRR - 1));
+                sl[k] = sl[k] < 0 ? -1 : __mul24(iy, s.pitch) + ix;
+              }
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
               const int e = sl[k] < 0 ? 0 : sl[k];
@@ -495,73 +566,68 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
             }
           }
         };
-        // stage B of a row: blend, K x K step, store
+        // stage B of a step: blend, stage the two rows, K x K steps, stores
         auto stage_b = [&](auto Dd) {
           constexpr int d = decltype(Dd)::value;
-          const RowMeta m = mcur[d];
-          if (m.flags & kRowSkip) return;
-          const int t = kGW * ci + d;
+          const int fl = flC[d];
+          if (fl & kStepSkip) return;
+          const int st = kGW * ci + d;
+          const float tx[4] = {rx4[d].x, rx4[d].y, rx4[d].z, rx4[d].w};
+          const float ty[4] = {ry4[d].x, ry4[d].y, ry4[d].z, ry4[d].w};
           float cur[4];
-          if (m.flags & kRowConst) {
+          // the chain of sample() / batch_blend_one()
 #pragma unroll
-            for (int k = 0; k < 4; k++) cur[k] = g.ccval;
-          } else {
-            const float tx[4] = {rx4[d].x, rx4[d].y, rx4[d].z, rx4[d].w};
-            const float ty[4] = {ry4[d].x, ry4[d].y, ry4[d].z, ry4[d].w};
-            // the chain of sample() / batch_blend_one()
+          for (int k = 0; k < 4; k++) {
+            const float wx0 = 1.f - tx[k], wy0 = 1.f - ty[k];
+            float r0 = wx0 * v[d & 1][k][0][0];
+            r0 = ipa_fma(tx[k], v[d & 1][k][0][1], r0);
+            float r1 = wx0 * v[d & 1][k][1][0];
+            r1 = ipa_fma(tx[k], v[d & 1][k][1][1], r1);
+            float o = wy0 * r0;
+            cur[k] = ipa_fma(ty[k], r1, o);
+          }
+          if (fl & kStepSlow) {
+            // footprints touching the source border (rare): tap by tap
+            const int sl[4] = {__float_as_int(rs4[d].x), __float_as_int(rs4[d].y),
+                               __float_as_int(rs4[d].z), __float_as_int(rs4[d].w)};
+            int vv0, vv1;
+            step_rows(st, vv0, vv1);
+            C sx[4], sy[4];
+            coords_of_step<FAST>(g, c, vv0, vv1, sx, sy);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-              const float wx0 = 1.f - tx[k], wy0 = 1.f - ty[k];
-              float r0 = wx0 * v[d & 1][k][0][0];
-              r0 = ipa_fma(tx[k], v[d & 1][k][0][1], r0);
-              float r1 = wx0 * v[d & 1][k][1][0];
-              r1 = ipa_fma(tx[k], v[d & 1][k][1][1], r1);
-              float o = wy0 * r0;
-              cur[k] = ipa_fma(ty[k], r1, o);
-            }
-            if (m.flags & kRowSlow) {
-              // footprints touching the source border (rare): tap by tap
-              const int sl[4] = {__float_as_int(rs4[d].x), __float_as_int(rs4[d].y),
-                                 __float_as_int(rs4[d].z), __float_as_int(rs4[d].w)};
-              const int vv = row_of(t);
-              C sx[4], sy[4];
-              coords_of_row<FAST>(g, c, vv, sx, sy);
-#pragma unroll
-              for (int k = 0; k < 4; k++)
-                if (sl[k] < 0 && (FAST || c.uq[k] >= 0))
-                  cur[k] = sample<ST, kLinear, C>(s, sx[k], sy[k], g.cval);
-            }
-            if constexpr (!FAST) {
-#pragma unroll
-              for (int k = 0; k < 4; k++) cur[k] = c.uq[k] < 0 ? g.ccval : cur[k];
+              bool live = !(fl & ((k >> 1) == 0 ? kRow0Const : (kRow1Const | kRow1Skip)));
+              if constexpr (!FAST) live = live && c.uq[k & 1] >= 0;
+              if (sl[k] < 0 && live) cur[k] = sample<ST, kLinear, C>(s, sx[k], sy[k], g.cval);
             }
           }
-          float* row = xp + kRowPad;
+          if constexpr (!FAST) {
 #pragma unroll
-          for (int k = 0; k < 4; k++) row[64u * k + lane] = cur[k];
+            for (int k = 0; k < 4; k++) {
+              const bool cst = (fl & ((k >> 1) == 0 ? kRow0Const : kRow1Const)) || c.uq[k & 1] < 0;
+              cur[k] = cst ? g.ccval : cur[k];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            xp[(k >> 1) * kXRow + kRowPad + 64u * (k & 1) + lane] = cur[k];
           __builtin_amdgcn_wave_barrier();
 
-          filter_step(acc, xp, lane, lane4_opaque, wts, wk);
-
-          const int o = t - (K - 1);
-          if (o >= 0 && o < nrows && writer) {
-            const float4 q = float4{acc[K - 1][0].x, acc[K - 1][0].y, acc[K - 1][1].x, acc[K - 1][1].y};
-            if constexpr (FAST) {
-              float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
-              __builtin_nontemporal_store(q.x, rows_ + 4u * lane);
-              __builtin_nontemporal_store(q.y, rows_ + 4u * lane + 1);
-              __builtin_nontemporal_store(q.z, rows_ + 4u * lane + 2);
-              __builtin_nontemporal_store(q.w, rows_ + 4u * lane + 3);
-            } else {
-              float* orow = dst + (long)(y0 + o) * p.dpitch + c.xo;
-              const int n = p.dw - c.xo < 4 ? p.dw - c.xo : 4;
-              if (p.vec_out && n == 4) {
-                *reinterpret_cast<float4*>(orow) = q;
-              } else {
-                const float e[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                  if (k < n) orow[k] = e[k];
+          for (int r = 0; r < 2; r++) {
+            if (r == 1 && (fl & kRow1Skip)) break;
+            filter_row(acc, xp + r * kXRow, lane, wts, wk);
+            const int o = 2 * st + r - (K - 1);
+            if (o >= 0 && o < nrows && writer) {
+              const v2f q = acc[K - 1];
+              if constexpr (FAST) {
+                float* rows_ = dst + ((long)(y0 + o) * p.dpitch + c.xs);  // scalar base
+                __builtin_nontemporal_store(q.x, rows_ + 2u * lane);
+                __builtin_nontemporal_store(q.y, rows_ + 2u * lane + 1);
+              } else {
+                float* orow = dst + (long)(y0 + o) * p.dpitch + xo;
+                orow[0] = q.x;
+                if (xo + 1 < p.dw) orow[1] = q.y;
               }
             }
           }
@@ -578,16 +644,27 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
           stage_b(Dd);
         });
       }
-      // d. the prefetched rows / spans become the current ones
+
+      // c. ring schedule of the next chunk (its spans became visible at X)
 #pragma unroll
-      for (int j = 0; j < kPend; j++) pend[j] = pnext[j];
-      pbase = nbase; pn = nn; pxlo = nxlo;
+      for (int d = 0; d < kGW; d++) { wmC[d] = 0; flC[d] = kStepSkip; }
+      pnC = 0;
+      if (active && ci + 1 < nchunks) plan(ci + 1);
+
+      // d. coordinates two chunks ahead, then the source rows of the next chunk
+      if constexpr (kMap) {
 #pragma unroll
-      for (int d = 0; d < kGW; d++) mcur[d] = mnext[d];
+        for (int k = 0; k < 4; k++) { cxa[k] = cxb[k]; cya[k] = cyb[k]; }
+        if (ci + 3 < nchunks) load_coords(ci + 3, cxb, cyb);
+      }
+      if (active && ci + 1 < nchunks) {
+#pragma unroll
+        for (int j = 0; j < kPend; j++)
+          if (j < pnC) pend[j].load(s.rsrc, __mul24(pbaseC + j, s.pitch) + xlo, lane);
+      }
       lds_barrier();  // Y: everyone is done with the records of chunk ci
     }
   }
-
 
   static __device__ __forceinline__ void body(const WaveParams& p, const Src& g,
                                               const Weights<float, K * K>& wts, kernarg_f32 wk) {
@@ -609,28 +686,26 @@ template <typename ST, typename Coord, int K, bool STREAM> struct GroupKernel {
     s.h = g.sh; s.w = g.sw; s.pitch = g.spitch;
     s.border = g.border; s.q5 = g.q5; s.cubic_a = 0.f; s.lanczos = nullptr;
 
-    const int xs = sxi * G::OW - 4 * G::HL;
-    Cols c;
+    const int xs = sxi * G::OW - 2 * G::HL;
+    SCols c;
     c.xs = xs;
-    c.xo = xs + lane * 4;
+    const int xo = xs + lane * 2;  // first of the lane's two output columns
     const int y0 = syi * p.strip_h;
     const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
-    const bool writer = lane >= G::HL && lane < 64 - G::HL && c.xo < p.dw;
+    const bool writer = lane >= G::HL && lane < 64 - G::HL && xo < p.dw;
     float* dst = reinterpret_cast<float*>(p.dst) + (long)(active ? frame : 0u) * p.dst_frame_elems;
 
-    const bool fast = p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
-                      y0 - G::H >= 0 && y0 - G::H + nrows + K - 1 <= p.dh;
+    // vec_out: 16-byte aligned rows and frames -> the 8-byte stores of a fast strip are aligned
+    const bool fast = p.vec_out && xs >= 0 && xs + kSW <= p.dw && y0 - G::H >= 0 &&
+                      y0 - G::H + nrows + K - 1 <= p.dh;
     if (fast) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
-      run_strip<true>(p, g, s, wts, wk, c, y0, nrows, writer, active, dst, sh, wave);
+      c.uq[0] = xs + lane;
+      c.uq[1] = xs + lane + 64;
+      run_strip<true>(p, g, s, wts, wk, c, xo, y0, nrows, writer, active, dst, sh, wave);
     } else {
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
-        c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
-      }
-      run_strip<false>(p, g, s, wts, wk, c, y0, nrows, writer, active, dst, sh, wave);
+      c.uq[0] = resolve_idx(xs + lane, p.dw, p.cbx);
+      c.uq[1] = resolve_idx(xs + lane + 64, p.dw, p.cbx);
+      run_strip<false>(p, g, s, wts, wk, c, xo, y0, nrows, writer, active, dst, sh, wave);
     }
   }
 };
