@@ -5,10 +5,11 @@
 
 A "step" is one pass of the hot path (LensDistortion-style undistort, bilinear,
 BORDER_CONSTANT, then a 5x5 Gaussian given as an explicit kernel, 'reflect'
-border) over one batch of synthetic 4K (3840x2160) float32 frames (128 by
-default: 4.2 GB in, 4.2 GB out) that are already resident in HBM.  The batch
-is far larger than the 256 MiB Infinity Cache, so source and destination
-really stream from/to HBM.
+border) over one batch of synthetic 4K (3840x2160) float32 frames (64 by
+default = the per-GPU batch of BASELINE.json's sharded configuration: 2.1 GB in,
+2.1 GB out) that are already resident in HBM.  The batch is far larger than
+the 256 MiB Infinity Cache, so source and destination really stream from/to
+HBM.
 
 For N > 1 the driver launches one rank per GPU (torch.distributed.run); frames
 are independent, every rank processes its own batch (weak scaling), no
@@ -16,8 +17,10 @@ data-path collective; torch.distributed (gloo) is used only for the barrier
 and the max-over-ranks of the elapsed time.
 
 Prints ONE JSON line (rank 0) with the contract fields plus `roofline`
-(dominant kernel, algorithmic bytes / HIP-event time) and `cpu_baseline`
-(the oracle C restatement timed on this box's host cores, N=1 only).
+(dominant kernel; COMPULSORY HBM bytes of the launch / HIP-event time, the
+map pair counted once per launch), `other_configs` (BASELINE configurations
+C2..C5 kernel-only, C4 also PCIe-inclusive; N=1 only) and `cpu_baseline` (the
+oracle C restatement timed on this box's host cores, N=1 only).
 """
 import argparse
 import json
@@ -113,33 +116,165 @@ def cpu_baseline(h, w, K, dist, k5, budget_s=15.0):
 
 
 def pmc_traffic(variant, batch, h, w):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC
-    passes of this same command (profiles/pmc_summary.json, written by
-    profiles/summarize.py: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE).  None if that
-    profile does not cover this variant/shape: counters cannot be read from inside the run."""
+    """HBM-side bytes per launch of the dominant kernel, from the rocprofv3 --pmc passes of THIS
+    round on this same command (profiles/pmc_summary.json, written by profiles/summarize.py:
+    FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE).  Counters cannot be read from inside the
+    run, so this is a recorded measurement: (bytes, source) or (None, reason)."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_summary.json')) as f:
             s = json.load(f)
         e = s.get(variant)
         if e and e.get('batch') == batch and e.get('height') == h and e.get('width') == w:
-            return e['traffic_bytes_per_launch']
+            return e['traffic_bytes_per_launch'], ('recorded: profiles/pmc_summary.json (%s; '
+                                                   'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
+                                                   'separate passes of this command)'
+                                                   % e.get('tag', 'r02'))
+        return None, 'no PMC pass recorded for variant=%s batch=%d %dx%d' % (variant, batch, w, h)
     except (OSError, ValueError, KeyError):
-        pass
-    return None
+        return None, 'profiles/pmc_summary.json missing'
+
+
+def timed(ctx, fn, steps, warmup):
+    """ms per call over `steps` calls, HIP events on the context's stream"""
+    for _ in range(warmup):
+        fn()
+    ctx.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    e0.record()
+    for _ in range(steps):
+        fn()
+    e1.record()
+    ctx.synchronize()
+    return e0.elapsed_ms(e1) / steps
+
+
+def other_configs(ctx, ia, ops, budget_launches=60):
+    """BASELINE.json configurations C2..C5, kernel-only on device-resident data (C4 also
+    PCIe-inclusive), each with its COMPULSORY HBM bytes: every input element read once, every
+    output written once, maps counted once per launch (frames of a launch share them)."""
+    from imgprocessor_amd.utils import getPerspectiveTransform
+    out = []
+    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
+    g /= g.sum()
+    k5 = np.outer(g, g)
+
+    def entry(name, frames, h, w, ms, comp_bytes, launches, note=None):
+        e = {'workload': name, 'frames': frames, 'ms': round(ms, 4),
+             'Mpix_s': round(frames * h * w / ms / 1e3, 1),
+             'compulsory_bytes': int(comp_bytes),
+             'frac_compulsory': round(comp_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             'launches': launches}
+        if note:
+            e['note'] = note
+        out.append(e)
+
+    # C2: 1080p float32, radial undistort (maps) + 5x5 Gaussian, 1 GPU
+    h, w, B = 1080, 1920, 64
+    K, dcoef = camera(h, w)
+    src = ctx.to_device(synth_frames(B, h, w, 200))
+    dst = ctx.empty((B, h, w), np.float32)
+    dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
+    ms = timed(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst), budget_launches, 5)
+    entry('C2 1080p f32, LensDistortion undistort (maps) + 5x5 Gaussian, %d frames/launch' % B,
+          B, h, w, ms, (8 * B + 8) * h * w, 1)
+    del src, dst, dmx, dmy
+
+    # C3: 4K float32, perspective remap (homography in the kernel: no maps) + separable 9+9
+    h, w, B = H4K, W4K, 16
+    quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+    rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+    Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))
+    g9 = ops.gaussian_kernel1d(1.0)
+    src = ctx.to_device(synth_frames(B, h, w, 300))
+    dst = ctx.empty((B, h, w), np.float32)
+    for interp in ('linear', 'cubic'):
+        ms = timed(ctx, lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, interp,
+                                                               out=dst), budget_launches, 5)
+        two = interp != 'linear'
+        entry('C3 4K f32, PerspectiveCorrection warp (%s) + separable 9+9, %d frames/launch'
+              % (interp, B), B, h, w, ms, (16 if two else 8) * B * h * w, 2 if two else 1,
+              'two launches through the workspace' if two else None)
+
+    # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here
+    # and on 8K frames below
+    k11 = np.random.default_rng(321).random((11, 11))
+    k11 /= k11.sum()
+
+    def rot_persp(h, w):
+        a = np.deg2rad(7.0)
+        cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+        R = np.array([[np.cos(a), -np.sin(a), cx - np.cos(a) * cx + np.sin(a) * cy],
+                      [np.sin(a), np.cos(a), cy - np.sin(a) * cx - np.cos(a) * cy],
+                      [0, 0, 1.0]])
+        P = np.array([[1, 0, 0], [0, 1, 0], [2e-6, 1e-6, 1.0]])
+        return P @ R
+    ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
+                                                        'cubic', out=dst), budget_launches, 5)
+    entry('C5-like 4K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
+          16 * B * h * w, 2, 'two launches through the workspace')
+    del src, dst
+
+    h, w, B = 4320, 7680, 4
+    src = ctx.to_device(synth_frames(B, h, w, 500))
+    dst = ctx.empty((B, h, w), np.float32)
+    ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
+                                                        'cubic', out=dst), budget_launches // 2, 3)
+    entry('C5 8K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
+          16 * B * h * w, 2, 'two launches through the workspace')
+    del src, dst
+
+    # C4: 4K uint16 -> float32 frames, undistort (maps) + dense 7x7; 64 frames per GPU
+    h, w, B = H4K, W4K, 64
+    K, dcoef = camera(h, w)
+    k7 = np.random.default_rng(123).random((7, 7))
+    k7 /= k7.sum()
+    f16 = np.round(synth_frames(16, h, w, 400) * 4095).astype(np.uint16)
+    u16 = ctx.to_device(np.concatenate([np.roll(f16, 29 * i, axis=1) for i in range(B // 16)]))
+    dst = ctx.empty((B, h, w), np.float32)
+    dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
+    ms = timed(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst), budget_launches // 2, 3)
+    entry('C4 4K uint16 -> float32, undistort (maps) + dense 7x7, %d frames/launch (kernel only)'
+          % B, B, h, w, ms, (6 * B + 8) * h * w, 1)
+    del u16, dst
+    # the same chain host -> host through page-locked buffers (PCIe-inclusive; never `value`)
+    try:
+        from imgprocessor_amd.sharding import FramePipeline
+        N = 24
+        pipe = FramePipeline(ctx.device_id, 3)
+        maps = {id(c): ops.build_undistort_map(K, dcoef, K, h, w, ctx=c, device=True)
+                for c in pipe.contexts}
+        fin = pipe.pinned_empty((N, h, w), np.uint16)
+        fout = pipe.pinned_empty((N, h, w), np.float32)
+        fin[...] = f16[:1]
+
+        def fn(c, d, o):
+            mx, my = maps[id(c)]
+            ops.remap_conv2d(d, mx, my, k7, out=o)
+        pipe.run(fin[:3], fout[:3], fn)
+        t0 = time.perf_counter()
+        pipe.run(fin, fout, fn)
+        ms_host = (time.perf_counter() - t0) * 1e3
+        e = {'workload': 'C4 the same chain host -> host (page-locked buffers, 3 overlapped '
+                         'workers on one GPU), PCIe-inclusive', 'frames': N,
+             'ms': round(ms_host, 3), 'Mpix_s': round(N * h * w / ms_host / 1e3, 1),
+             'pcie_bytes': int(6 * N * h * w), 'launches': N}
+        out.append(e)
+        del fin, fout
+    except Exception as ex:  # noqa: BLE001 - a report line, not the measurement
+        out.append({'workload': 'C4 host -> host', 'error': repr(ex)})
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    # defaults: ~0.6 s of timed device work.  Very short runs under-report by ~10 %: the GPU
-    # clocks are still ramping up from idle during the first ~100 ms of load (16-frame launches,
-    # 20 steps: 0.445 ms/step, 200: 0.407, 2000: 0.403 on the same box)
+    # defaults: ~0.3 s of timed device work
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--warmup', type=int, default=20)
-    # 128 frames = 4.2 GB in + 4.2 GB out of the 288 GB: launches of 16 / 32-64 / 128 frames reach
-    # 0.67 / 0.70 / 0.72-0.77 of the HBM peak (DESIGN.md section 5: the per-launch ramp and drain
-    # and the map rows are shared by more frames)
-    ap.add_argument('--batch', type=int, default=128, help='4K frames per step per GPU')
+    # 64 frames per launch = the per-GPU batch of BASELINE.json's sharded configuration (512
+    # frames over 8 GPUs); 4.2 GB of the 288 GB in + out.  --batch 128 is reported as an extra
+    # line of other_configs.
+    ap.add_argument('--batch', type=int, default=64, help='4K frames per step per GPU')
     ap.add_argument('--variant', default='fused_map',
                     choices=['fused_map', 'fused_analytic', 'two_kernel', 'two_kernel_analytic'])
     ap.add_argument('--height', type=int, default=H4K)
@@ -147,6 +282,8 @@ def main():
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--no-settle', action='store_true',
                     help='skip the untimed clock-settling launches of the setup phase')
+    ap.add_argument('--no-configs', action='store_true',
+                    help='skip the other_configs leg (BASELINE configurations C2..C5)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -189,28 +326,40 @@ def main():
     ctx.synchronize()
 
     px = B * h * w
+    # bytes per launch.  `compulsory`: what must cross the HBM interface - source and result
+    # once per frame, the map pair ONCE per launch (the frames of a launch share it through
+    # L2 / MALL; the PMC traffic confirms it).  `literal`: SURVEY section 8(d)'s per-pixel figure
+    # that charges the maps to every frame - kept as a second, clearly named number.
     if args.variant == 'fused_map':
         def step():
             ops.remap_conv2d(d_src, dmx, dmy, k5, out=d_dst)
-        bytes_per_px, launches, kname = 16, 1, 'wave_stencil_kernel<SampleRowSrc<float,linear,MapCoord>,5>'
+        literal_px, compulsory, launches = 16, (8 * B + 8) * h * w, 1
+        kname = 'wave_stencil_kernel<SampleRowSrc<float,linear,MapCoord>,5>'
     elif args.variant == 'fused_analytic':
         def step():
             ops.undistort_conv2d(d_src, K, dcoef, K, k5, out=d_dst)
-        bytes_per_px, launches, kname = 8, 1, 'wave_stencil_kernel<SampleRowSrc<float,linear,UndistortCoord>,5>'
+        literal_px, compulsory, launches = 8, 8 * B * h * w, 1
+        kname = 'wave_stencil_kernel<SampleRowSrc<float,linear,UndistortCoord>,5>'
     elif args.variant == 'two_kernel':
         def step():
             ops.remap(d_src, dmx, dmy, out=d_tmp)
             ops.conv2d(d_tmp, k5, out=d_dst)
-        bytes_per_px, launches, kname = 24, 2, 'remap_kernel<float,float,linear,MapCoord> + wave_stencil_kernel<LoadRowSrc,5>'
+        literal_px, compulsory, launches = 24, (16 * B + 8) * h * w, 2
+        kname = 'remap_kernel<float,float,linear,MapCoord> + wave_stencil_kernel<LoadRowSrc,5>'
     else:
         def step():
             ops.undistort(d_src, K, dcoef, K, out=d_tmp)
             ops.conv2d(d_tmp, k5, out=d_dst)
-        bytes_per_px, launches, kname = 16, 2, 'remap_kernel<float,float,linear,UndistortCoord> + wave_stencil_kernel<LoadRowSrc,5>'
+        literal_px, compulsory, launches = 16, 16 * B * h * w, 2
+        kname = 'remap_kernel<float,float,linear,UndistortCoord> + wave_stencil_kernel<LoadRowSrc,5>'
 
-    # Setup, not measurement: let the GPU clocks settle.  From idle they ramp up over the first
-    # ~100 ms of load; a short run (e.g. --steps 20 --warmup 3) would otherwise time the ramp
-    # (0.445 vs 0.403 ms/step).  Reported as config.clock_settle_launches.
+    # What a run WITHOUT any preparation sees (clocks still ramping up from idle): the first
+    # min(steps, 20) steps after the driver's warm-up count, reported as no_settle_*.
+    ns_steps = min(args.steps, 20)
+    ns_ms = timed(ctx, step, ns_steps, args.warmup)
+
+    # Setup, not measurement: let the GPU clocks settle (reported as config.clock_settle_launches;
+    # --no-settle skips it and the no_settle_* numbers above are then the whole story).
     settle = 0 if args.no_settle else max(20, 4800 // B)
     for _ in range(settle):
         step()
@@ -234,7 +383,9 @@ def main():
 
     if rank == 0:
         value = world * px * args.steps / el / 1e6
-        ach = bytes_per_px * px * args.steps / (ev_ms * 1e-3) / 1e9
+        step_s = ev_ms * 1e-3 / args.steps
+        ach = compulsory / step_s / 1e9
+        traffic, traffic_src = pmc_traffic(args.variant, B, h, w)
         line = {
             'metric': 'Mpix/s undistort+5x5 filter, 4K f32',
             'value': round(value, 1), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
@@ -246,16 +397,46 @@ def main():
                                    'variant=%s' % (w, h, B, args.variant),
                        'frames_per_step_per_gpu': B, 'variant': args.variant,
                        'clock_settle_launches': settle,
+                       'no_settle_ms_per_step': round(ns_ms, 4),
+                       'no_settle_value': round(world * px / ns_ms / 1e3, 1),
+                       'no_settle_steps': ns_steps,
                        'sharding': 'independent frames, %d rank(s), no collective' % world},
             'roofline': {'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                         'traffic': pmc_traffic(args.variant, B, h, w),
-                         'algorithmic_bytes_per_launch': bytes_per_px * px // launches
+                         'traffic': traffic, 'traffic_source': traffic_src,
+                         'bytes_model': 'compulsory: source + result per frame, map pair once '
+                                        'per launch',
+                         'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
-                         'kernel': kname, 'algorithmic_bytes_per_px': bytes_per_px,
-                         'launches_per_step': launches,
-                         'avg_step_ms_hip_events': round(ev_ms / args.steps, 4)},
+                         'compulsory_bytes_per_step': compulsory,
+                         'limiter': 'vector-memory front end of the CU (texture addresser busy '
+                                    '~80 %), not HBM: DESIGN.md section 5',
+                         'kernel': kname, 'launches_per_step': launches,
+                         'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
+                         'literal_survey_8d': {
+                             'bytes_per_px': literal_px,
+                             'achieved': round(literal_px * px / step_s / 1e9, 1),
+                             'frac': round(literal_px * px / step_s / 1e9 / HBM_PEAK_GBS, 4),
+                             'note': 'charges the map pair to every frame; NOT the roofline '
+                                     'fraction'},
+                         'no_settle_frac': round(compulsory / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
         }
+        if world == 1 and not args.no_configs and (h, w) == (H4K, W4K):
+            del d_src, d_dst, d_tmp
+            extra = []
+            if args.variant == 'fused_map' and B != 128:
+                B2 = 128
+                s2 = ctx.to_device(synth_frames(B2, h, w, seed0=7))
+                o2 = ctx.empty((B2, h, w), np.float32)
+                ms2 = timed(ctx, lambda: ops.remap_conv2d(s2, dmx, dmy, k5, out=o2), 40, 5)
+                c2 = (8 * B2 + 8) * h * w
+                extra.append({'workload': 'headline at %d frames/launch' % B2, 'frames': B2,
+                              'ms': round(ms2, 4), 'Mpix_s': round(B2 * h * w / ms2 / 1e3, 1),
+                              'compulsory_bytes': c2,
+                              'frac_compulsory': round(c2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              'launches': 1})
+                del s2, o2
+            line['other_configs'] = extra + other_configs(ctx, ia, ops)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(h, w, K, dcoef, k5)
         print(json.dumps(line))
