@@ -183,6 +183,16 @@ class LensDistortion(object):
             h, w = np.shape(image)[:2]
         dx, dy = self._device_maps(w, h)
         roi = None if keepSize else self.roi
+        if roi is not None and (roi[2] <= 0 or roi[3] <= 0):
+            # the optimal camera matrix left no valid rectangle: the reference's crop
+            # dst[y:y+h, x:x+w] (:327-329) is then an empty array
+            if isinstance(image, DeviceArray):
+                lead = tuple(shape[:-2])
+                self.img = np.empty(lead + (max(roi[3], 0), max(roi[2], 0)), image.dtype)
+            else:
+                a = np.asarray(image)
+                self.img = np.empty((max(roi[3], 0), max(roi[2], 0)) + a.shape[2:], a.dtype)
+            return self.img
 
         def run(d):
             return ops.remap(d, dx, dy, self.interpolation, 'constant', borderValue, map_roi=roi)
@@ -205,10 +215,18 @@ class LensDistortion(object):
         K, d = self._K_d()
         h, w = self.img.shape[-2:] if self.img is not None else self.coeffs['shape'][:2]
         newK, roi = self._new_camera_matrix(w, h)
-        pts = np.asarray(points, dtype=np.float64).reshape(-1, 2).copy()
+        pts = np.asarray(points, dtype=np.float32)
+        if pts.ndim == 2:
+            pts = np.expand_dims(pts, axis=0)
+        pts = pts.copy()
         if not keepSize:
-            pts[:, 0] -= roi[0]
-            pts[:, 1] -= roi[1]
+            # as written in the reference (:308-311): on the (1, N, 2) array this shifts BOTH
+            # coordinates of point 0 by the roi's x offset and both of point 1 by its y offset
+            # (and raises IndexError for a single point) - reproduced, not corrected
+            xx, yy = roi[:2]
+            pts[0, 0] -= xx
+            pts[0, 1] -= yy
+        pts = pts.reshape(-1, 2).astype(np.float64)
         n = _undistort_points_normalized(pts, K, d)
         return np.stack([n[:, 0] * newK[0, 0] + newK[0, 2],
                          n[:, 1] * newK[1, 1] + newK[1, 2]], axis=1)[None].astype(np.float32)

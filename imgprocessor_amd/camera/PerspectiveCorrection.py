@@ -106,8 +106,8 @@ class PerspectiveCorrection(object):
             val = np.ravel(val)[0]
         return mode, float(val)
 
-    def _warp(self, img, M_dst2src, out_shape, interpolation):
-        mode, val = self._border_kw()
+    def _warp(self, img, M_dst2src, out_shape, interpolation, border=None):
+        mode, val = self._border_kw() if border is None else border
 
         def run(d):
             return ops.warp_perspective(d, M_dst2src, out_shape, interpolation, mode, val)
@@ -133,8 +133,50 @@ class PerspectiveCorrection(object):
         """inverse warp back into an image of img's own shape — :374-378
         (flags=INTER_CUBIC | WARP_INVERSE_MAP: H itself maps destination -> source)"""
         s = img.shape[-2:] if isinstance(img, DeviceArray) else np.shape(img)[:2]
+        # the reference passes only `flags` here: cv2's default border (constant 0), not cv2_opts
         return self._warp(img, np.asarray(self.homography, dtype=np.float64), tuple(s),
-                          self.interpolation or 'cubic_cv_q5')
+                          self.interpolation or 'cubic_cv_q5', border=('constant', 0.0))
+
+    def distort(self, img, rotX=0, rotY=0, quad=None):
+        """apply a perspective distortion: rectify `img` (correct), warp the result into `quad`
+        and paste it centred into a zero image of img's shape - :193-270, the warp at :241-242
+        (cv2.warpPerspective(corr, H, (w, h), flags=INTER_CUBIC | WARP_INVERSE_MAP)).
+        Only the explicit-quad form is on the accelerated path: without `quad` the reference
+        projects the stored quad through a pose (rotX / rotY), which needs its 3-D point and
+        solvePnP code."""
+        if quad is None:
+            raise NotImplementedError('distort() without quad needs the pose / 3-D projection '
+                                      'code, outside the accelerated hot path')
+        if isinstance(img, DeviceArray):
+            img = img.get()
+        img = np.asarray(img)
+        self.img = img
+        corr = self.correct(img)
+        s = img.shape
+        wquad = sortCorners(quad)
+        wquad -= wquad.min(axis=0)
+        lx, ly = corr.shape[1], corr.shape[0]
+        objP = np.array([[0, 0], [lx, 0], [lx, ly], [0, ly]], dtype=np.float32)
+        homography = getPerspectiveTransform(wquad.astype(np.float32), objP)
+        w = wquad[:, 0].max() - wquad[:, 0].min()
+        h = wquad[:, 1].max() - wquad[:, 1].min()
+        # WARP_INVERSE_MAP: the matrix itself maps destination -> source
+        dist = self._warp(corr, np.asarray(homography, dtype=np.float64), (int(h), int(w)),
+                          self.interpolation or 'cubic_cv_q5', border=('constant', 0.0))
+        # move the middle of dist to the middle of the image
+        bg = np.zeros(shape=s)
+        rmn = (bg.shape[0] / 2, bg.shape[1] / 2)
+        ss = dist.shape
+        mn = (ss[0] / 2, ss[1] / 2)
+        ref = (int(rmn[0] - mn[0]), int(rmn[1] - mn[1]))
+        bg[ref[0]:ss[0] + ref[0], ref[1]:ss[1] + ref[1]] = dist
+        # finally move the quad into position (the reference re-estimates its pose here too;
+        # that call is outside the accelerated path and is not made)
+        self.quad = wquad
+        self.quad += (ref[1], ref[0])
+        self.img = bg
+        self._homography = None
+        return self.img
 
     def correctPoints(self, pts):
         """cv2.perspectiveTransform(pts, H) — :408-414"""

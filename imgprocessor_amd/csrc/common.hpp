@@ -153,5 +153,18 @@ template <> __device__ __forceinline__ uint16_t store_cast<uint16_t, float>(floa
   r = r < 65535.f ? r : 65535.f;
   return (uint16_t)r;
 }
+// integer destinations computed in double (sample_exact): cv::saturate_cast rounding
+template <> __device__ __forceinline__ uint8_t store_cast<uint8_t, double>(double v) {
+  double r = rint(v);
+  r = r > 0.0 ? r : 0.0;  // NaN -> 0
+  r = r < 255.0 ? r : 255.0;
+  return (uint8_t)r;
+}
+template <> __device__ __forceinline__ uint16_t store_cast<uint16_t, double>(double v) {
+  double r = rint(v);
+  r = r > 0.0 ? r : 0.0;
+  r = r < 65535.0 ? r : 65535.0;
+  return (uint16_t)r;
+}
 
 }  // namespace ipa

@@ -175,7 +175,14 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   coords4<Coord>(coord, x0, y, n, p.map_vec, sx, sy);
 
   alignas(16) DT out[4];
-  if constexpr (FIXED) {
+  if constexpr (std::is_integral<DT>::value && !FIXED) {
+    // integer destination: plain double arithmetic, then round-half-even + saturate
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      out[k] = k < n ? store_cast<DT, double>(
+                           sample_exact<ST, INTERP, typename Coord::coord_t>(s, sx[k], sy[k], p.cval))
+                     : (DT)0;
+  } else if constexpr (FIXED) {
     double r = rint(p.cval);
     uint8_t cv8 = (uint8_t)(r > 0 ? (r < 255 ? r : 255) : 0);
 #pragma unroll
@@ -332,6 +339,10 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
     launch_interp<uint8_t, float, Coord, false>(ctx, p, coord, base, grid);
   } else if (s == IPA_U8 && d == IPA_U8) {
     launch_interp<uint8_t, uint8_t, Coord, true>(ctx, p, coord, base, grid);
+  } else if (s == IPA_F32 && d == IPA_U8) {
+    launch_interp<float, uint8_t, Coord, false>(ctx, p, coord, base, grid);
+  } else if (s == IPA_F32 && d == IPA_U16) {
+    launch_interp<float, uint16_t, Coord, false>(ctx, p, coord, base, grid);
   } else {
     IPA_UNSUPPORTED(ctx, "remap: src dtype %d -> dst dtype %d not supported", s, d);
   }

@@ -258,6 +258,82 @@ __device__ __forceinline__ typename compute_of<ST>::type sample(const SrcView& s
   return out;
 }
 
+// One interpolated sample for INTEGER destinations: every product and sum in double, no fused
+// multiply-add, taps in row-major order (rs += wx[c] * v; out += wy[r] * rs) - the plain
+// double arithmetic of a scalar CPU implementation built without fp contraction, operation
+// for operation, so that the value handed to the round-half-even store is the same
+// double and uint8 / uint16 results agree bit for bit (cv::saturate_cast semantics of
+// cv2.remap on integer images, camera/LensDistortion.py:323-326).
+template <typename ST, int INTERP, typename C>
+__device__ __forceinline__ double sample_exact(const SrcView& s, C sx, C sy, double cval) {
+#pragma clang fp contract(off)
+  constexpr int NT = ntaps<INTERP>::value;
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cval;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  int i0[2];
+  double w[2][NT];
+  const C cc[2] = {sx, sy};
+#pragma unroll
+  for (int a = 0; a < 2; a++) {
+    const double c = (double)cc[a];
+    double fl, t;
+    int k = 0;
+    if (INTERP == kLanczos4 || s.q5) {
+      const int qi = (int)rint(c * 32.0);  // cvRound(coordinate * INTER_TAB_SIZE)
+      fl = (double)(qi >> 5);
+      k = qi & 31;
+      t = (double)k / 32.0;
+    } else {
+      fl = floor(c);
+      t = c - fl;
+    }
+    if constexpr (INTERP == kNearest) {
+      i0[a] = (int)rint(c);
+      w[a][0] = 1.0;
+    } else if constexpr (INTERP == kLinear) {
+      i0[a] = (int)fl;
+      w[a][0] = 1.0 - t;
+      w[a][1] = t;
+    } else if constexpr (INTERP == kCubic) {
+      i0[a] = (int)fl - 1;
+      const double A = (double)s.cubic_a;
+      w[a][0] = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A;
+      w[a][1] = ((A + 2) * t - (A + 3)) * t * t + 1;
+      w[a][2] = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1;
+      w[a][3] = 1.0 - w[a][0] - w[a][1] - w[a][2];
+    } else {
+      i0[a] = (int)fl - 3;
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[a][j] = (double)s.lanczos[k * 8 + j];
+    }
+  }
+  const int ix0 = i0[0], iy0 = i0[1];
+  if (s.border == IPA_BORDER_CONSTANT &&
+      (ix0 >= s.w || ix0 + NT <= 0 || iy0 >= s.h || iy0 + NT <= 0))
+    return cval;  // whole footprint outside
+  const bool interior = ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
+  double out = 0.0;
+#pragma unroll
+  for (int r = 0; r < NT; r++) {
+    const int yy = interior ? iy0 + r : resolve_idx(iy0 + r, s.h, s.border);
+    double rs = 0.0;
+#pragma unroll
+    for (int c = 0; c < NT; c++) {
+      const int xx = interior ? ix0 + c : resolve_idx(ix0 + c, s.w, s.border);
+      const double v = (yy < 0 || xx < 0)
+                           ? cval
+                           : (double)TapLoad<ST, typename compute_of<ST>::type>::one(s, yy * s.pitch + xx);
+      rs = rs + w[0][c] * v;
+    }
+    out = out + w[1][r] * rs;
+  }
+  return out;
+}
+
 // N samples at once, laid out for memory-level parallelism: the tap loads of
 // the WHOLE batch are issued back to back (range-checked buffer loads cannot
 // fault, so they are issued unconditionally at a clamped offset) before any

@@ -101,6 +101,18 @@ def build_undistort_map(K, dist5, newK, h, w, ctx=None, device=False):
     return mx, my
 
 
+def _check_dev_maps(mapx, mapy):
+    """device maps are read with plain (not range-checked) loads: refuse anything that is not a
+    pair of equally shaped 2-D float32 arrays instead of reinterpreting it"""
+    if not (_is_dev(mapx) and _is_dev(mapy)):
+        raise TypeError('device source needs device maps')
+    if mapx.dtype != np.float32 or mapy.dtype != np.float32:
+        raise TypeError('mapx/mapy must be float32 (got %s / %s)' % (mapx.dtype, mapy.dtype))
+    if mapx.ndim != 2 or tuple(mapx.shape) != tuple(mapy.shape):
+        raise ValueError('mapx/mapy must be 2-D and of equal shape (got %s / %s)'
+                         % (mapx.shape, mapy.shape))
+
+
 # ----------------------------------------------------------------- remap --
 def remap(src, mapx, mapy, interpolation='linear', border_mode='constant', border_value=0.0,
           out_dtype=None, out=None, ctx=None, map_roi=None):
@@ -110,8 +122,7 @@ def remap(src, mapx, mapy, interpolation='linear', border_mode='constant', borde
     interp, border = interp_id(interpolation), border_id(border_mode)
     if _is_dev(src):
         ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
-        if not (_is_dev(mapx) and _is_dev(mapy)):
-            raise TypeError('device source needs device maps')
+        _check_dev_maps(mapx, mapy)
         n, sh, sw = as_frames(src)
         mh, mw = mapx.shape
         dh, dw, moff = mh, mw, 0
@@ -229,8 +240,12 @@ def conv2d(img, kernel, mode='reflect', cval=0.0, mask=None, mode_y=None, out=No
     ctx = _ctx_of(img, mask, ctx=ctx)
     n, h, w = as_frames(img)
     if _is_dev(img):
-        if mask is not None and not _is_dev(mask):
-            raise TypeError('device image needs a device mask')
+        if mask is not None:
+            if not _is_dev(mask):
+                raise TypeError('device image needs a device mask')
+            if mask.dtype != np.uint8 or tuple(mask.shape) != (h, w):
+                raise ValueError('device mask must be uint8 of shape %s (got %s %s)'
+                                 % ((h, w), mask.dtype, mask.shape))
         dst = _dev_out(ctx, out, img.shape, img.dtype)
         ctx._check(ctx._lib.ipa_conv2d_dev(ctx.handle, img.ptr, dtype_id(img.dtype), h, w, w, kp,
                                            k.shape[0], k.shape[1],
@@ -347,12 +362,11 @@ def local_std(img, blurred, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
-def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None, fn='mean'):
-    """filters/maskedFilter.py:43-102 (_calcMean / _calcMedian by ``fn``).  fill_mask=True fills
-    ``arr`` IN PLACE (host arrays are copied back into ``arr``); fill_mask=False returns a new
-    NaN-padded array."""
-    if fn not in ('mean', 'median'):
-        raise ValueError("fn must be 'mean' or 'median'")
+def masked_mean(arr, mask, ksize, fill_mask=True, ctx=None, fn='median'):
+    """filters/maskedFilter.py:12-102 (_calcMean / _calcMedian by ``fn``; default and every value
+    other than 'mean': median, as in the reference).  fill_mask=True fills ``arr`` IN PLACE (host
+    arrays are copied back into ``arr``); fill_mask=False returns a new NaN-padded array."""
+    fn = 'mean' if fn == 'mean' else 'median'
     dev = _is_dev(arr)
     ctx = _ctx_of(arr, mask, ctx=ctx)
     if dev:
@@ -508,6 +522,7 @@ def remap_conv2d(src, mapx, mapy, kernel, interpolation='linear', border_mode='c
     ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
     if not (_is_dev(src) and _is_dev(mapx) and _is_dev(mapy)):
         raise TypeError('remap_conv2d works on DeviceArrays (use Context.to_device)')
+    _check_dev_maps(mapx, mapy)
     k = np.ascontiguousarray(kernel, dtype=np.float64)
     n, sh, sw = as_frames(src)
     dh, dw = mapx.shape
@@ -576,6 +591,7 @@ def remap_sepconv2d(src, mapx, mapy, ky, kx, interpolation='linear', border_mode
     ctx = _ctx_of(src, mapx, mapy, ctx=ctx)
     if not (_is_dev(src) and _is_dev(mapx) and _is_dev(mapy)):
         raise TypeError('remap_sepconv2d works on DeviceArrays (use Context.to_device)')
+    _check_dev_maps(mapx, mapy)
     ky, kx, pky, pkx = _sep_taps(ky, kx)
     n, sh, sw = as_frames(src)
     dh, dw = mapx.shape

@@ -266,9 +266,9 @@ def standardDeviation2d(img, ksize=5, blurred=None):
     return std
 
 
-def maskedFilter(arr, mask, ksize=30, fill_mask=True, fn='mean'):
-    """filters/maskedFilter.py:12-37, fn = 'mean' | 'median'"""
-    assert fn in ('mean', 'median')
+def maskedFilter(arr, mask, ksize=30, fill_mask=True, fn='median'):
+    """filters/maskedFilter.py:12-37: fn == 'mean' -> mean, anything else (default) -> median"""
+    fn = 'mean' if fn == 'mean' else 'median'
     mask = np.ascontiguousarray(mask, dtype=bool)
     if fill_mask:
         sel, out = mask, arr

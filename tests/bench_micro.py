@@ -190,7 +190,7 @@ if __name__ == '__main__':
 
             def fill():
                 work.copy_from(img)
-                ops.masked_mean(work, m, 30, True)
+                ops.masked_mean(work, m, 30, True, fn='mean')
             t = timeit(ctx, fill)
             print('%-8s maskedFilter mean k30 5%%  %8.1f us  %6.2f Gpx/s' % (np.dtype(dt).name, t, one / t / 1e3))
             t = timeit(ctx, lambda: varYSizeGaussianFilter(img, (0, 4), 1), n=3, warm=1)

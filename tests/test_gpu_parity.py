@@ -103,13 +103,15 @@ def test_remap_all_modes_vs_oracle(ia, oracle):
         assert got.dtype == np.float64
         assert_close(got, oracle.remap(img64, mx, my, interps[iname], oracle.REFLECT), 1e-12, 1e-12,
                      'f64 ' + iname)
-    # uint16 -> uint16 (round half even) may differ by 1 LSB at exact ties only
+    # integer destinations are computed in double like the oracle, then rounded half-even and
+    # saturated (cv::saturate_cast): bit-exact for every interpolation and border mode
     u16 = rng.integers(0, 4096, (H, W), dtype=np.uint16)
-    got = ia.ops.remap(u16, mx, my, 'linear')
-    want = oracle.remap(u16, mx, my)
-    assert got.dtype == np.uint16
-    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
-    assert (got != want).mean() < 1e-3
+    for iname, iid in interps.items():
+        for bname, bid in (('constant', oracle.CONSTANT), ('reflect', oracle.REFLECT)):
+            got = ia.ops.remap(u16, mx, my, iname, bname, 17.5)
+            want = oracle.remap(u16, mx, my, iid, bid, 17.5)
+            assert got.dtype == np.uint16
+            assert np.array_equal(got, want), 'u16->u16 %s/%s' % (iname, bname)
     # uint8 -> float32 ingest
     u8 = rng.integers(0, 256, (H, W), dtype=np.uint8)
     close32(ia.ops.remap(u8, mx, my, 'cubic', out_dtype=np.float32),
@@ -130,11 +132,23 @@ def test_remap_uint8_bit_exact(ia, oracle):
             want = oracle.remap(u8, mx, my, oracle.LINEAR, bid, cv)
             assert got.dtype == np.uint8 and np.array_equal(got, want), (bname, cv)
     assert np.array_equal(ia.ops.remap(u8, xx, yy), u8)
-    # "uint8 after rounding" of a float32 result: only exact-tie neighbours may differ
-    f = u8.astype(np.float32)
-    got = np.rint(ia.ops.remap(f, mx, my, 'linear'))
-    want = np.rint(oracle.remap(f, mx, my))
-    assert (got != want).mean() < 2e-3 and np.abs(got - want).max() <= 1
+    # "uint8 after rounding": float32 frames remapped INTO an integer array round the double
+    # sum once, like the oracle - bit-exact, ties included (values k/2 make ties frequent)
+    f = (u8.astype(np.float32) * 0.5 + 3.0).astype(np.float32)
+    hx = (xx + 0.5).astype(np.float32)
+    for mxx, myy in ((mx, my), (hx, yy)):
+        for dt in (np.uint8, np.uint16):
+            got = ia.ops.remap(f, mxx, myy, 'linear', out_dtype=dt)
+            want = oracle.remap(f, mxx, myy, out_dtype=dt)
+            assert got.dtype == dt and np.array_equal(got, want), dt
+    # uint8 through the wide interpolations (PerspectiveCorrection.correct's defaults)
+    for iname, iid in (('cubic', oracle.CUBIC_KEYS), ('cubic_cv', oracle.CUBIC_CV),
+                       ('cubic_cv_q5', oracle.CUBIC_CV | oracle.Q5), ('lanczos4', oracle.LANCZOS4),
+                       ('nearest', oracle.NEAREST)):
+        for bname, bid in (('constant', oracle.CONSTANT), ('reflect', oracle.REFLECT)):
+            got = ia.ops.remap(u8, mx, my, iname, bname, 3.0)
+            want = oracle.remap(u8, mx, my, iid, bid, 3.0)
+            assert got.dtype == np.uint8 and np.array_equal(got, want), (iname, bname)
 
 
 def test_known_answers(ia):
@@ -314,14 +328,14 @@ def test_masked_filter_and_nan_max(ia, oracle):
     g = load_golden('masked_filter.npz')
     for ks in (6, 11, 30):
         a = g['arr'].copy()
-        assert maskedFilter(a, g['mask'], ks) is a  # in place like the reference
+        assert maskedFilter(a, g['mask'], ks, fn='mean') is a  # in place like the reference
         assert_close(a, g['mean_fill_k%d' % ks], 1e-13, 1e-15)
-        got, want = maskedFilter(g['arr'].copy(), g['mask'], ks, fill_mask=False), \
+        got, want = maskedFilter(g['arr'].copy(), g['mask'], ks, fill_mask=False, fn='mean'), \
             g['mean_nofill_k%d' % ks]
         assert np.array_equal(np.isnan(got), np.isnan(want))
         assert_close(np.nan_to_num(got), np.nan_to_num(want), 1e-13, 1e-15)
     a32 = g['arr'].astype(np.float32)
-    close32(maskedFilter(a32, g['mask'], 6), g['mean32_fill_k6'], 'mean f32')
+    close32(maskedFilter(a32, g['mask'], 6, fn='mean'), g['mean32_fill_k6'], 'mean f32')
     for ks in (3, 6, 9):
         assert np.array_equal(nan_maximum_filter(g['arr_nan'], ks), g['nanmax_k%d' % ks],
                               equal_nan=True)
@@ -331,8 +345,8 @@ def test_masked_filter_and_nan_max(ia, oracle):
     m[:, 200:240] = True
     d = ia.default_context().to_device(big)
     dm = ia.default_context().to_device(m.astype(np.uint8))
-    assert maskedFilter(d, dm, 30) is d
-    assert_close(d.get(), oracle.maskedFilter(big.copy(), m, 30), 1e-13, 1e-15)
+    assert maskedFilter(d, dm, 30, fn='mean') is d
+    assert_close(d.get(), oracle.maskedFilter(big.copy(), m, 30, fn='mean'), 1e-13, 1e-15)
     bn = big.copy()
     bn[m] = np.nan
     assert np.array_equal(nan_maximum_filter(bn.astype(np.float32), 7),
@@ -357,8 +371,13 @@ def test_masked_filter_and_nan_max(ia, oracle):
     assert np.array_equal(maskedFilter(bn, m, 8, fn='median'), want, equal_nan=True)
     with pytest.raises(NotImplementedError):
         maskedFilter(big, m, 200, fn='median')   # window larger than the per-wave LDS buffer
-    with pytest.raises(ValueError):
-        maskedFilter(big, m, 5, fn='mode')
+    # the reference's default is the MEDIAN, and any fn other than 'mean' selects it too
+    # (filters/maskedFilter.py:12-13, 30-35)
+    a = g['arr'].copy()
+    assert maskedFilter(a, g['mask'], 6) is a
+    assert np.array_equal(a, g['median_fill_k6'])
+    assert np.array_equal(maskedFilter(g['arr'].copy(), g['mask'], 6, fn='mode'),
+                          g['median_fill_k6'])
 
 
 def test_median_threshold_golden(ia, oracle):

@@ -71,15 +71,17 @@ def test_std2d(oracle):
 def test_masked_filter_and_nan_max(oracle):
     g = load_golden('masked_filter.npz')
     for ks in (6, 11, 30):
-        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, True)
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, True, 'mean')
         assert_close(got, g['mean_fill_k%d' % ks], 1e-13, 1e-15)
-        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, False)
+        got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, False, 'mean')
         want = g['mean_nofill_k%d' % ks]
         assert np.array_equal(np.isnan(got), np.isnan(want))
         assert_close(np.nan_to_num(got), np.nan_to_num(want), 1e-13, 1e-15)
-    got = oracle.maskedFilter(g['arr'].astype(np.float32), g['mask'], 6, True)
+    got = oracle.maskedFilter(g['arr'].astype(np.float32), g['mask'], 6, True, 'mean')
     assert got.dtype == np.float32
     assert_close(got, g['mean32_fill_k6'], 1e-6, 1e-7)
+    # default = median (the reference's default)
+    assert np.array_equal(oracle.maskedFilter(g['arr'].copy(), g['mask'], 6), g['median_fill_k6'])
     for ks in (6, 11):   # median: selection only -> bit-exact
         got = oracle.maskedFilter(g['arr'].copy(), g['mask'], ks, True, 'median')
         assert np.array_equal(got, g['median_fill_k%d' % ks])
