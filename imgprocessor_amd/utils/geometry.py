@@ -72,8 +72,9 @@ def _undistort_points_normalized(pts, K, dist5, iters=20):
 def _rectangles(K, dist5, newK, size, N=9):
     w, h = size
     gx, gy = np.meshgrid(np.arange(N), np.arange(N))
-    pts = np.stack([gx.ravel() * w / (N - 1.0), gy.ravel() * h / (N - 1.0)], axis=1)
-    p = _undistort_points_normalized(pts.astype(np.float32).astype(np.float64), K, dist5)
+    # OpenCV 4.x: grid over [0, W-1] x [0, H-1] in double (2.4 / 3.0 sampled [0, W] in float)
+    pts = np.stack([gx.ravel() * (w - 1) / (N - 1.0), gy.ravel() * (h - 1) / (N - 1.0)], axis=1)
+    p = _undistort_points_normalized(pts, K, dist5)
     if newK is not None:
         p = np.stack([p[:, 0] * newK[0, 0] + newK[0, 2], p[:, 1] * newK[1, 1] + newK[1, 2]], 1)
     p = p.reshape(N, N, 2)
@@ -86,9 +87,11 @@ def _rectangles(K, dist5, newK, size, N=9):
 
 def getOptimalNewCameraMatrix(K, dist5, imageSize, alpha, newImgSize=None):
     """cv2.getOptimalNewCameraMatrix(K, d, (w,h), alpha, (w,h)) as OpenCV 4.x
-    documents/implements it (9x9 point grid, inner/outer rectangles, (W-1)
-    scaling) — LensDistortion.py:350-353.  OpenCV's result changed across 3.x/4.x
-    and cv2 is not available to pin it: treat as the 4.x behaviour, unpinned.
+    documents/implements it (9x9 point grid over [0, W-1] x [0, H-1], inner/outer rectangles,
+    (W-1) scaling) — LensDistortion.py:350-353.  OpenCV's result changed across 3.x/4.x and
+    cv2 is not available to pin it: this is the 4.x definition, checked against a second
+    independent restatement (tests/golden/gen_golden.py::optimal_new_camera_matrix_np),
+    unpinned against cv2 itself.
     Returns (newK float64 3x3, roi (x, y, w, h))."""
     K = np.asarray(K, dtype=np.float64).reshape(3, 3)
     w, h = imageSize

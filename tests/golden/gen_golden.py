@@ -399,6 +399,185 @@ def gen_remap_scipy():
     np.savez_compressed(os.path.join(HERE, 'remap_scipy.npz'), **out)
 
 
+# ---------------------------------------------------------------------------------------
+# cv2-specific behaviour.  cv2 cannot be imported here, so these
+# fixtures are SECOND, INDEPENDENT restatements of OpenCV's published definitions, written in
+# vectorised numpy from the textbook forms (piecewise Keys kernel, sinc-product Lanczos kernel,
+# integer bilinear weights, the 9 x 9 rectangle search) - not transcriptions of oracle/oracle.c
+# or of the product - plus the scipy identity for the 1/32-px coordinate rule.  They pin the
+# oracle and the GPU path against a differently-written implementation of the same definition;
+# they do NOT pin either against cv2 itself (DESIGN.md section 2 says so).
+# ---------------------------------------------------------------------------------------
+def _gather(img, iy, ix, cval):
+    """img[iy, ix] with a constant border (cv2.BORDER_CONSTANT per tap)"""
+    h, w = img.shape
+    ok = (iy >= 0) & (iy < h) & (ix >= 0) & (ix < w)
+    out = np.full(iy.shape, float(cval))
+    out[ok] = img[iy[ok], ix[ok]]
+    return out
+
+
+def keys_kernel(x, a):
+    """Keys' cubic convolution kernel, textbook piecewise form"""
+    x = np.abs(x)
+    return np.where(x <= 1, (a + 2) * x ** 3 - (a + 3) * x ** 2 + 1,
+                    np.where(x < 2, a * x ** 3 - 5 * a * x ** 2 + 8 * a * x - 4 * a, 0.0))
+
+
+def lanczos4_kernel(x):
+    """Lanczos kernel with a = 4: sinc(x) sinc(x / 4) on |x| < 4"""
+    return np.where(np.abs(x) < 4, np.sinc(x) * np.sinc(x / 4.0), 0.0)
+
+
+def remap_separable_np(img, mx, my, kernel, ntaps, q5, cval=0.0, normalise=False):
+    """dst = sum_r sum_c w_y[r] w_x[c] src[iy0 + r, ix0 + c] in float64; coordinates exact or
+    rounded to 1/32 px (cvRound(c * 32) / 32, round-half-even)"""
+    x = mx.astype(np.float64)
+    y = my.astype(np.float64)
+    if q5:
+        x = np.rint(x * 32) / 32
+        y = np.rint(y * 32) / 32
+    fx, fy = np.floor(x), np.floor(y)
+    tx, ty = x - fx, y - fy
+    first = -(ntaps // 2 - 1)           # -1 for 4 taps, -3 for 8
+    offs = np.arange(first, first + ntaps)
+    wx = np.stack([kernel(tx - o) for o in offs])   # tap at fx + o is (tx - o) away
+    wy = np.stack([kernel(ty - o) for o in offs])
+    if normalise:
+        wx = (wx / wx.sum(axis=0)).astype(np.float32).astype(np.float64)
+        wy = (wy / wy.sum(axis=0)).astype(np.float32).astype(np.float64)
+    out = np.zeros(x.shape)
+    src = img.astype(np.float64)
+    for r, oy in enumerate(offs):
+        row = np.zeros(x.shape)
+        for c, ox in enumerate(offs):
+            row += wx[c] * _gather(src, (fy + oy).astype(np.int64), (fx + ox).astype(np.int64), cval)
+        out += wy[r] * row
+    return out
+
+
+def remap_u8_fixed_np(img8, mx, my, cval8=0):
+    """cv2.remap on CV_8U, INTER_LINEAR: coordinates to 1/32 px, integer weights
+    (32 - fx)(32 - fy) * 32 ... (they sum to 2^15), rounded shift by 15"""
+    qx = np.rint(mx.astype(np.float64) * 32).astype(np.int64)
+    qy = np.rint(my.astype(np.float64) * 32).astype(np.int64)
+    ix, iy, fx, fy = qx >> 5, qy >> 5, qx & 31, qy & 31
+    src = img8.astype(np.int64)
+    h, w = src.shape
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = np.full(yy.shape, int(cval8), np.int64)
+        v[ok] = src[yy[ok], xx[ok]]
+        return v
+    acc = (tap(iy, ix) * (32 - fx) * (32 - fy) + tap(iy, ix + 1) * fx * (32 - fy) +
+           tap(iy + 1, ix) * (32 - fx) * fy + tap(iy + 1, ix + 1) * fx * fy) * 32
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+def optimal_new_camera_matrix_np(K, d, size, alpha):
+    """cv2.getOptimalNewCameraMatrix(K, d, (w, h), alpha, (w, h)), OpenCV 4.x definition:
+    a 9 x 9 grid of image points is undistorted to ideal coordinates; `outer` bounds all of
+    them, `inner` is bounded by the grid's edge points; the new matrix scales the (alpha-blended)
+    rectangle onto the (W - 1) x (H - 1) frame; the roi is the inner rectangle under the new
+    matrix (ceil of the origin, floor of the extent).  The inverse lens model is iterated to
+    convergence here (OpenCV stops after 5 fixed-point steps)."""
+    k1, k2, p1, p2, k3 = [float(v) for v in d]
+    w, h = size
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    gx, gy = np.meshgrid(np.arange(9) * (w - 1) / 8.0, np.arange(9) * (h - 1) / 8.0)
+
+    def ideal(P):
+        x0, y0 = (gx - cx) / fx, (gy - cy) / fy
+        x, y = x0.copy(), y0.copy()
+        for _ in range(60):
+            r2 = x * x + y * y
+            rad = 1 + r2 * (k1 + r2 * (k2 + r2 * k3))
+            dx = 2 * p1 * x * y + p2 * (r2 + 2 * x * x)
+            dy = p1 * (r2 + 2 * y * y) + 2 * p2 * x * y
+            x, y = (x0 - dx) / rad, (y0 - dy) / rad
+        if P is not None:
+            x, y = x * P[0, 0] + P[0, 2], y * P[1, 1] + P[1, 2]
+        return x, y
+
+    def rects(P):
+        x, y = ideal(P)
+        outer = (x.min(), y.min(), x.max() - x.min(), y.max() - y.min())
+        il, ir = x[:, 0].max(), x[:, -1].min()
+        it, ib = y[0, :].max(), y[-1, :].min()
+        return (il, it, ir - il, ib - it), outer
+    inner, outer = rects(None)
+    f0 = ((w - 1) / inner[2], (h - 1) / inner[3])
+    f1 = ((w - 1) / outer[2], (h - 1) / outer[3])
+    c0 = (-f0[0] * inner[0], -f0[1] * inner[1])
+    c1 = (-f1[0] * outer[0], -f1[1] * outer[1])
+    a = float(alpha)
+    M = np.array([[f0[0] * (1 - a) + f1[0] * a, 0, c0[0] * (1 - a) + c1[0] * a],
+                  [0, f0[1] * (1 - a) + f1[1] * a, c0[1] * (1 - a) + c1[1] * a], [0, 0, 1.0]])
+    inner, _ = rects(M)
+    x0, y0 = int(np.ceil(inner[0])), int(np.ceil(inner[1]))
+    x1, y1 = x0 + int(np.floor(inner[2])), y0 + int(np.floor(inner[3]))
+    x0c, y0c, x1c, y1c = max(x0, 0), max(y0, 0), min(x1, w), min(y1, h)
+    return M, np.array([x0c, y0c, max(x1c - x0c, 0), max(y1c - y0c, 0)])
+
+
+def gen_cv_modes():
+    from scipy.ndimage import map_coordinates
+    H, W = 96, 128
+    out = {}
+    img = synth((H, W), 4, np.float32)
+    img8 = np.round(synth((H, W), 5, np.float64) * 255).astype(np.uint8)
+    out['img'] = img
+    out['img8'] = img8
+    for name in ('radial', 'strong'):
+        fx, fy, cx, cy, d = REMAP_CASES[name]
+        K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.]])
+        newK = K.copy()
+        if name == 'strong':
+            newK = np.array([[90., 0, 66], [0, 95., 45], [0, 0, 1.]])
+        mx, my = undistort_map_np(K, d, newK, H, W)
+        out['mapx_' + name] = mx
+        out['mapy_' + name] = my
+        # (i) the 1/32-px rule through scipy: linear_cv_q5 == map_coordinates at rounded coords
+        qx = np.rint(mx.astype(np.float64) * 32) / 32
+        qy = np.rint(my.astype(np.float64) * 32) / 32
+        for cv, cname in ((0.0, 'c0'), (0.37, 'c037')):
+            out['q5lin_%s_%s' % (name, cname)] = map_coordinates(
+                img.astype(np.float64), [qy, qx], order=1, mode='grid-constant',
+                cval=cv).astype(np.float32)
+        # (ii) independent restatements
+        out['cubic075_%s' % name] = remap_separable_np(img, mx, my, lambda t: keys_kernel(t, -0.75),
+                                                       4, q5=False).astype(np.float32)
+        out['cubic075q5_%s' % name] = remap_separable_np(img, mx, my,
+                                                         lambda t: keys_kernel(t, -0.75), 4,
+                                                         q5=True).astype(np.float32)
+        out['cubic05_%s' % name] = remap_separable_np(img, mx, my, lambda t: keys_kernel(t, -0.5),
+                                                      4, q5=False).astype(np.float32)
+        out['lanczos4_%s' % name] = remap_separable_np(img, mx, my, lanczos4_kernel, 8, q5=True,
+                                                       normalise=True).astype(np.float32)
+        out['u8fix_%s' % name] = remap_u8_fixed_np(img8, mx, my, 0)
+        out['u8fix17_%s' % name] = remap_u8_fixed_np(img8, mx, my, 17)
+    # the Lanczos4 table itself: rows k / 32, taps -3..4, normalised
+    t = np.arange(32) / 32.0
+    tab = np.stack([lanczos4_kernel(t - o) for o in range(-3, 5)], axis=1)
+    out['lanczos_tab'] = tab / tab.sum(axis=1, keepdims=True)
+    # getOptimalNewCameraMatrix(alpha = 0, 1) for three cameras
+    cams = {'barrel': (640, 480, [[600., 0, 319.5], [0, 600., 239.5], [0, 0, 1]],
+                       [-0.2, 0.05, 0, 0, 0]),
+            'pincushion': (640, 480, [[700., 0, 330.0], [0, 690., 250.0], [0, 0, 1]],
+                           [0.12, 0.01, 1e-3, -5e-4, 0.0]),
+            'c2': (1920, 1080, [[1920., 0, 959.5], [0, 1920., 539.5], [0, 0, 1]],
+                   [-0.12, 0.03, 1e-3, -5e-4, 0.0])}
+    for name, (w, h, K, d) in cams.items():
+        K = np.array(K)
+        out['optK_in_%s' % name] = np.concatenate([K.ravel(), d, [w, h]])
+        for alpha in (0, 1):
+            M, roi = optimal_new_camera_matrix_np(K, d, (w, h), alpha)
+            out['optK_%s_a%d' % (name, alpha)] = M
+            out['optroi_%s_a%d' % (name, alpha)] = roi
+    np.savez_compressed(os.path.join(HERE, 'cv_modes.npz'), **out)
+
+
 SKIMAGE_CHILD = r'''
 import sys, warnings
 import numpy as np
@@ -455,6 +634,7 @@ if __name__ == '__main__':
     install_shim()
     gen_stencils()
     gen_remap_scipy()
+    gen_cv_modes()
     gen_warp_skimage()
     for f in sorted(os.listdir(HERE)):
         if f.endswith('.npz'):

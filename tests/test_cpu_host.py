@@ -86,8 +86,8 @@ def test_geometry_helpers(oracle):
     # zero distortion: the optimal matrix maps the full frame onto itself
     K = np.array([[500., 0, 319.5], [0, 500., 239.5], [0, 0, 1]])
     nK, roi = getOptimalNewCameraMatrix(K, np.zeros(5), (640, 480), 1)
-    assert roi[0] <= 1 and roi[1] <= 1 and roi[2] >= 638 and roi[3] >= 478
-    assert abs(nK[0, 0] - 500 * 639 / 640) < 1e-6 and abs(nK[0, 2] - 319.5 * 639 / 640) < 1e-6
+    assert tuple(roi) == (0, 0, 639, 479)
+    assert np.allclose(nK, K, rtol=0, atol=1e-9)  # the 4.x definition is the identity here
     # barrel distortion: alpha=1 keeps every source pixel -> smaller focal length, inner roi
     nK, roi = getOptimalNewCameraMatrix(K, [-0.2, 0.05, 0, 0, 0], (640, 480), 1)
     assert nK[0, 0] < 500 and 0 < roi[2] < 640 and 0 < roi[3] < 480
@@ -316,3 +316,28 @@ def test_two_rank_partition_gloo(tmp_path):
     res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
     assert res['max'] == 0.75
     assert res['cover'] == [1] * 37
+
+
+def test_optimal_new_camera_matrix_independent_restatement():
+    """utils.getOptimalNewCameraMatrix (what LensDistortion uses for cv2.getOptimalNewCameraMatrix,
+    camera/LensDistortion.py:350-353) against the second numpy restatement of OpenCV 4.x's
+    definition in tests/golden/gen_golden.py (converged inverse lens model there, 20 fixed-point
+    steps here): matrix within 1e-6 relative, roi identical (alpha = 0: within one pixel)"""
+    import numpy as np
+    from tests.conftest import load_golden
+    from imgprocessor_amd.utils import getOptimalNewCameraMatrix
+    g = load_golden('cv_modes.npz')
+    for name in ('barrel', 'pincushion', 'c2'):
+        v = g['optK_in_' + name]
+        K, d, (w, h) = v[:9].reshape(3, 3), v[9:14], (int(v[14]), int(v[15]))
+        for alpha in (0, 1):
+            M, roi = getOptimalNewCameraMatrix(K, d, (w, h), alpha, (w, h))
+            want = g['optK_%s_a%d' % (name, alpha)]
+            assert np.allclose(M, want, rtol=1e-6, atol=1e-6), (name, alpha, M, want)
+            want_roi = [int(r) for r in g['optroi_%s_a%d' % (name, alpha)]]
+            if alpha == 1:
+                assert [int(r) for r in roi] == want_roi, (name, roi, want_roi)
+            else:
+                # alpha = 0 maps the inner rectangle EXACTLY onto [0, W-1]: ceil / floor of a value
+                # that is an integer up to the convergence error of the inverse lens model
+                assert all(abs(int(a) - b) <= 1 for a, b in zip(roi, want_roi)), (name, roi)

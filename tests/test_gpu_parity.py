@@ -737,3 +737,24 @@ def test_errors(ia):
                      np.zeros((4, 4), np.float32), out_dtype=np.float32)
     with pytest.raises(ValueError):
         ia.ops.undistort(img, np.eye(3), np.zeros(5), np.zeros((3, 3)))  # singular newK
+
+
+def test_cv_modes_vs_independent_restatements(ia, oracle):
+    """the GPU path against the second, independently written numpy restatements of the
+    cv2-specific modes (cv_modes.npz; the oracle is checked against the same fixtures in
+    test_oracle_golden.py).  These are the DEFAULTS of the reference's classes:
+    PerspectiveCorrection.correct = Lanczos4, uncorrect / distort = bicubic a=-0.75 at 1/32 px,
+    cv2.remap on uint8 = 15-bit fixed point."""
+    g = load_golden('cv_modes.npz')
+    img, img8 = g['img'], g['img8']
+    for name in ('radial', 'strong'):
+        mx, my = g['mapx_' + name], g['mapy_' + name]
+        for cname, cv in (('c0', 0.0), ('c037', 0.37)):
+            close32(ia.ops.remap(img, mx, my, 'linear_cv_q5', 'constant', cv),
+                    g['q5lin_%s_%s' % (name, cname)], 'q5 vs scipy ' + name, scale=1.0)
+        for key, iname in (('cubic075', 'cubic_cv'), ('cubic075q5', 'cubic_cv_q5'),
+                           ('cubic05', 'cubic'), ('lanczos4', 'lanczos4')):
+            close32(ia.ops.remap(img, mx, my, iname), g['%s_%s' % (key, name)],
+                    key + ' ' + name, scale=1.0)
+        assert np.array_equal(ia.ops.remap(img8, mx, my), g['u8fix_' + name])
+        assert np.array_equal(ia.ops.remap(img8, mx, my, border_value=17), g['u8fix17_' + name])

@@ -313,3 +313,44 @@ def test_known_answers(oracle):
         return oracle.warp_perspective(img, np.linalg.inv(M), img.shape,
                                        oracle.CUBIC_CV | oracle.Q5, oracle.REFLECT)
     assert np.abs(a - rotate(rotate(a, 14), -14)).mean() < 0.005
+
+
+# ---- cv2-specific modes against the independent numpy restatements (cv_modes.npz) ----------
+def _lanczos_table(oracle):
+    import ctypes as C
+    lib = oracle.lib()
+    tab = np.zeros((32, 8), np.float32)
+    for k in range(32):
+        row = np.zeros(8, np.float32)
+        lib.orc_lanczos4_weights(C.c_float(k / 32.0), row.ctypes.data_as(C.c_void_p))
+        tab[k] = row
+    return tab
+
+
+def test_cv_modes_independent_restatements(oracle):
+    """linear_cv_q5 == scipy at coordinates rounded to 1/32 px; Keys a=-0.75 / a=-0.5, Lanczos4
+    and the uint8 fixed-point bilinear against second, independently written numpy
+    restatements (tests/golden/gen_golden.py::gen_cv_modes).  Measured deviations are printed:
+    they are the margin these modes have against a different implementation of the same
+    definition - cv2 itself remains unavailable."""
+    g = load_golden('cv_modes.npz')
+    img, img8 = g['img'], g['img8']
+    worst = {}
+    for name in ('radial', 'strong'):
+        mx, my = g['mapx_' + name], g['mapy_' + name]
+        for cname, cv in (('c0', 0.0), ('c037', 0.37)):
+            got = oracle.remap(img, mx, my, oracle.LINEAR | oracle.Q5, oracle.CONSTANT, cv)
+            want = g['q5lin_%s_%s' % (name, cname)]
+            assert_close(got, want, 0, 3e-7, 'q5 ' + name + cname)
+        for key, iid in (('cubic075', oracle.CUBIC_CV), ('cubic075q5', oracle.CUBIC_CV | oracle.Q5),
+                         ('cubic05', oracle.CUBIC_KEYS), ('lanczos4', oracle.LANCZOS4)):
+            got = oracle.remap(img, mx, my, iid)
+            want = g['%s_%s' % (key, name)]
+            err = float(np.abs(got.astype(np.float64) - want).max())
+            worst[key] = max(worst.get(key, 0.0), err)
+            assert_close(got, want, 0, 2e-6, key + ' ' + name)
+        assert np.array_equal(oracle.remap(img8, mx, my), g['u8fix_' + name])
+        assert np.array_equal(oracle.remap(img8, mx, my, cval=17), g['u8fix17_' + name])
+    tab = _lanczos_table(oracle)
+    assert_close(tab, g['lanczos_tab'], 0, 2e-7, 'Lanczos4 table')
+    print('max |oracle - independent restatement|:', worst)
