@@ -24,6 +24,9 @@ struct ipa_tuning {
   int group = 0;          // 1: batches of >= group_min frames on the frame-group kernel
   int group_min = 2;
   int group_ring = 1;     // frame-group kernel samples from its LDS ring of source rows
+  int ring = 0;           // 1: clean strips of batches >= ring_min frames on the ring kernel
+  int ring_min = 2;
+  int ring_ablate = 0;    // measurement only: parts of the ring kernel switched off (wrong results)
 };
 
 struct ipa_ctx {
@@ -39,6 +42,9 @@ struct ipa_ctx {
   void* tab = nullptr;
   size_t tab_bytes = 0;
   void* tab_pinned = nullptr;  // pinned staging so the H2D is truly stream-ordered
+  // per-call strip plans of the ring kernels (device only, stream-ordered reuse)
+  void* plan = nullptr;
+  size_t plan_bytes = 0;
   std::mutex mu;
 };
 
@@ -48,6 +54,7 @@ struct ipa_event {
 
 void ipa_set_error(ipa_ctx* ctx, const char* fmt, ...);
 int ipa_ws_reserve(ipa_ctx* ctx, size_t bytes);                         // ctx->ws >= bytes
+int ipa_plan_reserve(ipa_ctx* ctx, size_t bytes);                       // ctx->plan >= bytes
 int ipa_tab_upload(ipa_ctx* ctx, const void* host, size_t bytes, void** d);  // stream-ordered
 
 #define IPA_HIP(ctx, call)                                                            \

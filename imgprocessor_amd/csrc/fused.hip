@@ -13,6 +13,9 @@ int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
 // fused_group.hip: batches, one workgroup per strip of 4 frames; 1 = not covered
 int ipa_fused_group_launch(ipa_ctx*, const FusedCall&, int K, int use_ring);
+// fused_ring.hip: plans the strips, runs the clean ones on the ring kernel and sets f.p.skip for
+// the per-frame kernel launched afterwards; 1 = not covered (f untouched)
+int ipa_fused_ring_launch(ipa_ctx*, FusedCall&, int K);
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
 static int inv3f(const double* m, double* o) {
@@ -107,6 +110,10 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
       IPA_HIP(ctx, hipGetLastError());
       return IPA_OK;
     }
+  }
+  if (ctx->tune.ring && n_frames >= ctx->tune.ring_min) {
+    rc = ipa_fused_ring_launch(ctx, f, kh);
+    if (rc < 0) return rc;
   }
   switch (kh) {
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;

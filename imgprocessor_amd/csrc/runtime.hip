@@ -65,6 +65,9 @@ const TuneName kTuneNames[] = {
     {"group", "IPA_GROUP", &ipa_tuning::group},
     {"group_min", "IPA_GROUP_MIN", &ipa_tuning::group_min},
     {"group_ring", "IPA_GROUP_RING", &ipa_tuning::group_ring},
+    {"ring", "IPA_RING", &ipa_tuning::ring},
+    {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
+    {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
 };
 }  // namespace
 
@@ -134,6 +137,7 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   if (c->ws) (void)hipFree(c->ws);
   if (c->tab) (void)hipFree(c->tab);
+  if (c->plan) (void)hipFree(c->plan);
   if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -272,6 +276,21 @@ int ipa_ws_reserve(ipa_ctx* c, size_t bytes) {
   size_t want = bytes + (bytes >> 2) + (1u << 20);
   IPA_HIP(c, hipMalloc(&c->ws, want));
   c->ws_bytes = want;
+  return IPA_OK;
+}
+
+int ipa_plan_reserve(ipa_ctx* c, size_t bytes) {
+  if (c->plan_bytes >= bytes) return IPA_OK;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipStreamSynchronize(c->stream));
+  if (c->plan) {
+    IPA_HIP(c, hipFree(c->plan));
+    c->plan = nullptr;
+    c->plan_bytes = 0;
+  }
+  size_t want = bytes + (bytes >> 1) + (1u << 16);
+  IPA_HIP(c, hipMalloc(&c->plan, want));
+  c->plan_bytes = want;
   return IPA_OK;
 }
 

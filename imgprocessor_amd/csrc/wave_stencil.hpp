@@ -97,6 +97,8 @@ struct WaveParams {
   unsigned strips;     // per frame
   int vec_out;
   int frames_inner;    // 0: grid.y = frame; n: 1-D grid, frame index fastest (see the kernel)
+  // strips another kernel computes (ring_stencil.hpp): skip[strip] != 0 -> nothing to do here
+  const unsigned* skip = nullptr;
 };
 
 // grid for a launch over n_frames; fills p.frames_inner
@@ -481,6 +483,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   __shared__ __attribute__((aligned(16))) float xpose[kLead + IPA_WPB * kXp + kLead];
   float* xp = xpose + kLead + wave * kXp;
   if (sid >= p.strips) return;  // whole wave
+  if (p.skip && p.skip[sid]) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
   src.set_frame(frame);
 

@@ -78,7 +78,7 @@ int ipa_ctx_create(int device_id, ipa_ctx** ctx);
 int ipa_ctx_destroy(ipa_ctx* ctx);
 int ipa_ctx_synchronize(ipa_ctx* ctx);
 /* Launch-shape knobs of a context ("strip_h", "frames_inner", "big_wave", "big_fused",
- * "stream_k", "group", "group_min", "group_ring").  ipa_ctx_create reads
+ * "stream_k", "ring", "ring_min", "group", "group_min", "group_ring").  ipa_ctx_create reads
  * their IPA_* environment defaults once; no launch path consults the environment.  The
  * reference has no counterpart (its numba / cv2 calls take no launch parameters). */
 int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value);

@@ -1,6 +1,7 @@
-"""GPU: the frame-group kernel (csrc/group_stencil.hpp: one workgroup per strip of 4 frames,
-shared footprint records, bilinear taps from an LDS ring of source rows) against the per-frame
-marching kernel - the same arithmetic, so the results must agree BIT FOR BIT - and against the
+"""GPU: the ring kernel (csrc/ring_stencil.hpp: planned clean strips, bilinear taps from an LDS
+ring of source rows, the other strips left to the per-frame kernel through a skip mask) and the
+experimental frame-group kernel (csrc/group_stencil.hpp: one workgroup per strip of 4 frames,
+shared footprint records) against the per-frame marching kernel - the same arithmetic, so the results must agree BIT FOR BIT - and against the
 oracle.  Geometries are chosen to exercise every branch: ring rows, rows that do not fit the
 ring (rotation), footprints on the source border, constant / reflect filter borders, rim
 strips, ragged sizes, batches that do not fill the last group.
@@ -54,10 +55,14 @@ def run_three(ia, src, mx, my, k, **kw):
     from imgprocessor_amd import ops
     ctx = ia.default_context(0)
     d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
-    old = ctx.set_tuning(group=0)
+    old = ctx.set_tuning(group=0, ring=0, group_min=1, group_ring=0, ring_min=1)
     try:
         ref = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
-        ctx.set_tuning(group=1, group_min=1, group_ring=0)
+        # clean strips on the ring kernel, the rest on the per-frame kernel (skip mask)
+        ctx.set_tuning(ring=1)
+        split = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
+        same_bits(split, ref, 'ring kernel + per-frame kernel')
+        ctx.set_tuning(ring=0, group=1)
         gat = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
         ctx.set_tuning(group_ring=1)
         ring = ops.remap_conv2d(d_src, dmx, dmy, k, **kw).get()
@@ -152,10 +157,15 @@ def test_group_analytic_sources(ia, oracle):
     k = kern(5, 3)
     d_src = ctx.to_device(src)
     M = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
-    old = ctx.set_tuning(group=0)
+    old = ctx.set_tuning(group=0, ring=0, ring_min=1)
     try:
         ref_u = ops.undistort_conv2d(d_src, K, dist, K, k).get()
         ref_h = ops.warp_perspective_conv2d(d_src, M, (h, w), k).get()
+        ctx.set_tuning(ring=1)
+        same_bits(ops.undistort_conv2d(d_src, K, dist, K, k).get(), ref_u, 'undistort, ring kernel')
+        same_bits(ops.warp_perspective_conv2d(d_src, M, (h, w), k).get(), ref_h,
+                  'homography, ring kernel')
+        ctx.set_tuning(ring=0)
         for ring in (0, 1):
             ctx.set_tuning(group=1, group_min=1, group_ring=ring)
             same_bits(ops.undistort_conv2d(d_src, K, dist, K, k).get(), ref_u,
