@@ -128,7 +128,7 @@ def pmc_traffic(variant, batch, h, w):
             return e['traffic_bytes_per_launch'], ('recorded: profiles/pmc_summary.json (%s; '
                                                    'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, '
                                                    'separate passes of this command)'
-                                                   % e.get('tag', 'r02'))
+                                                   % e.get('round', 'r02'))
         return None, 'no PMC pass recorded for variant=%s batch=%d %dx%d' % (variant, batch, w, h)
     except (OSError, ValueError, KeyError):
         return None, 'profiles/pmc_summary.json missing'

@@ -48,6 +48,8 @@ def main():
     ap.add_argument('--batch', type=int, default=16)
     ap.add_argument('--height', type=int, default=2160)
     ap.add_argument('--width', type=int, default=3840)
+    ap.add_argument('--csv-only', action='store_true',
+                    help='write only <tag>_pmc.csv (e.g. a pass over the other_configs kernels)')
     a = ap.parse_args()
 
     stats = find(a.stats_dir, '*kernel_stats.csv')
@@ -61,6 +63,8 @@ def main():
         for k in sorted(set(fetch) | set(write)):
             w.writerow([k, fetch.get(k, (0, 0))[1], '%.1f' % fetch.get(k, (0, 0))[0],
                         '%.1f' % write.get(k, (0, 0))[0]])
+    if a.csv_only:
+        return
     # dominant kernel = largest fetch
     dom = max(fetch, key=lambda k: fetch[k][0])
     traffic = (2 * fetch[dom][0] + write.get(dom, (0, 0))[0]) * 1024
