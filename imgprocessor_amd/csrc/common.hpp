@@ -45,7 +45,8 @@ struct ipa_ctx {
   // per-call strip plans of the ring kernels (device only, stream-ordered reuse)
   void* plan = nullptr;
   size_t plan_bytes = 0;
-  std::mutex mu;
+  // No lock here: a context (stream + workspaces) belongs to ONE host thread at a time
+  // (INTEGRATION.md section 4); the Python layer hands every thread its own default context.
 };
 
 struct ipa_event {

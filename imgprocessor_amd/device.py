@@ -244,17 +244,22 @@ class DeviceArray(object):
             pass
 
 
-_default = {}
-_lock = threading.Lock()
+_default = threading.local()
 
 
 def default_context(device_id=0):
-    """process-wide context of a device (created on first use)"""
-    with _lock:
-        c = _default.get(device_id)
-        if c is None or c.handle is None:
-            c = _default[device_id] = Context(device_id)
-        return c
+    """the calling THREAD's context of a device (created on first use).  A context owns one
+    stream and one staging workspace and is not re-entrant (ctypes releases the GIL during a
+    call), so the implicit context every drop-in wrapper falls back to must not be shared between
+    host threads: each thread gets its own.  Pass an explicit ``ctx=`` (or DeviceArrays, which
+    carry theirs) to share one deliberately."""
+    d = getattr(_default, 'ctx', None)
+    if d is None:
+        d = _default.ctx = {}
+    c = d.get(device_id)
+    if c is None or c.handle is None:
+        c = d[device_id] = Context(device_id)
+    return c
 
 
 def device_count():
