@@ -62,6 +62,8 @@ PROTOTYPES = {
     'ipa_sepconv2d': [_vp, _vp, _i, _i, _i, _dp, _i, _dp, _i, _vp, _i, _i, _i, _d],
     'ipa_extend_array_dev': [_vp, _vp, _i, _i, _i, _l, _i, _i, _i, _i, _vp, _l],
     'ipa_conv_ydep_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _i, _i, _vp, _l],
+    'ipa_var_y_gauss_dev': [_vp, _vp, _i, _i, _i, _l, C.c_double, C.c_double, _i,
+                            C.POINTER(C.c_double), _i, _i, _i, _vp, _l],
     'ipa_local_std_dev': [_vp, _vp, _vp, _i, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_masked_mean_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],
     'ipa_masked_median_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _l, _i, _i, _vp, _l],

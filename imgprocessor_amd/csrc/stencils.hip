@@ -179,11 +179,40 @@ masked_mean_fill_wave_kernel(T* grid, const unsigned char* __restrict__ mask, in
     const int ww = ymx - ymn, ntap = (xmx - xmn) * ww;
     double val = 0.0;
     int n = 0;
-    for (int t = lane; t < ntap; t += 64) {
-      const int dy = t / ww, ii = xmn + dy, jj = ymn + (t - dy * ww);
-      if (!mask[(long)ii * mpitch + jj]) {
-        val += (double)grid[(long)ii * pitch + jj];
-        n++;
+    if (ww <= 64) {
+      // lanes over the columns of a window row (two rows per pass when the window is at most
+      // 32 wide): no per-tap division, and mask + value of EIGHT rows are loaded back to back
+      // before any of them is looked at - the loop was bound by the latency of one dependent
+      // mask -> value load pair per pass
+      const bool two = ww <= 32;
+      const int half = two ? lane >> 5 : 0, step = two ? 2 : 1;
+      const int cl = two ? (lane & 31) : lane;
+      const bool col_ok = cl < ww;
+      const int jj = ymn + (col_ok ? cl : 0);
+      for (int ii = xmn + half; ii < xmx; ii += 8 * step) {
+        unsigned char m[8];
+        T g[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int r = ii + u * step < xmx ? ii + u * step : xmx - 1;
+          m[u] = mask[(long)r * mpitch + jj];
+          g[u] = grid[(long)r * pitch + jj];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          if (col_ok && ii + u * step < xmx && !m[u]) {
+            val += (double)g[u];
+            n++;
+          }
+        }
+      }
+    } else {
+      for (int t = lane; t < ntap; t += 64) {
+        const int dy = t / ww, ii = xmn + dy, jj = ymn + (t - dy * ww);
+        if (!mask[(long)ii * mpitch + jj]) {
+          val += (double)grid[(long)ii * pitch + jj];
+          n++;
+        }
       }
     }
 #pragma unroll
@@ -470,6 +499,10 @@ median_threshold_kernel(const T* __restrict__ img, const T* __restrict__ bg,
 
 using namespace ipa;
 
+int ipa_local_std_wave_launch(ipa_ctx* ctx, const void* img, const void* blurred, int dtype, int h,
+                              int w, long pitch, long bpitch, int hkx, int hky, void* out,
+                              long opitch);  // stencils_ydep.hip
+
 extern "C" {
 
 static int median_threshold_launch(ipa_ctx* ctx, const void* d_img, int dtype, const void* d_bg,
@@ -703,6 +736,12 @@ int ipa_local_std_dev(ipa_ctx* ctx, const void* d_img, const void* d_blurred, in
   dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   const int hkx = ksize_x / 2, hky = ksize_y / 2;
+  // square windows up to 11: 256-px tiles, 4 pixels per lane (stencils_ydep.hip)
+  if (ipa_local_std_wave_launch(ctx, d_img, d_blurred, dtype, h, w, pitch, blurred_pitch, hkx, hky,
+                                d_out, out_pitch) == 0) {
+    IPA_HIP(ctx, hipGetLastError());
+    return IPA_OK;
+  }
   const size_t lds = (size_t)(64 + 2 * hky) * (4 + 2 * hkx) * (dtype == IPA_F32 ? 4 : 8);
   if (lds <= 48 * 1024) {  // the block's window fits in LDS: staged version
     if (dtype == IPA_F32)

@@ -2,12 +2,14 @@
 
 A Gaussian whose sigma along y changes from row to row.  The per-row k0 x k1
 coefficient tables are what the reference builds with one ``gaussian_filter``
-call per row on a centred delta (:40-46); the delta is separable, so here they
-are the outer products of vectorised 1-D responses (same weights, truncation
-and reflection; equal to the reference's tables to rounding).  The
-O(H·W·k0·k1) NaN-skipping correlation (:53-68) runs as a HIP
-kernel with the borders resolved on the fly (defaults modex='wrap',
-modey='reflect', like the reference's padding).
+call per row on a centred delta (:40-46); the delta is separable, so a table is
+the outer product of two 1-D responses (same weights, truncation and
+reflection; equal to the reference's tables to rounding).  The y responses of
+all rows are computed ON THE DEVICE (``ipa_var_y_gauss_dev``), and the
+O(H·W·k0·k1) NaN-skipping correlation (:53-68) forms its coefficients on the fly
+with the borders resolved while staging (defaults modex='wrap',
+modey='reflect', like the reference's padding).  ``_row_kernels`` (host tables)
+remains for ``ops.conv_ydep`` callers with arbitrary tables and for the tests.
 
 ``stdyrange`` as an ndarray raises UnboundLocalError in the reference (``mx``
 is never set on that branch); only the int / (mn, mx) forms are defined.
@@ -60,7 +62,6 @@ def varYSizeGaussianFilter(arr, stdyrange, stdx=0, modex='wrap', modey='reflect'
     if type(stdyrange) not in (list, tuple):
         stdyrange = (0, stdyrange)
     mn, mx = stdyrange
-    stdys = np.linspace(mn, mx, s0)
     kx = int(stdx * 2.5)
     kx += 1 - kx % 2
     ky = int(mx * 2.5)
@@ -69,5 +70,7 @@ def varYSizeGaussianFilter(arr, stdyrange, stdx=0, modex='wrap', modey='reflect'
         raise Exception('modey not supported')
     if modex not in ('reflect', 'wrap'):
         raise Exception('modex not supported')
-    kernels = _row_kernels(stdys, stdx, ky, kx)
-    return ops.conv_ydep(arr, kernels, modex=modex, modey=modey, ctx=ctx)
+    # the per-row tables are separable (delta input): the y responses of all rows are built on
+    # the device from (mn, mx); only the kx x-responses are computed here
+    rowk = _delta_response(kx, [stdx])[0]
+    return ops.var_y_gauss(arr, mn, mx, ky, rowk, modex=modex, modey=modey, ctx=ctx)

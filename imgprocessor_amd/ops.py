@@ -345,6 +345,24 @@ def conv_ydep(arr, kernels, modex='wrap', modey='reflect', ctx=None):
     return d_out.get()
 
 
+def var_y_gauss(arr, sig_min, sig_max, ky, rowk, modex='wrap', modey='reflect', ctx=None):
+    """filters/varYSizeGaussianFilter.py:9-68 in one launch pair: per-row Gaussian tables built
+    on the device (stdys = linspace(sig_min, sig_max, H)), `rowk` = the kx x-responses"""
+    dev = _is_dev(arr)
+    ctx = _ctx_of(arr, ctx=ctx)
+    d_in = arr if dev else ctx.to_device(_float_img(arr))
+    if d_in.ndim != 2:
+        raise ValueError('var_y_gauss works on 2-D arrays')
+    h, w = d_in.shape
+    rk = np.ascontiguousarray(rowk, dtype=np.float64).ravel()
+    d_out = DeviceArray(ctx, (h, w), d_in.dtype)
+    ctx._check(ctx._lib.ipa_var_y_gauss_dev(
+        ctx.handle, d_in.ptr, dtype_id(d_in.dtype), h, w, w, float(sig_min), float(sig_max),
+        int(ky), rk.ctypes.data_as(C.POINTER(C.c_double)), rk.size, border_id(modex),
+        border_id(modey), d_out.ptr, w), 'var_y_gauss')
+    return d_out if dev else d_out.get()
+
+
 def local_std(img, blurred, ksize, ctx=None):
     """filters/standardDeviation.py:34-70 (_calc) for ksize=(kx, ky)"""
     dev = _is_dev(img)

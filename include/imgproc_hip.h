@@ -192,6 +192,14 @@ int ipa_sepconv2d(ipa_ctx* ctx, const void* src, int dtype, int h, int w, const 
 int ipa_conv_ydep_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
                       const double* d_kernels, int k0, int k1, int border_x, int border_y,
                       void* d_dst, long dst_pitch);
+/* filters/varYSizeGaussianFilter.py:9-50 in one call: the per-row Gaussian tables
+ * (gaussian_filter(delta, (stdys[r], stdx)) with stdys = linspace(sig_min, sig_max, h), :22-46) are
+ * built on the device as separable factors - `rowk` = the kx x-responses of the delta (host,
+ * kx doubles) - and the NaN-skipping row-dependent correlation (:53-68) forms the coefficients
+ * on the fly.  Returns after the launch has consumed `rowk`. */
+int ipa_var_y_gauss_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
+                        double sig_min, double sig_max, int ky, const double* rowk, int kx,
+                        int border_x, int border_y, void* d_dst, long dst_pitch);
 
 /* replaces filters/standardDeviation.py:34-70 (_calc): local standard deviation of
  * img around blurred[i,j] over the window [i-kx/2, min(i+kx/2, h)) x [j-ky/2, min(j+ky/2, w)),

@@ -53,6 +53,23 @@ def test_var_y_gauss_golden(ia):
     close32(got, g['out_0_4_1'], 'f32', scale=1.0)
     with pytest.raises(UnboundLocalError):  # the reference's ndarray branch is broken
         varYSizeGaussianFilter(g['arr'], np.ones(40))
+    # the device-built separable tables against the host tables through the generic kernel
+    # (arbitrary-table path), on a frame with several workgroups per axis, NaNs included
+    from imgprocessor_amd.filters.varYSizeGaussianFilter import _row_kernels
+    big = synth((301, 700), 9, np.float64)
+    big[17, 100:140] = np.nan
+    big[200:204, 650:] = np.nan
+    for dt, tol in ((np.float64, 1e-13), (np.float32, 1e-6)):
+        b = big.astype(dt)
+        for (rng, stdx, modex) in (((0, 10), 1, 'wrap'), ((2, 6), 0, 'reflect'), ((0, 3), 2.5, 'wrap')):
+            mn, mx = rng
+            kx = int(stdx * 2.5); kx += 1 - kx % 2
+            ky = int(mx * 2.5); ky += 1 - ky % 2
+            tab = _row_kernels(np.linspace(mn, mx, b.shape[0]), stdx, ky, kx)
+            want = ia.ops.conv_ydep(b, tab, modex=modex)
+            got = varYSizeGaussianFilter(b, rng, stdx, modex=modex)
+            assert got.dtype == dt
+            assert_close(got, want, tol, tol, 'device tables %s %s %s' % (dt.__name__, rng, stdx))
 
 
 def test_std2d_golden(ia):
