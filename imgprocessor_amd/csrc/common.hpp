@@ -27,6 +27,7 @@ struct ipa_tuning {
   int ring = 0;           // 1: clean strips of batches >= ring_min frames on the ring kernel
   int ring_min = 2;
   int ring_ablate = 0;    // measurement only: parts of the ring kernel switched off (wrong results)
+  int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
 };
 
 struct ipa_ctx {

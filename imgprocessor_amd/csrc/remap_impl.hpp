@@ -18,6 +18,7 @@
 
 #include "common.hpp"
 #include "sampler.hpp"
+#include "ring_remap.hpp"
 
 namespace ipa {
 
@@ -37,6 +38,9 @@ struct RemapParams {
   unsigned tiles_x, tiles;
   int dst_vec, map_vec;
   int frames_inner;  // n_frames when the grid is 1-D with the frame index fastest, else 0
+  // tiles the ring kernel computes (ring_remap.hpp): skip[strip row * tiles_x + tile column]
+  const unsigned* skip;
+  int skip_strip_h;
 };
 
 template <typename Coord>
@@ -111,6 +115,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     __syncthreads();
   }
   unsigned tyi = t / p.tiles_x, txi = t - tyi * p.tiles_x;
+  if (p.skip && p.skip[(tyi * 4u / (unsigned)p.skip_strip_h) * p.tiles_x + txi]) return;
   int x0 = (int)((txi * 64 + threadIdx.x) * 4);
   int y = (int)(tyi * 4 + threadIdx.y);
   if (y >= p.dh || x0 >= p.dw) return;
@@ -276,6 +281,60 @@ static inline bool aligned_rows(const void* base, long pitch_elems, long frame_e
   return true;
 }
 
+// plan + ring kernel for the clean strips of a batch; sets p.skip for remap_kernel.
+// Returns 1 when the call is not covered.
+template <int INTERP, typename Coord>
+static void ring_remap_launch_one(ipa_ctx* ctx, const RingGeom& gm, const RingRemapArgs& ra,
+                                  const Coord& coord, const RingPlan& plan) {
+  using RK = RingRemapKernel<INTERP, Coord>;
+  const unsigned groups = ((unsigned)ra.n_frames + RK::kWaves - 1) / RK::kWaves;
+  hipLaunchKernelGGL((ring_remap_kernel<INTERP, Coord>), dim3((unsigned)gm.strips * groups),
+                     dim3(64 * RK::kWaves), 0, ctx->stream, gm, ra, coord, plan);
+}
+
+template <typename Coord>
+static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, int base,
+                             int n_frames) {
+  RingGeom gm;
+  gm.dh = p.dh; gm.dw = p.dw;
+  gm.strips_x = (p.dw + kSW - 1) / kSW;
+  gm.pairs_x = (gm.strips_x + 1) / 2;  // == tiles_x of remap_kernel (256-px tiles)
+  gm.strip_h = 32;
+  const int rows = (p.dh + gm.strip_h - 1) / gm.strip_h;
+  gm.strips = gm.strips_x * rows;
+  gm.pairs = gm.pairs_x * rows;
+  if ((unsigned)gm.pairs_x != p.tiles_x) return 1;
+  const size_t info_b = (size_t)gm.strips * sizeof(int4);
+  const size_t cnts_b = (size_t)gm.strips * kPlanWords * sizeof(unsigned);
+  const size_t pair_b = (size_t)gm.pairs * sizeof(unsigned);
+  int rc = ipa_plan_reserve(ctx, info_b + cnts_b + pair_b);
+  if (rc) return rc;
+  RingPlan plan;
+  plan.info = reinterpret_cast<int4*>(ctx->plan);
+  plan.cnts = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->plan) + info_b);
+  plan.pair_clean = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->plan) + info_b + cnts_b);
+  RingTaps tp;
+  tp.nt = base == IPA_INTER_LINEAR ? 2 : (base == IPA_INTER_LANCZOS4 ? 8 : 4);
+  tp.q5 = (p.q5 || base == IPA_INTER_LANCZOS4) ? 1 : 0;
+  tp.rr = base == IPA_INTER_LANCZOS4 ? ring_rows<kLanczos4>::value : ring_rows<kLinear>::value;
+  hipLaunchKernelGGL((ring_plan_kernel<Coord, 1>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
+                     coord, p.sh, p.sw, tp, plan);
+  RingRemapArgs ra;
+  ra.dst = p.dst; ra.dst_frame_elems = p.dst_frame_elems; ra.dpitch = p.dpitch;
+  ra.src = p.src; ra.src_frame_bytes = p.src_frame_bytes; ra.src_bytes = p.src_bytes;
+  ra.spitch = p.spitch; ra.n_frames = n_frames; ra.q5 = p.q5; ra.cubic_a = p.cubic_a;
+  ra.lanczos = p.lanczos;
+  switch (base) {
+    case IPA_INTER_LINEAR: ring_remap_launch_one<kLinear, Coord>(ctx, gm, ra, coord, plan); break;
+    case IPA_INTER_CUBIC_CV:
+    case IPA_INTER_CUBIC_KEYS: ring_remap_launch_one<kCubic, Coord>(ctx, gm, ra, coord, plan); break;
+    default: ring_remap_launch_one<kLanczos4, Coord>(ctx, gm, ra, coord, plan); break;
+  }
+  p.skip = plan.pair_clean;
+  p.skip_strip_h = gm.strip_h;
+  return 0;
+}
+
 template <typename Coord>
 static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, int map_vec) {
   if (!ctx) return IPA_ERR_BAD_ARG;
@@ -325,6 +384,23 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   p.frames_inner = inner ? a.n_frames : 0;
   dim3 grid = inner ? dim3(p.tiles * (unsigned)a.n_frames, 1) : dim3(p.tiles, (unsigned)a.n_frames);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
+  p.skip = nullptr;
+  p.skip_strip_h = 4;
+  // batches of float32 frames: the clean strips on the ring kernel (taps from LDS), the rest
+  // below behind the skip mask
+  // (ring_remap = 1: where it measured faster - 16 x 4K frames, gather -> ring + rest + plan:
+  // Lanczos4 1164 -> 799 us (map), 1228 -> 1073 (homography), 1099 -> 861 (lens model); bicubic
+  // 477 -> 402 us from maps but 471 -> 562 / 456 -> 537 with coordinates computed in the kernel,
+  // bilinear 369 -> 354 / 336 -> 379 / 343 -> 363; ring_remap = 2: every covered case)
+  const bool ring_pays = base == IPA_INTER_LANCZOS4 ||
+                         (std::is_same<Coord, MapCoord>::value &&
+                          (base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS));
+  if ((ctx->tune.ring_remap > 1 || (ctx->tune.ring_remap == 1 && ring_pays)) &&
+      a.n_frames >= ctx->tune.ring_min && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
+      base != IPA_INTER_NEAREST) {
+    rc = ring_remap_launch<Coord>(ctx, p, coord, base, a.n_frames);
+    if (rc < 0) return rc;
+  }
 
   int s = a.src_dt, d = a.dst_dt;
   if (s == IPA_F32 && d == IPA_F32) {

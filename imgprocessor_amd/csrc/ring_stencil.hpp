@@ -45,6 +45,13 @@ struct RingPlan {
   unsigned* pair_clean;  // per strip pair (= one strip of wave_stencil_kernel): 1 = both clean
 };
 
+// footprint of the interpolation the plan is made for
+struct RingTaps {
+  int nt;                // taps per axis (2 bilinear, 4 bicubic, 8 Lanczos4)
+  int q5;                // coordinates rounded to 1/32 px first (cv2's rule; always for Lanczos4)
+  int rr;                // ring rows the kernel keeps (power of two)
+};
+
 struct RingGeom {
   int dh, dw;            // output (= filter domain)
   int strips_x;          // 128-px strips per strip row
@@ -91,7 +98,7 @@ __device__ __forceinline__ void ring_coords(const Coord& coord, int xs, int v0, 
 // ------------------------------------------------------------------------- planning --
 template <typename Coord, int K>
 __global__ void __launch_bounds__(128)
-ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingPlan plan) {
+ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan plan) {
   using C = typename Coord::coord_t;
   using G = group_geom<K>;
   __shared__ int flag[2];
@@ -112,7 +119,8 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingPlan plan) {
                y0 - G::H + T <= gm.dh && nsteps <= 8 * kPlanWords;
 
   SrcView s;  // only what axis_frac reads
-  s.q5 = 0;
+  s.q5 = tp.q5;
+  const int nt = tp.nt, back = tp.nt / 2 - 1;  // first tap = floor(coordinate) - back
   int sxmin = INT_MAX, sxmax = INT_MIN, ybase = 0, hrun = 0, cnt0 = 0;
   unsigned words[kPlanWords];
 #pragma unroll
@@ -135,9 +143,11 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingPlan plan) {
                         sy[k] > (C)-kCoordLimit && sy[k] < (C)kCoordLimit;
         int ix0, iy0;
         float tx, ty;
-        axis_frac<kLinear, float, C, 0>(s, ok ? sx[k] : (C)0, ix0, tx);
-        axis_frac<kLinear, float, C, 0>(s, ok ? sy[k] : (C)0, iy0, ty);
-        const bool inside = ok && ix0 >= 0 && iy0 >= 0 && ix0 + 2 <= sw && iy0 + 2 <= sh;
+        axis_frac<kLinear, float, C, -1>(s, ok ? sx[k] : (C)0, ix0, tx);
+        axis_frac<kLinear, float, C, -1>(s, ok ? sy[k] : (C)0, iy0, ty);
+        ix0 -= back;
+        iy0 -= back;
+        const bool inside = ok && ix0 >= 0 && iy0 >= 0 && ix0 + nt <= sw && iy0 + nt <= sh;
         bad = bad || (live && !inside);
         const bool use = live && inside;
         const int xl = use ? ix0 : INT_MAX, xh = use ? ix0 : INT_MIN;
@@ -148,25 +158,25 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingPlan plan) {
         ymx = yh > ymx ? yh : ymx;
       }
       wave_span(xmn, xmx, ymn, ymx);
-      if (__builtin_amdgcn_ballot_w64(bad) != 0 || ymx - ymn + 2 > kRR) {
+      if (__builtin_amdgcn_ballot_w64(bad) != 0 || ymx - ymn + nt > tp.rr) {
         clean = false;
         break;
       }
       sxmin = xmn < sxmin ? xmn : sxmin;
       sxmax = xmx > sxmax ? xmx : sxmax;
-      const int need = ymx + 2;
+      const int need = ymx + nt;
       int cnt;
       if (st == 0) {
         ybase = ymn;
         hrun = need;
-        cnt0 = need - ymn;  // <= kRR
+        cnt0 = need - ymn;  // <= rr
         cnt = 0;
       } else {
         cnt = need > hrun ? need - hrun : 0;
         hrun = need > hrun ? need : hrun;
       }
-      // the ring holds rows [max(ybase, hrun - kRR), hrun)
-      const int lowest = ybase > hrun - kRR ? ybase : hrun - kRR;
+      // the ring holds rows [max(ybase, hrun - rr), hrun)
+      const int lowest = ybase > hrun - tp.rr ? ybase : hrun - tp.rr;
       if (cnt > kRingMaxNew || ymn < lowest) {
         clean = false;
         break;
@@ -177,7 +187,7 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingPlan plan) {
     }
   }
   const int xlo = (sxmin & ~3) - 4;
-  if (clean && sxmax + 2 > xlo + kRW) clean = false;
+  if (clean && sxmax + nt > xlo + kRW) clean = false;
   if (exists && lane == 0) {
     plan.info[sid] = int4{clean ? 1 : 0, xlo, ybase, cnt0};
 #pragma unroll

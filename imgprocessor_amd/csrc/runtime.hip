@@ -68,6 +68,7 @@ const TuneName kTuneNames[] = {
     {"ring", "IPA_RING", &ipa_tuning::ring},
     {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
     {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
+    {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
 };
 }  // namespace
 

@@ -1,6 +1,6 @@
 """micro-benchmark helper (GPU box): times single entry points with HIP events.
 
-    python tests/bench_micro.py conv|copy|strip|remap|configs|stencils|host|pipeline
+    python tests/bench_micro.py conv|copy|strip|remap|ringremap|configs|stencils|host|pipeline
 
 conv / remap / strip: the filter, remap and fused kernels on 16 x 4K float32 frames
 (IPA_STRIP_H, IPA_FRAMES_INNER, IMGPROC_HIP_LIB select variants); configs: the BASELINE
@@ -69,6 +69,22 @@ if __name__ == '__main__':
         dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
         t = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst))
         print('fused_map strip_h=%s  %8.1f us %6.0f GB/s(16B/px)' % (sh, t, 16 * px / t / 1e3))
+    if what == 'ringremap':
+        dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
+        Hm = np.array([[0.97, 0.02, 20.0], [-0.015, 1.02, 12.5], [2e-6, -3e-6, 1.0]])
+        for interp in ('linear', 'cubic', 'lanczos4'):
+            for name, fn in (('map', lambda: ops.remap(src, dmx, dmy, interp, out=dst)),
+                             ('homography', lambda: ops.warp_perspective(src, Hm, (h, w), interp,
+                                                                         out=dst)),
+                             ('lens model', lambda: ops.undistort(src, Kc, dc, Kc, interp,
+                                                                  out=dst))):
+                ts = []
+                for on in (0, 2):
+                    old = ctx.set_tuning(ring_remap=on)
+                    ts.append(timeit(ctx, fn))
+                    ctx.set_tuning(**old)
+                print('%-9s %-11s gather %8.1f us   ring %8.1f us  (%5.1f Gpx/s)'
+                      % (interp, name, ts[0], ts[1], px / ts[1] / 1e3))
     if what == 'remap':
         dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
         for interp in ('nearest', 'linear', 'cubic', 'lanczos4'):

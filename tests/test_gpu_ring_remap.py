@@ -1,0 +1,149 @@
+"""GPU: the standalone ring remap (csrc/ring_remap.hpp: batches of float32 frames, clean strips
+sampled from an LDS ring of source rows, bilinear / bicubic / Lanczos4) against the gather
+kernel (csrc/remap_impl.hpp) - the same arithmetic in the same order, so the results must agree
+BIT FOR BIT - and against the oracle.
+"""
+import numpy as np
+import pytest
+
+from .conftest import assert_close
+from .test_gpu_group import frames, radial_maps, rot_maps, same_bits
+
+pytestmark = pytest.mark.gpu
+
+INTERPS = ['linear', 'linear_cv_q5', 'cubic', 'cubic_cv_q5', 'lanczos4']
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)
+    return imgprocessor_amd
+
+
+def orc_interp(oracle, name):
+    return {'linear': oracle.LINEAR, 'linear_cv_q5': oracle.LINEAR | oracle.Q5,
+            'cubic': oracle.CUBIC_KEYS, 'cubic_cv': oracle.CUBIC_CV,
+            'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5, 'lanczos4': oracle.LANCZOS4}[name]
+
+
+def both(ia, fn):
+    """fn() with the gather kernel alone, then with the ring kernel taking the clean strips"""
+    ctx = ia.default_context(0)
+    old = ctx.set_tuning(ring_remap=0, ring_min=1)
+    try:
+        ref = fn().get()
+        ctx.set_tuning(ring_remap=2)
+        got = fn().get()
+    finally:
+        ctx.set_tuning(**old)
+    return ref, got
+
+
+@pytest.mark.parametrize('interp', INTERPS)
+@pytest.mark.parametrize('shape,n', [((96, 300), 1), ((131, 517), 3), ((200, 1030), 6)])
+def test_ring_remap_radial(ia, oracle, interp, shape, n):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, interp))
+    same_bits(got, ref, '%s %r x%d' % (interp, shape, n))
+    want = oracle.remap(src[n - 1], mx, my, orc_interp(oracle, interp))
+    assert_close(got[n - 1], want, 1e-5, 1e-5 * np.abs(want).max(), interp + ' vs oracle')
+
+
+@pytest.mark.parametrize('interp', INTERPS)
+@pytest.mark.parametrize('case', ['rot3', 'rot20', 'rot90', 'shift_out', 'pincushion', 'flipx',
+                                  'zoom_out', 'zoom_in'])
+def test_ring_remap_geometries(ia, interp, case):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 150, 700, 5
+    src = frames(n, h, w)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    if case.startswith('rot'):
+        mx, my = rot_maps(h, w, float(case[3:]))
+    elif case == 'shift_out':
+        mx, my, _, _ = radial_maps(h, w, shift=-40.5)
+    elif case == 'pincushion':
+        mx, my, _, _ = radial_maps(h, w, k1=0.25)
+    elif case == 'flipx':
+        mx, my = (w - 1 - x + 0.25).astype(np.float32), (y + 0.5).astype(np.float32)
+    elif case == 'zoom_out':
+        mx, my = (x * 1.7 - 100).astype(np.float32), (y * 1.7 - 30).astype(np.float32)
+    else:
+        mx, my = (x * 0.31 + 7.3).astype(np.float32), (y * 0.31 + 3.1).astype(np.float32)
+    d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    for kw in ({}, {'border_mode': 'reflect'}, {'border_mode': 'replicate', 'border_value': 0.5}):
+        ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, interp, **kw))
+        same_bits(got, ref, '%s %s %r' % (case, interp, kw))
+
+
+@pytest.mark.parametrize('interp', INTERPS)
+def test_ring_remap_analytic_sources(ia, interp):
+    """lens model and homography evaluated in the kernel"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 140, 900, 6
+    src = frames(n, h, w)
+    _, _, K, dist = radial_maps(h, w)
+    d_src = ctx.to_device(src)
+    M = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
+    ref, got = both(ia, lambda: ops.undistort(d_src, K, dist, K, interp))
+    same_bits(got, ref, 'undistort ' + interp)
+    ref, got = both(ia, lambda: ops.warp_perspective(d_src, M, (h, w), interp))
+    same_bits(got, ref, 'homography ' + interp)
+    ref, got = both(ia, lambda: ops.warp_perspective(d_src, M, (h + 37, w - 101), interp))
+    same_bits(got, ref, 'homography, other output size ' + interp)
+
+
+def test_ring_remap_nan_and_far_coordinates(ia):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 80, 600, 4
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    mx = mx.copy(); my = my.copy()
+    mx[10, 50:60] = np.nan
+    my[20, 300:310] = np.inf
+    mx[30, 400:420] = 3e7
+    mx[40:44, :] = -5.0
+    d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    for interp in INTERPS:
+        ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, interp, border_value=0.25))
+        same_bits(got, ref, interp)
+
+
+@pytest.mark.parametrize('interp', ['linear', 'cubic', 'lanczos4'])
+def test_ring_remap_4k(ia, oracle, interp):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 2160, 3840, 3
+    src = frames(n, h, w)
+    d_src = ctx.to_device(src)
+    M = np.array([[0.97, 0.02, 20.0], [-0.015, 1.02, 12.5], [2e-6, -3e-6, 1.0]])
+    ref, got = both(ia, lambda: ops.warp_perspective(d_src, M, (h, w), interp))
+    same_bits(got, ref, '4K homography ' + interp)
+    mx, my, _, _ = radial_maps(h, w)
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, interp))
+    same_bits(got, ref, '4K map ' + interp)
+    sub = slice(1000, 1100)
+    want = oracle.remap(src[2], mx, my, orc_interp(oracle, interp))
+    assert_close(got[2][sub], want[sub], 1e-5, 1e-5 * np.abs(want).max(), '4K vs oracle')
+
+
+def test_ring_remap_other_dtypes_take_the_gather_kernel(ia):
+    """integer frames and float64 are not covered by the ring kernel: same results either way"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 100, 400, 3
+    mx, my, _, _ = radial_maps(h, w)
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    for dt in (np.uint16, np.float64):
+        d_src = ctx.to_device(frames(n, h, w, dt) if dt == np.uint16 else frames(n, h, w).astype(dt))
+        ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, 'cubic'))
+        assert np.array_equal(ref, got)
