@@ -27,6 +27,7 @@ struct ipa_tuning {
   int ring = 0;           // 1: clean strips of batches >= ring_min frames on the ring kernel
   int ring_min = 2;
   int ring_ablate = 0;    // measurement only: parts of the ring kernel switched off (wrong results)
+  int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
 };
 
@@ -46,6 +47,19 @@ struct ipa_ctx {
   // per-call strip plans of the ring kernels (device only, stream-ordered reuse)
   void* plan = nullptr;
   size_t plan_bytes = 0;
+  // what the plan buffer holds when it can be reused by the next call (coordinate sources given
+  // by value: lens model, homography): the source's parameters + geometry; n = 0: nothing.
+  // ipa_plan_reserve() clears it, the user that wants reuse sets it after filling the buffer.
+  double plan_key[40];
+  int plan_key_n = 0;
+  // float32 coordinate maps of the last lens model a fused undistort + filter call was made
+  // with (what LensDistortion.getUndistortRectifyMap caches, camera/LensDistortion.py:344-345):
+  // the next call with the same K, distortion, newK and size reads them instead of evaluating
+  // the model per pixel and frame
+  void* lens_map = nullptr;
+  size_t lens_map_bytes = 0;
+  double lens_key[25];
+  int lens_key_n = 0;
   // No lock here: a context (stream + workspaces) belongs to ONE host thread at a time
   // (INTEGRATION.md section 4); the Python layer hands every thread its own default context.
 };
@@ -56,6 +70,8 @@ struct ipa_event {
 
 void ipa_set_error(ipa_ctx* ctx, const char* fmt, ...);
 int ipa_ws_reserve(ipa_ctx* ctx, size_t bytes);                         // ctx->ws >= bytes
+int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, const double* newK,
+                        int h, int w, float** mx, float** my);
 int ipa_plan_reserve(ipa_ctx* ctx, size_t bytes);                       // ctx->plan >= bytes
 int ipa_tab_upload(ipa_ctx* ctx, const void* host, size_t bytes, void** d);  // stream-ordered
 

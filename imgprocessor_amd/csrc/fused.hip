@@ -199,6 +199,15 @@ int ipa_undistort_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, 
                                 int conv_border_x) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  if (ctx->tune.lens_cache) {
+    float *mx = nullptr, *my = nullptr;
+    int rc = ipa_lens_map_cached(ctx, K, dist5, newK, dh, dw, &mx, &my);
+    if (rc) return rc;
+    return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, mx, my, dw, ky, nky, kx,
+                                   nkx, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames,
+                                   src_frame_stride, dst_frame_stride, interp, border_mode,
+                                   border_value, conv_border_y, conv_border_x);
+  }
   FusedCall f;
   f.coord_kind = 1;
   UndistortCoord& c = f.und;
@@ -305,6 +314,18 @@ int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                              int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  if (ctx->tune.lens_cache) {
+    // the model's float32 coordinates are the same for every frame and every call with these
+    // parameters: evaluate them once (bit for bit what the per-pixel evaluation gives) and run
+    // the map-based kernels, 9x9 / 11x11 in one kernel included
+    float *mx = nullptr, *my = nullptr;
+    int rc = ipa_lens_map_cached(ctx, K, dist5, newK, dh, dw, &mx, &my);
+    if (rc) return rc;
+    return ipa_remap_conv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, mx, my, dw, kernel, kh, kw,
+                                d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                dst_frame_stride, interp, border_mode, border_value, conv_border_x,
+                                conv_border_y);
+  }
   void* tmp = nullptr;
   int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;

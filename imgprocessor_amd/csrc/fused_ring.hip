@@ -34,7 +34,7 @@ static int ring_launch(ipa_ctx* ctx, FusedCall& f, const Coord& c) {
   plan.pair_clean = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->plan) + info_b + cnts_b);
 
   hipLaunchKernelGGL((ring_plan_kernel<Coord, K>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
-                     c, f.sh, f.sw, RingTaps{2, 0, kRR}, plan);
+                     c, f.sh, f.sw, RingTaps{2, 0, kRR}, plan, nullptr, nullptr);
 
   RingSrc<ST, Coord> g;
   g.coord = c;

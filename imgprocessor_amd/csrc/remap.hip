@@ -126,6 +126,41 @@ static int stage_out(ipa_ctx* ctx, void* dst, const Staged& st) {
   return IPA_OK;
 }
 
+// the float32 maps of a lens model, kept in the context until another model or size is asked for
+int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, const double* newK,
+                        int h, int w, float** mx, float** my) {
+  double key[25];
+  for (int i = 0; i < 9; i++) key[i] = K[i];
+  for (int i = 0; i < 5; i++) key[9 + i] = dist5[i];
+  for (int i = 0; i < 9; i++) key[14 + i] = newK[i];
+  key[23] = (double)h;
+  key[24] = (double)w;
+  const size_t mb = ((size_t)h * w * 4 + 255) & ~(size_t)255;
+  const bool hit = ctx->lens_key_n == 25 && memcmp(ctx->lens_key, key, sizeof(key)) == 0;
+  if (!hit) {
+    ctx->lens_key_n = 0;
+    if (ctx->lens_map_bytes < 2 * mb) {
+      IPA_HIP(ctx, hipSetDevice(ctx->device));
+      IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier calls may still read the old maps
+      if (ctx->lens_map) {
+        IPA_HIP(ctx, hipFree(ctx->lens_map));
+        ctx->lens_map = nullptr;
+        ctx->lens_map_bytes = 0;
+      }
+      IPA_HIP(ctx, hipMalloc(&ctx->lens_map, 2 * mb));
+      ctx->lens_map_bytes = 2 * mb;
+    }
+    int rc = ipa_build_undistort_map_dev(ctx, K, dist5, newK, h, w, (float*)ctx->lens_map,
+                                         (float*)((char*)ctx->lens_map + mb), w);
+    if (rc) return rc;
+    memcpy(ctx->lens_key, key, sizeof(key));
+    ctx->lens_key_n = 25;
+  }
+  *mx = (float*)ctx->lens_map;
+  *my = (float*)((char*)ctx->lens_map + mb);
+  return IPA_OK;
+}
+
 extern "C" {
 
 int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dist5,

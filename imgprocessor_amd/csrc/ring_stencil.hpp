@@ -77,7 +77,7 @@ __device__ __forceinline__ void ring_coords(const Coord& coord, int xs, int v0, 
                                             typename Coord::coord_t (&sx)[4],
                                             typename Coord::coord_t (&sy)[4]) {
   const int lane = threadIdx.x & 63;
-  if constexpr (std::is_same<Coord, MapCoord>::value) {
+  if constexpr (coord_is_table<Coord>::value) {
     const int v[2] = {v0, v1};
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -98,7 +98,8 @@ __device__ __forceinline__ void ring_coords(const Coord& coord, int xs, int v0, 
 // ------------------------------------------------------------------------- planning --
 template <typename Coord, int K>
 __global__ void __launch_bounds__(128)
-ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan plan) {
+ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan plan,
+                 typename Coord::coord_t* outx, typename Coord::coord_t* outy) {
   using C = typename Coord::coord_t;
   using G = group_geom<K>;
   __shared__ int flag[2];
@@ -134,6 +135,15 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan
       const int v1 = live1 ? v0 + 1 : v0;
       C sx[4], sy[4];
       ring_coords<Coord>(coord, xs, v0, v1, sx, sy);
+      if (outx) {  // coordinates computed in the kernel: kept for the frames of the batch
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const unsigned o = (unsigned)((k >> 1) ? v1 : v0) * (unsigned)gm.dw +
+                             (unsigned)(xs + (int)lane + 64 * (k & 1));
+          outx[o] = sx[k];
+          outy[o] = sy[k];
+        }
+      }
       int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
       bool bad = false;
 #pragma unroll

@@ -69,6 +69,7 @@ const TuneName kTuneNames[] = {
     {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
     {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
+    {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
 };
 }  // namespace
 
@@ -139,6 +140,7 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   if (c->ws) (void)hipFree(c->ws);
   if (c->tab) (void)hipFree(c->tab);
   if (c->plan) (void)hipFree(c->plan);
+  if (c->lens_map) (void)hipFree(c->lens_map);
   if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
   (void)hipStreamDestroy(c->stream);
   delete c;
@@ -281,6 +283,7 @@ int ipa_ws_reserve(ipa_ctx* c, size_t bytes) {
 }
 
 int ipa_plan_reserve(ipa_ctx* c, size_t bytes) {
+  c->plan_key_n = 0;  // the caller overwrites the buffer
   if (c->plan_bytes >= bytes) return IPA_OK;
   IPA_HIP(c, hipSetDevice(c->device));
   IPA_HIP(c, hipStreamSynchronize(c->stream));

@@ -532,6 +532,23 @@ struct MapCoord {
   }
 };
 
+// coordinates a planning pass stored in the coordinate source's own type (ring_stencil.hpp):
+// the frames of a batch then read them instead of evaluating the source again
+template <typename T> struct StoredCoord {
+  using coord_t = T;
+  const T* mx;
+  const T* my;
+  long pitch;
+  __device__ __forceinline__ void get(int u, int v, T& sx, T& sy) const {
+    long o = (long)v * pitch + u;
+    sx = mx[o];
+    sy = my[o];
+  }
+};
+template <typename Coord> struct coord_is_table : std::false_type {};
+template <> struct coord_is_table<MapCoord> : std::true_type {};
+template <typename T> struct coord_is_table<StoredCoord<T>> : std::true_type {};
+
 // cv2.initUndistortRectifyMap with R = I evaluated per pixel in double and
 // rounded to the float32 a CV_32FC1 map stores (camera/LensDistortion.py:355-357).
 // No fp contraction here: the map builder, the analytic kernels and the CPU

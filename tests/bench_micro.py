@@ -71,7 +71,10 @@ if __name__ == '__main__':
         print('fused_map strip_h=%s  %8.1f us %6.0f GB/s(16B/px)' % (sh, t, 16 * px / t / 1e3))
     if what == 'ringremap':
         dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
-        Hm = np.array([[0.97, 0.02, 20.0], [-0.015, 1.02, 12.5], [2e-6, -3e-6, 1.0]])
+        from imgprocessor_amd.utils import getPerspectiveTransform
+        quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+        rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+        Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))  # the C3 / C5 warp
         for interp in ('linear', 'cubic', 'lanczos4'):
             for name, fn in (('map', lambda: ops.remap(src, dmx, dmy, interp, out=dst)),
                              ('homography', lambda: ops.warp_perspective(src, Hm, (h, w), interp,

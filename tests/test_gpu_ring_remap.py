@@ -147,3 +147,69 @@ def test_ring_remap_other_dtypes_take_the_gather_kernel(ia):
         d_src = ctx.to_device(frames(n, h, w, dt) if dt == np.uint16 else frames(n, h, w).astype(dt))
         ref, got = both(ia, lambda: ops.remap(d_src, dmx, dmy, 'cubic'))
         assert np.array_equal(ref, got)
+
+
+def test_ring_remap_plan_reuse(ia):
+    """sources given by value keep their plan + coordinates for the next call with the same
+    parameters: repeated, alternating and changed parameters all give the gather kernel's bits"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 140, 900, 4
+    src = frames(n, h, w)
+    d_src = ctx.to_device(src)
+    Ms = [np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]]),
+          np.array([[1.02, -0.01, -3.0], [0.015, 0.99, 1.5], [-1e-5, 1e-5, 1.0]])]
+    old = ctx.set_tuning(ring_remap=0, ring_min=1)
+    try:
+        want = {(i, interp): ops.warp_perspective(d_src, M, (h, w), interp).get()
+                for i, M in enumerate(Ms) for interp in ('cubic', 'lanczos4')}
+        ctx.set_tuning(ring_remap=2)
+        for i, interp in [(0, 'cubic'), (0, 'cubic'), (1, 'cubic'), (0, 'cubic'), (0, 'lanczos4'),
+                          (0, 'lanczos4'), (1, 'lanczos4'), (1, 'cubic'), (1, 'cubic')]:
+            got = ops.warp_perspective(d_src, Ms[i], (h, w), interp).get()
+            same_bits(got, want[(i, interp)], 'M%d %s' % (i, interp))
+        # another output size with the same matrix
+        ctx.set_tuning(ring_remap=0)
+        w2 = ops.warp_perspective(d_src, Ms[1], (h - 9, w - 130), 'cubic').get()
+        ctx.set_tuning(ring_remap=2)
+        same_bits(ops.warp_perspective(d_src, Ms[1], (h - 9, w - 130), 'cubic').get(), w2, 'size')
+        # a different source size with the same matrix and output size (another inside test)
+        src2 = ctx.to_device(frames(n, h - 20, w - 40))
+        ctx.set_tuning(ring_remap=0)
+        w3 = ops.warp_perspective(src2, Ms[1], (h - 9, w - 130), 'cubic').get()
+        ctx.set_tuning(ring_remap=2)
+        same_bits(ops.warp_perspective(src2, Ms[1], (h - 9, w - 130), 'cubic').get(), w3, 'src size')
+    finally:
+        ctx.set_tuning(**old)
+
+
+def test_lens_map_cache_matches_per_pixel_model(ia):
+    """fused undistort + filter: the cached float32 maps (default) against the lens model
+    evaluated in the kernel (lens_cache=0) - bit for bit, across changes of model and size"""
+    from imgprocessor_amd import ops
+    from .test_gpu_group import kern
+    ctx = ia.default_context(0)
+    h, w, n = 140, 900, 3
+    d_src = ctx.to_device(frames(n, h, w))
+    _, _, K, dist = radial_maps(h, w)
+    K2 = K.copy(); K2[0, 2] += 3.5
+    dist2 = dist * 0.5
+    g = ops.gaussian_kernel1d(1.0)
+    calls = [(K, dist, K), (K, dist, K), (K2, dist, K), (K, dist2, K2), (K, dist, K)]
+    for k in (kern(5, 2), kern(9, 4)):
+        old = ctx.set_tuning(lens_cache=0)
+        try:
+            want = [ops.undistort_conv2d(d_src, a, b, c, k).get() for a, b, c in calls]
+            want_s = [ops.undistort_sepconv2d(d_src, a, b, c, g, g).get() for a, b, c in calls]
+            ctx.set_tuning(lens_cache=1)
+            for i, (a, b, c) in enumerate(calls):
+                same_bits(ops.undistort_conv2d(d_src, a, b, c, k).get(), want[i], 'conv %d' % i)
+                same_bits(ops.undistort_sepconv2d(d_src, a, b, c, g, g).get(), want_s[i], 'sep %d' % i)
+            # a smaller frame with the same model
+            d2 = ctx.to_device(frames(n, h - 13, w - 77))
+            ctx.set_tuning(lens_cache=0)
+            w2 = ops.undistort_conv2d(d2, K, dist, K, k).get()
+            ctx.set_tuning(lens_cache=1)
+            same_bits(ops.undistort_conv2d(d2, K, dist, K, k).get(), w2, 'other size')
+        finally:
+            ctx.set_tuning(**old)
