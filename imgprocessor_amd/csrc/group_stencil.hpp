@@ -143,6 +143,12 @@ template <> struct PendRow<float> {
     *reinterpret_cast<float2*>(row + 2u * lane) = float2{a[0], a[1]};
     row[128u + (lane & 31u)] = b;  // both halves of the wave store the same value
   }
+  // column c at row[2 c]: one row of a row-pair-interleaved ring (ring_remap.hpp, Lanczos4)
+  __device__ __forceinline__ void write_every_other(float* row, unsigned lane) const {
+    row[4u * lane] = a[0];
+    row[4u * lane + 2u] = a[1];
+    row[2u * (128u + (lane & 31u))] = b;
+  }
 };
 template <> struct PendRow<uint16_t> {
   unsigned a;

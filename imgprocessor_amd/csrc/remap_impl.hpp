@@ -292,25 +292,9 @@ static void ring_remap_launch_one(ipa_ctx* ctx, const RingGeom& gm, const RingRe
                      dim3(64 * RK::kWaves), 0, ctx->stream, gm, ra, coord, plan);
 }
 
-// the parameters of a coordinate source given by value, for the plan buffer's reuse key
-static inline int coord_key(const MapCoord&, double*) { return 0; }
-static inline int coord_key(const UndistortCoord& c, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.ir[i];
-  const double v[10] = {c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.k3, (double)c.affine};
-  for (int i = 0; i < 10; i++) k[9 + i] = v[i];
-  return 19;
-}
-static inline int coord_key(const HomographyCoord& c, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.m[i];
-  return 9;
-}
-
 template <typename Coord>
 static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, int base,
                              int n_frames) {
-  using CT = typename Coord::coord_t;
-  constexpr bool kByValue = !std::is_same<Coord, MapCoord>::value;
-  using KCoord = typename std::conditional<kByValue, StoredCoord<CT>, MapCoord>::type;
   RingGeom gm;
   gm.dh = p.dh; gm.dw = p.dw;
   gm.strips_x = (p.dw + kSW - 1) / kSW;
@@ -320,50 +304,15 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
   gm.strips = gm.strips_x * rows;
   gm.pairs = gm.pairs_x * rows;
   if ((unsigned)gm.pairs_x != p.tiles_x) return 1;
-  if (kByValue && (size_t)p.dh * p.dw >= (1ull << 32)) return 1;  // 32-bit coordinate offsets
   RingTaps tp;
   tp.nt = base == IPA_INTER_LINEAR ? 2 : (base == IPA_INTER_LANCZOS4 ? 8 : 4);
   tp.q5 = (p.q5 || base == IPA_INTER_LANCZOS4) ? 1 : 0;
   tp.rr = base == IPA_INTER_LANCZOS4 ? ring_rows<kLanczos4>::value : ring_rows<kLinear>::value;
-  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  const size_t info_b = up((size_t)gm.strips * sizeof(int4));
-  const size_t cnts_b = up((size_t)gm.strips * kPlanWords * sizeof(unsigned));
-  const size_t pair_b = up((size_t)gm.pairs * sizeof(unsigned));
-  // sources given by value: the planning pass evaluates every coordinate of the clean strips
-  // anyway; it keeps them (in the source's own type, so the frames sample exactly what the
-  // gather kernel computes), and the next call with the same source and geometry skips the pass
-  const size_t coord_b = kByValue ? up((size_t)p.dh * p.dw * sizeof(CT)) : 0;
-  double key[40];
-  int kn = coord_key(coord, key);
-  if (kByValue) {
-    const double g[8] = {(double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw, (double)tp.nt,
-                         (double)tp.q5, (double)tp.rr, (double)sizeof(CT)};
-    for (int i = 0; i < 8; i++) key[kn++] = g[i];
-  }
-  const bool hit = kByValue && ctx->plan_key_n == kn &&
-                   memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0;
-  if (!hit) {
-    int rc = ipa_plan_reserve(ctx, info_b + cnts_b + pair_b + 2 * coord_b);
-    if (rc) return rc;
-  }
-  char* pb = reinterpret_cast<char*>(ctx->plan);
   RingPlan plan;
-  plan.info = reinterpret_cast<int4*>(pb);
-  plan.cnts = reinterpret_cast<unsigned*>(pb + info_b);
-  plan.pair_clean = reinterpret_cast<unsigned*>(pb + info_b + cnts_b);
-  CT* outx = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b) : nullptr;
-  CT* outy = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b + coord_b) : nullptr;
-  if (!hit) {
-    hipLaunchKernelGGL((ring_plan_kernel<Coord, 1>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
-                       coord, p.sh, p.sw, tp, plan, outx, outy);
-    if (kByValue) {
-      memcpy(ctx->plan_key, key, (size_t)kn * sizeof(double));
-      ctx->plan_key_n = kn;
-    }
-  }
-  KCoord kc;
-  if constexpr (kByValue) kc = KCoord{outx, outy, (long)p.dw};
-  else kc = coord;
+  typename ring_kernel_coord<Coord>::type kc;
+  int rc = ring_plan_prepare<Coord, 1>(ctx, gm, coord, p.sh, p.sw, tp, &plan, &kc);
+  if (rc) return rc;
+  using KCoord = typename ring_kernel_coord<Coord>::type;
   RingRemapArgs ra;
   ra.dst = p.dst; ra.dst_frame_elems = p.dst_frame_elems; ra.dpitch = p.dpitch;
   ra.src = p.src; ra.src_frame_bytes = p.src_frame_bytes; ra.src_bytes = p.src_bytes;

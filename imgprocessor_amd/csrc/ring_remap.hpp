@@ -48,6 +48,12 @@ template <int O0, int O1> __device__ __forceinline__ v2f lds_read2(int byte_addr
   asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(d) : "v"(byte_addr), "n"(O0), "n"(O1));
   return d;
 }
+// ds_read_b64 of an 8-byte-aligned address + byte offset (16-bit immediate)
+template <int OFF> __device__ __forceinline__ v2f lds_read_b64(int byte_addr) {
+  v2f d;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(byte_addr), "n"(OFF));
+  return d;
+}
 __device__ __forceinline__ void lds_wait_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <int INTERP> struct ring_rows { static constexpr int value = 8; };
@@ -71,11 +77,17 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
   static constexpr int NT = ntaps<INTERP>::value;
   static constexpr int RR = ring_rows<INTERP>::value;
   static constexpr int kSlots = RR + NT - 1;
+  // Lanczos4: rows in interleaved pairs - pair p = {row 2p, row 2p + 1}, column c of both at
+  // float 2c - so that ONE aligned ds_read_b64 (256 B/clk, twice ds_read2_b32) fetches two tap
+  // rows of a column.  A footprint starting on an odd row spans 5 pairs; the 4 pairs after the
+  // last one mirror the first 4.
+  static constexpr int kPairs = RR / 2, kPairSlots = RR / 2 + 4, kPairFloats = 2 * kRW;
+  static constexpr int kRingFloats = INTERP == kLanczos4 ? kPairSlots * kPairFloats : kSlots * kRW;
   // frames per workgroup: the Lanczos4 ring is 14.7 KB per wave
   static constexpr int kWaves = INTERP == kLanczos4 ? 2 : 4;
 
   struct Shared {
-    float ring[kWaves][kSlots * kRW];
+    float ring[kWaves][kRingFloats];
     float lz[INTERP == kLanczos4 ? 256 : 4];
   };
 
@@ -113,9 +125,16 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
     s.lanczos = sh.lz;
     float* ringw = sh.ring[wave];
     auto put_row = [&](const PendRow<float>& r, int y) {
-      const int slot = y & (RR - 1);
-      r.write(ringw + slot * kRW, lane);
-      if (slot < NT - 1) r.write(ringw + (slot + RR) * kRW, lane);  // mirror: no footprint wraps
+      if constexpr (INTERP == kLanczos4) {
+        const int ps = (y >> 1) & (kPairs - 1);
+        float* row = ringw + ps * kPairFloats + (y & 1);
+        r.write_every_other(row, lane);
+        if (ps < 4) r.write_every_other(row + kPairs * kPairFloats, lane);
+      } else {
+        const int slot = y & (RR - 1);
+        r.write(ringw + slot * kRW, lane);
+        if (slot < NT - 1) r.write(ringw + (slot + RR) * kRW, lane);  // mirror: no footprint wraps
+      }
     };
 
     int hres = __builtin_amdgcn_readfirstlane(info.z);  // rows [.., hres) are in the ring
@@ -160,6 +179,7 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
       int ad[4];
       float wx[4][kLz ? 1 : NT], wy[4][kLz ? 1 : NT];
       int kx[4], ky[4];
+      bool odd[4];  // Lanczos4: the footprint starts on the second row of its first pair
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         int ix0, iy0;
@@ -169,11 +189,13 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
           iy0 = (qy >> 5) - 3;
           kx[k] = (qx & 31) << 5;  // byte offset of the table row
           ky[k] = (qy & 31) << 5;
+          odd[k] = (iy0 & 1) != 0;
+          ad[k] = (__mul24((iy0 >> 1) & (kPairs - 1), kPairFloats) + 2 * (ix0 - xlo)) << 2;
         } else {
           axis_split<INTERP, float, C>(s, cx[k], ix0, wx[k]);
           axis_split<INTERP, float, C>(s, cy[k], iy0, wy[k]);
+          ad[k] = (__mul24(iy0 & (RR - 1), kRW) + (ix0 - xlo)) << 2;
         }
-        ad[k] = (__mul24(iy0 & (RR - 1), kRW) + (ix0 - xlo)) << 2;
       }
 #pragma unroll
       for (int k = 0; k < 4; k++) asm volatile("" : "+v"(ad[k]) : : "memory");
@@ -196,7 +218,54 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
       __builtin_amdgcn_wave_barrier();
       const int rbase = lds_address(ringw);
       float out[4];
-      constexpr int kBatch = kLz ? 1 : 4;
+      if constexpr (kLz) {
+        // (the reads of sample k + 1 issued between the fmas of sample k, two register sets:
+        // 198 VGPRs, 642 -> 708 us - one sample at a time it stays)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const char* lzb = reinterpret_cast<const char*>(sh.lz);
+          const float4* rx = reinterpret_cast<const float4*>(lzb + kx[k]);
+          const float4* ry = reinterpret_cast<const float4*>(lzb + ky[k]);
+          const float4 a0 = rx[0], a1 = rx[1], b0 = ry[0], b1 = ry[1];
+          const v2f wp[4] = {v2f{a0.x, a0.y}, v2f{a0.z, a0.w}, v2f{a1.x, a1.y}, v2f{a1.z, a1.w}};
+          const float uy[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+          // 5 pairs x 8 columns: rows 2 pb .. 2 pb + 9, of which the sample uses 8 from row
+          // `odd` on (the other two are never selected)
+          v2f t[5][8];
+          const int ra = rbase + ad[k];
+          static_for<0, 5>([&](auto pp_) {
+            constexpr int pp = decltype(pp_)::value;
+            static_for<0, 8>([&](auto cc) {
+              constexpr int c = decltype(cc)::value;
+              t[pp][c] = lds_read_b64<pp * kPairFloats * 4 + c * 8>(ra);
+            });
+          });
+          lds_wait_all();
+#pragma unroll
+          for (int pp = 0; pp < 5; pp++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) asm volatile("" : "+v"(t[pp][c]));
+          float rsum[10];
+#pragma unroll
+          for (int pp = 0; pp < 5; pp++) {
+            v2f rs = pk_mul_half<0>(wp[0], t[pp][0]);
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+              if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[pp][c], rs);
+              else rs = pk_fma_half<0>(wp[c >> 1], t[pp][c], rs);
+            }
+            rsum[2 * pp] = rs.x;
+            rsum[2 * pp + 1] = rs.y;
+          }
+          float o = uy[0] * (odd[k] ? rsum[1] : rsum[0]);
+#pragma unroll
+          for (int r = 1; r < 8; r++) o = ipa_fma(uy[r], odd[k] ? rsum[r + 1] : rsum[r], o);
+          asm volatile("" : "+v"(o));
+          out[k] = o;
+          __builtin_amdgcn_sched_barrier(0);  // one sample's taps in flight
+        }
+      } else {
+      constexpr int kBatch = 4;
 #pragma unroll
       for (int k0 = 0; k0 < 4; k0 += kBatch) {
         float ux[kBatch][NT], uy[kBatch][NT];
@@ -253,6 +322,7 @@ template <int INTERP, typename Coord> struct RingRemapKernel {
           out[k0 + q] = o;
         }
         if constexpr (kLz) __builtin_amdgcn_sched_barrier(0);  // one sample's taps in flight
+      }
       }
       __builtin_amdgcn_wave_barrier();
       // 5. stores: sample k = row (k >> 1), column lane + 64 (k & 1)

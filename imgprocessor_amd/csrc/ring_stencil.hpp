@@ -208,6 +208,76 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan
   if (threadIdx.x == 0) plan.pair_clean[pair] = (flag[0] && flag[1]) ? 1u : 0u;
 }
 
+// ------------------------------------------------------------------ host: plan + reuse --
+// the parameters of a coordinate source given by value, for the plan buffer's reuse key
+static inline int coord_key(const MapCoord&, double*) { return 0; }
+static inline int coord_key(const UndistortCoord& c, double* k) {
+  for (int i = 0; i < 9; i++) k[i] = c.ir[i];
+  const double v[10] = {c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.k3, (double)c.affine};
+  for (int i = 0; i < 10; i++) k[9 + i] = v[i];
+  return 19;
+}
+static inline int coord_key(const HomographyCoord& c, double* k) {
+  for (int i = 0; i < 9; i++) k[i] = c.m[i];
+  return 9;
+}
+
+// the coordinate source the ring kernels read: maps as they are, sources given by value
+// through the coordinates the planning pass stored
+template <typename Coord> struct ring_kernel_coord {
+  using type = StoredCoord<typename Coord::coord_t>;
+};
+template <> struct ring_kernel_coord<MapCoord> { using type = MapCoord; };
+
+// Plan of a call in ctx->plan: strip records, step counts, pair flags and - for sources given
+// by value - the coordinates of the clean strips, in the source's own type (so the frames
+// sample exactly what the gather / per-frame kernels compute).  The planning pass evaluates
+// every such coordinate anyway; the next call with the same source and geometry skips the pass.
+template <typename Coord, int K>
+static int ring_plan_prepare(ipa_ctx* ctx, const RingGeom& gm, const Coord& coord, int sh, int sw,
+                             const RingTaps& tp, RingPlan* plan,
+                             typename ring_kernel_coord<Coord>::type* kc) {
+  using CT = typename Coord::coord_t;
+  constexpr bool kByValue = !std::is_same<Coord, MapCoord>::value;
+  if (kByValue && (size_t)gm.dh * gm.dw >= (1ull << 32)) return 1;  // 32-bit coordinate offsets
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t info_b = up((size_t)gm.strips * sizeof(int4));
+  const size_t cnts_b = up((size_t)gm.strips * kPlanWords * sizeof(unsigned));
+  const size_t pair_b = up((size_t)gm.pairs * sizeof(unsigned));
+  const size_t coord_b = kByValue ? up((size_t)gm.dh * gm.dw * sizeof(CT)) : 0;
+  double key[40];
+  int kn = coord_key(coord, key);
+  if (kByValue) {
+    const double g[10] = {(double)gm.dh, (double)gm.dw, (double)sh, (double)sw, (double)tp.nt,
+                          (double)tp.q5, (double)tp.rr, (double)sizeof(CT), (double)K,
+                          (double)gm.strip_h};
+    for (int i = 0; i < 10; i++) key[kn++] = g[i];
+  }
+  const bool hit = kByValue && ctx->plan_key_n == kn &&
+                   memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0;
+  if (!hit) {
+    int rc = ipa_plan_reserve(ctx, info_b + cnts_b + pair_b + 2 * coord_b);
+    if (rc) return rc;
+  }
+  char* pb = reinterpret_cast<char*>(ctx->plan);
+  plan->info = reinterpret_cast<int4*>(pb);
+  plan->cnts = reinterpret_cast<unsigned*>(pb + info_b);
+  plan->pair_clean = reinterpret_cast<unsigned*>(pb + info_b + cnts_b);
+  CT* outx = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b) : nullptr;
+  CT* outy = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b + coord_b) : nullptr;
+  if (!hit) {
+    hipLaunchKernelGGL((ring_plan_kernel<Coord, K>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
+                       coord, sh, sw, tp, *plan, outx, outy);
+    if (kByValue) {
+      memcpy(ctx->plan_key, key, (size_t)kn * sizeof(double));
+      ctx->plan_key_n = kn;
+    }
+  }
+  if constexpr (kByValue) *kc = StoredCoord<CT>{outx, outy, (long)gm.dw};
+  else *kc = coord;
+  return 0;
+}
+
 // --------------------------------------------------------------------------- hot loop --
 template <typename ST, typename Coord, int K> struct RingKernel {
   using C = typename Coord::coord_t;
