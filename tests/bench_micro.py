@@ -1,6 +1,6 @@
 """micro-benchmark helper (GPU box): times single entry points with HIP events.
 
-    python tests/bench_micro.py conv|copy|strip|remap|ringremap|configs|stencils|host|pipeline
+    python tests/bench_micro.py conv|copy|strip|remap|ringremap|intremap|configs|stencils|host|pipeline
 
 conv / remap / strip: the filter, remap and fused kernels on 16 x 4K float32 frames
 (IPA_STRIP_H, IPA_FRAMES_INNER, IMGPROC_HIP_LIB select variants); configs: the BASELINE
@@ -69,6 +69,22 @@ if __name__ == '__main__':
         dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
         t = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst))
         print('fused_map strip_h=%s  %8.1f us %6.0f GB/s(16B/px)' % (sh, t, 16 * px / t / 1e3))
+    if what == 'intremap':
+        # integer frames: every product and sum in double, results equal to the oracle bit for bit
+        from imgprocessor_amd.utils import getPerspectiveTransform
+        quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+        rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+        Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))
+        dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
+        for dt in (np.uint8, np.uint16):
+            a = rng.random((B, h, w), dtype=np.float32)
+            isrc = ctx.to_device((a * (255 if dt == np.uint8 else 4095)).astype(dt))
+            idst = ctx.empty((B, h, w), dt)
+            for interp in ('linear', 'linear_cv_q5', 'cubic', 'lanczos4'):
+                t1 = timeit(ctx, lambda: ops.remap(isrc, dmx, dmy, interp, out=idst))
+                t2 = timeit(ctx, lambda: ops.warp_perspective(isrc, Hm, (h, w), interp, out=idst))
+                print('%-7s %-13s remap(maps) %8.1f us   warp %8.1f us  (%6.1f Gpx/s)'
+                      % (np.dtype(dt).name, interp, t1, t2, px / t2 / 1e3))
     if what == 'ringremap':
         dmx, dmy = ops.build_undistort_map(Kc, dc, Kc, h, w, ctx=ctx, device=True)
         from imgprocessor_amd.utils import getPerspectiveTransform
