@@ -195,6 +195,21 @@ def other_configs(ctx, ia, ops, budget_launches=60):
               % (interp, B), B, h, w, ms, (16 if two else 8) * B * h * w, 2 if two else 1,
               'two launches through the workspace' if two else None)
 
+    # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
+    # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
+    # uint8 frames (every product and sum in double, bit-exact against the oracle)
+    ms = timed(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
+               budget_launches, 5)
+    entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
+          8 * B * h * w, 3, 'planning pass (first call) + ring kernel + gather kernel on the rim')
+    u8 = ctx.to_device(np.round(synth_frames(B, h, w, 310) * 255).astype(np.uint8))
+    d8 = ctx.empty((B, h, w), np.uint8)
+    ms = timed(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
+               budget_launches // 2, 3)
+    entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
+          ms, 2 * B * h * w, 1, 'bound by the double arithmetic of the exact integer result')
+    del u8, d8
+
     # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here
     # and on 8K frames below
     k11 = np.random.default_rng(321).random((11, 11))
