@@ -224,6 +224,73 @@ masked_mean_fill_wave_kernel(T* grid, const unsigned char* __restrict__ mask, in
   }
 }
 
+// The same fill for windows up to 64 columns wide (k <= 32): the masked pixels of a 64-px
+// segment share their window rows and overlap in columns, so the wave first forms, per column
+// of the segment's 64 + 2k columns, the sum and count of the unmasked pixels over the window
+// rows - two columns per lane, every load independent of every other - and parks them in its
+// LDS slice; a masked pixel then sums its <= 2k column entries with one LDS read per lane and a
+// shuffle reduction.  Per segment 4 loads per window row instead of 2 dependent passes per
+// masked pixel (4K, 5 % masked, k = 15: 332 -> see profiles/r02_micro.txt).
+template <typename T>
+__global__ void __launch_bounds__(256)
+masked_mean_fill_cols_kernel(T* grid, const unsigned char* __restrict__ mask, int gx, int gy,
+                             long pitch, long mpitch, int k, int segs_x) {
+  __shared__ double cs[4][128];
+  __shared__ int cn[4][128];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long seg = (long)blockIdx.x * 4 + wave;
+  const int i = (int)(seg / segs_x);
+  if (i >= gx) return;
+  const int js = (int)(seg - (long)i * segs_x) * 64;
+  const int jl = js + lane;
+  unsigned long long todo = __ballot(jl < gy && mask[(long)i * mpitch + jl] != 0);
+  if (!todo) return;
+  const int xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+  const int c0 = js - k;
+  const int ca = c0 + lane, cb = c0 + 64 + lane;
+  const bool oka = ca >= 0 && ca < gy, okb = cb < js + 64 + k && cb >= 0 && cb < gy;
+  const long oa = oka ? ca : 0, ob = okb ? cb : 0;
+  double sa = 0.0, sb = 0.0;
+  int na = 0, nb = 0;
+  for (int ii = xmn; ii < xmx; ii += 4) {
+    unsigned char ma[4], mb[4];
+    T ga[4], gb[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int r = ii + u < xmx ? ii + u : xmx - 1;
+      ma[u] = mask[(long)r * mpitch + oa];
+      mb[u] = mask[(long)r * mpitch + ob];
+      ga[u] = grid[(long)r * pitch + oa];
+      gb[u] = grid[(long)r * pitch + ob];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bool live = ii + u < xmx;
+      if (live && oka && !ma[u]) { sa += (double)ga[u]; na++; }
+      if (live && okb && !mb[u]) { sb += (double)gb[u]; nb++; }
+    }
+  }
+  cs[wave][lane] = sa; cs[wave][64 + lane] = sb;
+  cn[wave][lane] = na; cn[wave][64 + lane] = nb;
+  __builtin_amdgcn_wave_barrier();
+  while (todo) {
+    const int b = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    const int j = js + b;
+    const int ymn = j - k < 0 ? 0 : j - k, ymx = j + k > gy ? gy : j + k;
+    const int e = ymn - c0 + lane;
+    const bool in = lane < ymx - ymn;
+    double val = in ? cs[wave][e] : 0.0;
+    int n = in ? cn[wave][e] : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      val += __shfl_xor(val, off, 64);
+      n += __shfl_xor(n, off, 64);
+    }
+    if (lane == 0 && n > 0) grid[(long)i * pitch + j] = (T)(val / (double)n);
+  }
+}
+
 // filters/maskedFilter.py:76-102 (_calcMedian): np.median of the mask == 0 pixels of the clipped
 // window, wave-cooperative like the fill above.  The wave collects the window values as
 // order-preserving integer keys in its LDS buffer (ballot-ranked append), then finds the middle
@@ -616,12 +683,22 @@ int ipa_masked_mean_dev(ipa_ctx* ctx, const void* d_arr, int dtype, const unsign
     const int segs_x = (w + 63) / 64;
     const long segs = (long)segs_x * h;
     dim3 wgrid((unsigned)((segs + 3) / 4)), wblock(256);
-    if (dtype == IPA_F32)
-      hipLaunchKernelGGL((masked_mean_fill_wave_kernel<float>), wgrid, wblock, 0, ctx->stream,
-                         (float*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
-    else
-      hipLaunchKernelGGL((masked_mean_fill_wave_kernel<double>), wgrid, wblock, 0, ctx->stream,
-                         (double*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
+    const bool cols = ksize / 2 >= 1 && ksize / 2 <= 32;
+    if (dtype == IPA_F32) {
+      if (cols)
+        hipLaunchKernelGGL((masked_mean_fill_cols_kernel<float>), wgrid, wblock, 0, ctx->stream,
+                           (float*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
+      else
+        hipLaunchKernelGGL((masked_mean_fill_wave_kernel<float>), wgrid, wblock, 0, ctx->stream,
+                           (float*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
+    } else {
+      if (cols)
+        hipLaunchKernelGGL((masked_mean_fill_cols_kernel<double>), wgrid, wblock, 0, ctx->stream,
+                           (double*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
+      else
+        hipLaunchKernelGGL((masked_mean_fill_wave_kernel<double>), wgrid, wblock, 0, ctx->stream,
+                           (double*)d_out, d_mask, h, w, pitch, mask_pitch, ksize / 2, segs_x);
+    }
   } else if (dtype == IPA_F32) {
     if (fill_mask) IPA_MM(float, true); else IPA_MM(float, false);
   } else {
