@@ -40,7 +40,7 @@ struct RemapParams {
   int frames_inner;  // n_frames when the grid is 1-D with the frame index fastest, else 0
   // tiles the ring kernel computes (ring_remap.hpp): skip[strip row * tiles_x + tile column]
   const unsigned* skip;
-  int skip_strip_h;
+  unsigned tile_rows;  // groups of 4 rows per workgroup (1; a strip of the skip mask behind it)
 };
 
 template <typename Coord>
@@ -97,7 +97,9 @@ __device__ __forceinline__ void store4(DT* row, int x0, const DT (&v)[4], int n,
   }
 }
 
-template <typename ST, typename DT, int INTERP, typename Coord, bool FIXED>
+// REST: the launch behind a ring kernel's skip mask (float32 batches): tile_rows groups of rows
+// per workgroup.  A separate instantiation - the loop costs the plain launch 10-15 %.
+template <typename ST, typename DT, int INTERP, typename Coord, bool FIXED, bool REST = false>
 __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) {
   using CT = typename compute_of<ST>::type;
   // frames_inner: the frames of one tile are neighbours in the XCD-contiguous block order, so
@@ -107,6 +109,11 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     frame = t % (unsigned)p.frames_inner;
     t /= (unsigned)p.frames_inner;
   }
+  // a workgroup = tile_rows groups of 4 rows x 256 px.  Behind a ring kernel's skip mask
+  // tile_rows spans one strip of the mask: a launch that mostly has nothing to do is then
+  // bound by far fewer workgroup dispatches (16 x 4K: 130 k -> 16 k, 55 -> 12 us)
+  const unsigned tyb = t / p.tiles_x, txi = t - tyb * p.tiles_x;
+  if (REST && p.skip[tyb * p.tiles_x + txi]) return;
   // Lanczos4: the 32 x 8 weight table is read four float4 per sample - from LDS, not through
   // the vector-memory path the 16 tap-row gathers of the sample already load
   __shared__ __attribute__((aligned(16))) float lz_tab[INTERP == kLanczos4 ? 256 : 4];
@@ -114,18 +121,18 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     lz_tab[threadIdx.y * 64 + threadIdx.x] = p.lanczos[threadIdx.y * 64 + threadIdx.x];
     __syncthreads();
   }
-  unsigned tyi = t / p.tiles_x, txi = t - tyi * p.tiles_x;
-  if (p.skip && p.skip[(tyi * 4u / (unsigned)p.skip_strip_h) * p.tiles_x + txi]) return;
-  int x0 = (int)((txi * 64 + threadIdx.x) * 4);
-  int y = (int)(tyi * 4 + threadIdx.y);
-  if (y >= p.dh || x0 >= p.dw) return;
-  int n = p.dw - x0 < 4 ? p.dw - x0 : 4;
-
   SrcView s;
   s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
   s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
   s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a;
   s.lanczos = INTERP == kLanczos4 ? lz_tab : p.lanczos;
+  const int x0 = (int)((txi * 64 + threadIdx.x) * 4);
+  if (x0 >= p.dw) return;
+  const int n = p.dw - x0 < 4 ? p.dw - x0 : 4;
+  const unsigned tile_rows = REST ? p.tile_rows : 1u;
+  for (unsigned sub = 0; sub < tile_rows; sub++) {
+  const int y = (int)((tyb * tile_rows + sub) * 4 + threadIdx.y);
+  if (y >= p.dh) return;
 
   // Row segments that lie wholly inside the output row sample in LANE-INTERLEAVED order
   // (footprint k of lane L = segment pixel L + 64 k): the 64 gathers of one instruction then
@@ -172,7 +179,8 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
       const float4 q = *reinterpret_cast<const float4*>(xp + 4u * lane);
       DT* row = reinterpret_cast<DT*>(p.dst) + (long)frame * p.dst_frame_elems + (long)y * p.dpitch;
       *reinterpret_cast<float4*>(row + xw + 4u * lane) = q;
-      return;
+      __builtin_amdgcn_wave_barrier();  // the row is reused by the next group of rows
+      continue;
     }
   }
 
@@ -211,6 +219,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   }
   DT* row = reinterpret_cast<DT*>(p.dst) + (long)frame * p.dst_frame_elems + (long)y * p.dpitch;
   store4<DT>(row, x0, out, n, p.dst_vec);
+  }
 }
 
 #ifdef IPA_REMAP_API_TU  // only remap.hip carries the map builder
@@ -273,6 +282,27 @@ static void launch_interp(ipa_ctx* ctx, const RemapParams& p, const Coord& c, in
   }
 }
 
+// the strips a ring kernel left (float32 -> float32, p.skip / p.tile_rows set)
+template <typename Coord>
+static void launch_rest(ipa_ctx* ctx, const RemapParams& p, const Coord& c, int base, dim3 grid) {
+  dim3 block(64, 4);
+  switch (base) {
+    case IPA_INTER_LINEAR:
+      hipLaunchKernelGGL((remap_kernel<float, float, kLinear, Coord, false, true>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+    case IPA_INTER_CUBIC_CV:
+    case IPA_INTER_CUBIC_KEYS:
+      hipLaunchKernelGGL((remap_kernel<float, float, kCubic, Coord, false, true>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+    default:
+      hipLaunchKernelGGL((remap_kernel<float, float, kLanczos4, Coord, false, true>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
+  }
+}
+
 static inline bool aligned_rows(const void* base, long pitch_elems, long frame_elems, int n_frames,
                          size_t elem, size_t vec_bytes) {
   if (((uintptr_t)base) % vec_bytes) return false;
@@ -325,7 +355,7 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
     default: ring_remap_launch_one<kLanczos4, KCoord>(ctx, gm, ra, kc, plan); break;
   }
   p.skip = plan.pair_clean;
-  p.skip_strip_h = gm.strip_h;
+  p.tile_rows = (unsigned)gm.strip_h / 4u;
   return 0;
 }
 
@@ -379,29 +409,32 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   dim3 grid = inner ? dim3(p.tiles * (unsigned)a.n_frames, 1) : dim3(p.tiles, (unsigned)a.n_frames);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   p.skip = nullptr;
-  p.skip_strip_h = 4;
+  p.tile_rows = 1;
   // batches of float32 frames: the clean strips on the ring kernel (taps from LDS), the rest
   // below behind the skip mask
   // (ring_remap = 1: where it measured faster - 16 x 4K frames, gather -> ring + rest (+ plan):
-  //   Lanczos4  maps 1161 -> 791 us, lens model 1106 -> 750, homography 1231 -> 971
-  //   bicubic   maps  473 -> 393,    lens model  461 -> 375, homography  487 -> 515 (stays)
-  //   bilinear  maps  354 -> 345 (stays), lens model 343 -> 298, homography 338 -> 419 (stays)
+  //   Lanczos4  maps 1156 -> 712 us, lens model 1111 -> 676, homography 1112 -> 707
+  //   bicubic   maps  477 -> 378,    lens model  461 -> 356, homography  464 -> 423
+  //   bilinear  maps  351 -> 297,    lens model  343 -> 261, homography  344 -> 355 (stays)
   // the lens model and the homography read the coordinates the planning pass stored; the
   // homography's are doubles, 16 B per pixel and frame.  ring_remap = 2: every covered case)
-  constexpr bool kMaps = std::is_same<Coord, MapCoord>::value;
-  constexpr bool kLens = std::is_same<Coord, UndistortCoord>::value;
-  const bool cubic = base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS;
-  const bool ring_pays = base == IPA_INTER_LANCZOS4 || (cubic && (kMaps || kLens)) ||
-                         (base == IPA_INTER_LINEAR && kLens);
+  constexpr bool kHom = std::is_same<Coord, HomographyCoord>::value;
+  const bool ring_pays = !(base == IPA_INTER_LINEAR && kHom);
   if ((ctx->tune.ring_remap > 1 || (ctx->tune.ring_remap == 1 && ring_pays)) &&
       a.n_frames >= ctx->tune.ring_min && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
       base != IPA_INTER_NEAREST) {
     rc = ring_remap_launch<Coord>(ctx, p, coord, base, a.n_frames);
     if (rc < 0) return rc;
+    if (p.skip) {
+      p.tiles = p.tiles_x * ((tiles_y + p.tile_rows - 1) / p.tile_rows);
+      grid = inner ? dim3(p.tiles * (unsigned)a.n_frames, 1) : dim3(p.tiles, (unsigned)a.n_frames);
+    }
   }
 
   int s = a.src_dt, d = a.dst_dt;
-  if (s == IPA_F32 && d == IPA_F32) {
+  if (p.skip) {
+    launch_rest<Coord>(ctx, p, coord, base, grid);
+  } else if (s == IPA_F32 && d == IPA_F32) {
     launch_interp<float, float, Coord, false>(ctx, p, coord, base, grid);
   } else if (s == IPA_F64 && d == IPA_F64) {
     launch_interp<double, double, Coord, false>(ctx, p, coord, base, grid);
