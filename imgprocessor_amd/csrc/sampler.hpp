@@ -155,6 +155,8 @@ template <> struct TapLoad<uint16_t, float> {
 // --------------------------------------------------------------- weights --
 __device__ __forceinline__ float ipa_floor(float x) { return floorf(x); }
 __device__ __forceinline__ double ipa_floor(double x) { return floor(x); }
+__device__ __forceinline__ float ipa_abs(float x) { return __builtin_fabsf(x); }
+__device__ __forceinline__ double ipa_abs(double x) { return __builtin_fabs(x); }
 __device__ __forceinline__ float ipa_rint(float x) { return rintf(x); }
 __device__ __forceinline__ double ipa_rint(double x) { return rint(x); }
 
@@ -454,18 +456,24 @@ __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], 
   static_assert(INTERP == kLinear || INTERP == kCubic, "split sampling: bilinear/bicubic only");
   b.interior = 0;
   int e[N];
+  const unsigned xlim = s.w - NT + 1 > 0 ? (unsigned)(s.w - NT + 1) : 0u;
+  const unsigned ylim = s.h - NT + 1 > 0 ? (unsigned)(s.h - NT + 1) : 0u;
 #pragma unroll
   for (int k = 0; k < N; k++) {
-    bool ok = sx[k] > (C)-kCoordLimit && sx[k] < (C)kCoordLimit && sy[k] > (C)-kCoordLimit &&
-              sy[k] < (C)kCoordLimit;
+    // the same decisions with fewer instructions (this loop is a third of the fused kernel's
+    // VALU work): |c| < limit is one compare with a source modifier and false for NaN; a
+    // footprint lies inside when (unsigned)i0 < extent - NT + 1
+    const bool ok = ipa_abs(sx[k]) < (C)kCoordLimit && ipa_abs(sy[k]) < (C)kCoordLimit;
     int ix0, iy0;
     axis_frac<INTERP, CT, C, QM>(s, ok ? sx[k] : (C)0, ix0, b.tx[k]);
     axis_frac<INTERP, CT, C, QM>(s, ok ? sy[k] : (C)0, iy0, b.ty[k]);
-    bool in = ok && ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
+    const bool in = ok && (unsigned)ix0 < xlim && (unsigned)iy0 < ylim;
     b.interior |= in ? (1u << k) : 0u;
     // |iy0| <= kCoordLimit < 2^23 and pitch < 2^23 (checked at the entry points): one
-    // full-rate v_mul_i32_i24 (+ add) instead of a quarter-rate 32-bit multiply
-    e[k] = in ? __mul24(iy0, s.pitch) + ix0 : 0;
+    // full-rate v_mul_i32_i24 (+ add) instead of a quarter-rate 32-bit multiply.  Footprints
+    // that are not inside load from wherever this lands - range-checked buffer loads return 0
+    // beyond the frame - and are redone by sample()
+    e[k] = __mul24(iy0, s.pitch) + ix0;
   }
 #pragma unroll
   for (int k = 0; k < N; k++)
