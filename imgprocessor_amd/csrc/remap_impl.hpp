@@ -146,6 +146,8 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     __shared__ __attribute__((aligned(16))) DT xpose[4][256];
     const int xw = (int)(txi * 256u);  // wave-uniform (threadIdx.y = wave)
     if (xw + 256 <= p.dw && p.dst_vec && p.map_vec) {
+      SrcView si = s;  // neighbouring lanes, neighbouring pixels: dword pairs
+      si.pair_split = 1;
       const unsigned lane = threadIdx.x;
       typename Coord::coord_t qx[4], qy[4];
       if constexpr (std::is_same<Coord, MapCoord>::value) {
@@ -171,7 +173,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
           bx[j] = qx[b + j];
           by[j] = qy[b + j];
         }
-        sample_batch<ST, INTERP, BN>(s, bx, by, cval, o);
+        sample_batch<ST, INTERP, BN>(si, bx, by, cval, o);
 #pragma unroll
         for (int j = 0; j < BN; j++) xp[64u * (b + j) + lane] = store_cast<DT, CT>(o[j]);
       }

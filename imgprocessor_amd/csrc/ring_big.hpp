@@ -208,6 +208,7 @@ template <int INTERP, typename Coord, int K> struct RingBigKernel {
     s.rsrc = make_rsrc(g.src + (long)frame * g.src_frame_bytes, g.src_bytes);
     s.w = g.sw; s.h = g.sh; s.pitch = g.spitch;
     s.border = g.border; s.q5 = g.q5; s.cubic_a = g.cubic_a; s.lanczos = nullptr;
+    s.pair_split = 1;
     float* xp = sh.xrow + kLead + wave * 2 * kXRow;
     float* ringw = sh.ring[wave];
     v2f acc[K];

@@ -35,6 +35,11 @@ struct SrcView {
   int q5;                 // 1: cv2-style 1/32-px coordinate rounding
   float cubic_a;          // Keys parameter (-0.75 cv2, -0.5 skimage)
   const float* lanczos;   // [32][8] table (device), only for kLanczos4
+  // 1: neighbouring lanes sample neighbouring pixels (the lane-interleaved order of the fused
+  // kernels and of remap_kernel's aligned segments): bilinear float tap rows then load as two
+  // dword gathers - which cost by the cache lines the wave touches - instead of one dwordx2
+  // (16 clocks whatever its addresses).  0: one lane = 4 consecutive pixels, the dwordx2 wins.
+  int pair_split = 0;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -65,8 +70,20 @@ template <> struct TapLoad<float, float> {
       // gather by the cache lines it touches (tools/ta_micro.hip) - and the lane-interleaved
       // samplers make neighbouring lanes hit neighbouring pixels.  Measured +1.5 % on the
       // fused 4K kernel and the bilinear remap (profiles/r01_micro.txt).
-      v[0] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, e << 2, 0, 0));
-      v[1] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (e << 2) + 4, 0, 0));
+      // (the "4" is hidden from the compiler, which otherwise fuses the pair into the dwordx2
+      // again, as it silently did for most of round 2: 64 x 4K fused 5x5 1.481 -> 1.387 ms on
+      // one box.  Through a second descriptor at base + 4 instead: 1.573 ms; with the sc0 scope
+      // bit on one of the two: level with this form)
+      if (s.pair_split) {
+        int four = 4;
+        asm("" : "+s"(four));
+        v[0] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, e << 2, 0, 0));
+        v[1] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (e << 2) + four, 0, 0));
+      } else {
+        auto r = __builtin_amdgcn_raw_buffer_load_b64(s.rsrc, e << 2, 0, 0);
+        v[0] = u2f(r[0]);
+        v[1] = u2f(r[1]);
+      }
     } else {
 #pragma unroll
       for (int k = 0; k < N; k += 4) {

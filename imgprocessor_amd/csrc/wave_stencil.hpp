@@ -217,6 +217,7 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     s.rsrc = make_rsrc(src + (long)f * src_frame_bytes, src_bytes);
     s.h = sh; s.w = sw; s.pitch = spitch;
     s.border = border; s.q5 = q5; s.cubic_a = cubic_a; s.lanczos = lanczos;
+    s.pair_split = 1;  // strips sample lane-interleaved
   }
   __device__ __forceinline__ bool vectors_ok() const { return !kMap || map_vec != 0; }
 
