@@ -54,6 +54,11 @@ struct ipa_ctx {
   // ipa_plan_reserve() clears it, the user that wants reuse sets it after filling the buffer.
   double plan_key[40];
   int plan_key_n = 0;
+  // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
+  // and the source + geometry it belongs to: ring_plan_prepare's hint
+  unsigned* ring_hint = nullptr;
+  double ring_hint_key[40];
+  int ring_hint_n = 0;
   // float32 coordinate maps of the last lens model a fused undistort + filter call was made
   // with (what LensDistortion.getUndistortRectifyMap caches, camera/LensDistortion.py:344-345):
   // the next call with the same K, distortion, newK and size reads them instead of evaluating

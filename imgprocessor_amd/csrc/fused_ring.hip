@@ -32,6 +32,7 @@ static int ring_launch(ipa_ctx* ctx, FusedCall& f, const Coord& c) {
   plan.info = reinterpret_cast<int4*>(ctx->plan);
   plan.cnts = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->plan) + info_b);
   plan.pair_clean = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->plan) + info_b + cnts_b);
+  plan.stats = nullptr;
 
   hipLaunchKernelGGL((ring_plan_kernel<Coord, K>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
                      c, f.sh, f.sw, RingTaps{2, 0, kRR}, plan, nullptr, nullptr);

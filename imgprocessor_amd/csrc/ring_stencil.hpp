@@ -43,6 +43,7 @@ struct RingPlan {
   int4* info;            // per strip: x = clean, y = xlo, z = first source row, w = rows of step 0
   unsigned* cnts;        // per strip: kPlanWords words of 4-bit counts
   unsigned* pair_clean;  // per strip pair (= one strip of wave_stencil_kernel): 1 = both clean
+  unsigned* stats;       // [0] = clean pairs of the call (zeroed before the planning launch)
 };
 
 // footprint of the interpolation the plan is made for
@@ -205,12 +206,21 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan
   }
   if (lane == 0) flag[wave] = (clean || !exists) ? 1 : 0;
   __syncthreads();
-  if (threadIdx.x == 0) plan.pair_clean[pair] = (flag[0] && flag[1]) ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    const unsigned pc = (flag[0] && flag[1]) ? 1u : 0u;
+    plan.pair_clean[pair] = pc;
+    if (pc && plan.stats) atomicAdd(plan.stats, 1u);
+  }
 }
 
 // ------------------------------------------------------------------ host: plan + reuse --
 // the parameters of a coordinate source given by value, for the plan buffer's reuse key
-static inline int coord_key(const MapCoord&, double*) { return 0; }
+static inline int coord_key(const MapCoord& c, double* k) {
+  k[0] = (double)reinterpret_cast<uintptr_t>(c.mx);
+  k[1] = (double)reinterpret_cast<uintptr_t>(c.my);
+  k[2] = (double)c.pitch;
+  return 3;
+}
 static inline int coord_key(const UndistortCoord& c, double* k) {
   for (int i = 0; i < 9; i++) k[i] = c.ir[i];
   const double v[10] = {c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.k3, (double)c.affine};
@@ -244,30 +254,53 @@ static int ring_plan_prepare(ipa_ctx* ctx, const RingGeom& gm, const Coord& coor
   const size_t info_b = up((size_t)gm.strips * sizeof(int4));
   const size_t cnts_b = up((size_t)gm.strips * kPlanWords * sizeof(unsigned));
   const size_t pair_b = up((size_t)gm.pairs * sizeof(unsigned));
+  const size_t stat_b = 256;
   const size_t coord_b = kByValue ? up((size_t)gm.dh * gm.dw * sizeof(CT)) : 0;
   double key[40];
   int kn = coord_key(coord, key);
-  if (kByValue) {
-    const double g[10] = {(double)gm.dh, (double)gm.dw, (double)sh, (double)sw, (double)tp.nt,
-                          (double)tp.q5, (double)tp.rr, (double)sizeof(CT), (double)K,
-                          (double)gm.strip_h};
-    for (int i = 0; i < 10; i++) key[kn++] = g[i];
-  }
+  const double g[10] = {(double)gm.dh, (double)gm.dw, (double)sh, (double)sw, (double)tp.nt,
+                        (double)tp.q5, (double)tp.rr, (double)sizeof(CT), (double)K,
+                        (double)gm.strip_h};
+  for (int i = 0; i < 10; i++) key[kn++] = g[i];
+  // How many strips the last call with this source and geometry found clean (read back without
+  // waiting, so possibly one call old): a call that would leave most strips to the gather
+  // kernel anyway - strong rotation, footprints outside the source - skips the ring path.  A
+  // hint only: the results are the same bits either way.
+  const bool same = ctx->ring_hint_n == kn &&
+                    memcmp(ctx->ring_hint_key, key, (size_t)kn * sizeof(double)) == 0;
+  if (same && ctx->ring_hint && ctx->ring_hint[1] == (unsigned)gm.pairs &&
+      ctx->ring_hint[0] != 0xffffffffu && 2u * ctx->ring_hint[0] < (unsigned)gm.pairs)
+    return 1;
   const bool hit = kByValue && ctx->plan_key_n == kn &&
                    memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0;
   if (!hit) {
-    int rc = ipa_plan_reserve(ctx, info_b + cnts_b + pair_b + 2 * coord_b);
+    int rc = ipa_plan_reserve(ctx, info_b + cnts_b + pair_b + stat_b + 2 * coord_b);
     if (rc) return rc;
   }
   char* pb = reinterpret_cast<char*>(ctx->plan);
   plan->info = reinterpret_cast<int4*>(pb);
   plan->cnts = reinterpret_cast<unsigned*>(pb + info_b);
   plan->pair_clean = reinterpret_cast<unsigned*>(pb + info_b + cnts_b);
-  CT* outx = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b) : nullptr;
-  CT* outy = kByValue ? reinterpret_cast<CT*>(pb + info_b + cnts_b + pair_b + coord_b) : nullptr;
+  plan->stats = reinterpret_cast<unsigned*>(pb + info_b + cnts_b + pair_b);
+  char* cb = pb + info_b + cnts_b + pair_b + stat_b;
+  CT* outx = kByValue ? reinterpret_cast<CT*>(cb) : nullptr;
+  CT* outy = kByValue ? reinterpret_cast<CT*>(cb + coord_b) : nullptr;
   if (!hit) {
+    if (!ctx->ring_hint)
+      IPA_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->ring_hint), 2 * sizeof(unsigned)));
+    if (!same) {
+      // another source / geometry: nothing known yet (a read-back of the old one still in
+      // flight may land here once - a wrong hint for one call, corrected by the next)
+      ctx->ring_hint[0] = 0xffffffffu;
+      memcpy(ctx->ring_hint_key, key, (size_t)kn * sizeof(double));
+      ctx->ring_hint_n = kn;
+    }
+    IPA_HIP(ctx, hipMemsetAsync(plan->stats, 0, 2 * sizeof(unsigned), ctx->stream));
     hipLaunchKernelGGL((ring_plan_kernel<Coord, K>), dim3(gm.pairs), dim3(128), 0, ctx->stream, gm,
                        coord, sh, sw, tp, *plan, outx, outy);
+    IPA_HIP(ctx, hipMemcpyAsync(ctx->ring_hint, plan->stats, sizeof(unsigned),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    ctx->ring_hint[1] = (unsigned)gm.pairs;
     if (kByValue) {
       memcpy(ctx->plan_key, key, (size_t)kn * sizeof(double));
       ctx->plan_key_n = kn;

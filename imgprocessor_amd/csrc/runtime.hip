@@ -142,6 +142,7 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   if (c->tab) (void)hipFree(c->tab);
   if (c->plan) (void)hipFree(c->plan);
   if (c->lens_map) (void)hipFree(c->lens_map);
+  if (c->ring_hint) (void)hipHostFree(c->ring_hint);
   if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
   (void)hipStreamDestroy(c->stream);
   delete c;

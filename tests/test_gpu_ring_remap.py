@@ -213,3 +213,38 @@ def test_lens_map_cache_matches_per_pixel_model(ia):
             same_bits(ops.undistort_conv2d(d2, K, dist, K, k).get(), w2, 'other size')
         finally:
             ctx.set_tuning(**old)
+
+
+def test_ring_remap_hint_skips_the_ring_for_rotations(ia):
+    """a source that leaves no clean strips (strong rotation): from the second call on the ring
+    path is skipped on the hint of the first; results stay those of the gather kernel"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 300, 900, 4
+    src = frames(n, h, w)
+    d_src = ctx.to_device(src)
+    mx, my = rot_maps(h, w, 25.0)
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    a = np.deg2rad(25.0)
+    M = np.array([[np.cos(a), -np.sin(a), 100.0], [np.sin(a), np.cos(a), -80.0], [0, 0, 1.0]])
+    old = ctx.set_tuning(ring_remap=0, ring_min=1)
+    try:
+        want_m = ops.remap(d_src, dmx, dmy, 'cubic').get()
+        want_h = ops.warp_perspective(d_src, M, (h, w), 'lanczos4').get()
+        ctx.set_tuning(ring_remap=2)
+        for i in range(4):
+            same_bits(ops.remap(d_src, dmx, dmy, 'cubic').get(), want_m, 'maps, call %d' % i)
+            ctx.synchronize()
+        for i in range(4):
+            same_bits(ops.warp_perspective(d_src, M, (h, w), 'lanczos4').get(), want_h,
+                      'homography, call %d' % i)
+        # back to a source with clean strips
+        mx2, my2, _, _ = radial_maps(h, w)
+        d2x, d2y = ctx.to_device(mx2), ctx.to_device(my2)
+        ctx.set_tuning(ring_remap=0)
+        want_r = ops.remap(d_src, d2x, d2y, 'cubic').get()
+        ctx.set_tuning(ring_remap=2)
+        for i in range(3):
+            same_bits(ops.remap(d_src, d2x, d2y, 'cubic').get(), want_r, 'radial, call %d' % i)
+    finally:
+        ctx.set_tuning(**old)
