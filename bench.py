@@ -197,7 +197,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
 
     # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
     # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
-    # uint8 frames (every product and sum in double, bit-exact against the oracle)
+    # uint8 frames (OpenCV's 8U short-weight arithmetic, bit-exact against the oracle)
     ms = timed(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
                budget_launches, 5)
     entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
@@ -207,7 +207,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
                budget_launches // 2, 3)
     entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
-          ms, 2 * B * h * w, 1, 'bound by the double arithmetic of the exact integer result')
+          ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weights, formed per sample (integer-exact)")
     del u8, d8
 
     # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here

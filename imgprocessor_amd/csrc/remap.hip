@@ -54,6 +54,16 @@ static void lanczos4_row(float x, float* coeffs) {
   for (int i = 0; i < 8; i++) coeffs[i] *= sum;
 }
 
+// OpenCV interpolateCubic (A = -0.75) in float32, the rows of cv2's bicubic table
+static void cubic_row_f32(float x, float* c) {
+#pragma clang fp contract(off)
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
 static std::mutex g_lz_mu;
 static float* g_lanczos_dev[64] = {nullptr};
 
@@ -62,8 +72,10 @@ int ipa_lanczos_table(ipa_ctx* ctx, const float** out) {
   int dev = ctx->device;
   IPA_REQUIRE(ctx, dev >= 0 && dev < 64, "device id out of range");
   if (!g_lanczos_dev[dev]) {
-    float tab[32 * 8];
+    // [0, 256): Lanczos4 rows; [256, 384): bicubic rows (the uint8 fixed-point path)
+    float tab[32 * 8 + 32 * 4];
     for (int k = 0; k < 32; k++) lanczos4_row((float)k / 32.f, tab + k * 8);
+    for (int k = 0; k < 32; k++) cubic_row_f32((float)k * (1.f / 32), tab + 256 + k * 4);
     float* d = nullptr;
     IPA_HIP(ctx, hipSetDevice(dev));
     IPA_HIP(ctx, hipMalloc((void**)&d, sizeof(tab)));

@@ -116,16 +116,21 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   if (REST && p.skip[tyb * p.tiles_x + txi]) return;
   // Lanczos4: the 32 x 8 weight table is read four float4 per sample - from LDS, not through
   // the vector-memory path the 16 tap-row gathers of the sample already load
-  __shared__ __attribute__((aligned(16))) float lz_tab[INTERP == kLanczos4 ? 256 : 4];
-  if constexpr (INTERP == kLanczos4) {
-    lz_tab[threadIdx.y * 64 + threadIdx.x] = p.lanczos[threadIdx.y * 64 + threadIdx.x];
+  constexpr bool kTabFixed = FIXED && INTERP != kLinear;  // uint8 bicubic / Lanczos4 by tables
+  __shared__ __attribute__((aligned(16)))
+  float lz_tab[kTabFixed ? 384 : (INTERP == kLanczos4 ? 256 : 4)];
+  if constexpr (INTERP == kLanczos4 || kTabFixed) {
+    const unsigned tid = threadIdx.y * 64 + threadIdx.x;
+    lz_tab[tid] = p.lanczos[tid];
+    if constexpr (kTabFixed)
+      if (tid < 128u) lz_tab[256 + tid] = p.lanczos[256 + tid];
     __syncthreads();
   }
   SrcView s;
   s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
   s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
   s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a;
-  s.lanczos = INTERP == kLanczos4 ? lz_tab : p.lanczos;
+  s.lanczos = (INTERP == kLanczos4 || kTabFixed) ? lz_tab : p.lanczos;
   const int x0 = (int)((txi * 64 + threadIdx.x) * 4);
   if (x0 >= p.dw) return;
   const int n = p.dw - x0 < 4 ? p.dw - x0 : 4;
@@ -141,6 +146,8 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   // dword loads.  A wave-private LDS row puts the results back into 4-px-per-lane order for
   // the 16-byte store.  Same samples, same arithmetic: identical results.
   // (map-based remaps only: the analytic coordinate sources measured 3-13 % slower this way)
+  // (float destinations only: integer ones - uint8 / uint16, bound by their arithmetic - measured
+  // level (uint8) to 8-20 % slower (uint16) this way)
   constexpr bool kIlv = !FIXED && sizeof(DT) == 4 && std::is_same<Coord, MapCoord>::value;
   if constexpr (kIlv) {
     __shared__ __attribute__((aligned(16))) DT xpose[4][256];
@@ -150,16 +157,11 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
       si.pair_split = 1;
       const unsigned lane = threadIdx.x;
       typename Coord::coord_t qx[4], qy[4];
-      if constexpr (std::is_same<Coord, MapCoord>::value) {
-        const long o = (long)y * coord.pitch + xw;
+      const long o = (long)y * coord.pitch + xw;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-          qx[k] = coord.mx[o + lane + 64u * k];
-          qy[k] = coord.my[o + lane + 64u * k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; k++) coord.get(xw + (int)lane + 64 * k, y, qx[k], qy[k]);
+      for (int k = 0; k < 4; k++) {
+        qx[k] = coord.mx[o + lane + 64u * k];
+        qy[k] = coord.my[o + lane + 64u * k];
       }
       CT cval = (CT)p.cval;
       constexpr int BN = batch_of<INTERP>::value;
@@ -167,15 +169,15 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
 #pragma unroll
       for (int b = 0; b < 4; b += BN) {
         typename Coord::coord_t bx[BN], by[BN];
-        CT o[BN];
+        CT ov[BN];
 #pragma unroll
         for (int j = 0; j < BN; j++) {
           bx[j] = qx[b + j];
           by[j] = qy[b + j];
         }
-        sample_batch<ST, INTERP, BN>(si, bx, by, cval, o);
+        sample_batch<ST, INTERP, BN>(si, bx, by, cval, ov);
 #pragma unroll
-        for (int j = 0; j < BN; j++) xp[64u * (b + j) + lane] = store_cast<DT, CT>(o[j]);
+        for (int j = 0; j < BN; j++) xp[64u * (b + j) + lane] = store_cast<DT, CT>(ov[j]);
       }
       __builtin_amdgcn_wave_barrier();  // wave-private row: in-order ds_write / ds_read
       const float4 q = *reinterpret_cast<const float4*>(xp + 4u * lane);
@@ -201,7 +203,10 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     double r = rint(p.cval);
     uint8_t cv8 = (uint8_t)(r > 0 ? (r < 255 ? r : 255) : 0);
 #pragma unroll
-    for (int k = 0; k < 4; k++) out[k] = k < n ? sample_u8_fixed(s, sx[k], sy[k], cv8) : 0;
+    for (int k = 0; k < 4; k++) {
+      if constexpr (INTERP == kLinear) out[k] = k < n ? sample_u8_fixed(s, sx[k], sy[k], cv8) : 0;
+      else out[k] = k < n ? sample_u8_tab<INTERP>(s, sx[k], sy[k], cv8) : 0;
+    }
   } else {
     CT cval = (CT)p.cval;
     constexpr int BN = batch_of<INTERP>::value;
@@ -272,13 +277,16 @@ static void launch_interp(ipa_ctx* ctx, const RemapParams& p, const Coord& c, in
       hipLaunchKernelGGL((remap_kernel<ST, DT, kLinear, Coord, FIXED>), grid, block, 0,
                          ctx->stream, p, c);
       break;
-    case IPA_INTER_CUBIC_CV:
+    case IPA_INTER_CUBIC_CV:  // (uint8 -> uint8: cv2's fixed-point tables)
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kCubic, Coord, FIXED>), grid, block, 0,
+                         ctx->stream, p, c);
+      break;
     case IPA_INTER_CUBIC_KEYS:
       hipLaunchKernelGGL((remap_kernel<ST, DT, kCubic, Coord, false>), grid, block, 0,
                          ctx->stream, p, c);
       break;
     default:
-      hipLaunchKernelGGL((remap_kernel<ST, DT, kLanczos4, Coord, false>), grid, block, 0,
+      hipLaunchKernelGGL((remap_kernel<ST, DT, kLanczos4, Coord, FIXED>), grid, block, 0,
                          ctx->stream, p, c);
       break;
   }
@@ -390,7 +398,8 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   p.q5 = (a.interp & IPA_INTER_Q5) ? 1 : 0;
   p.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
   p.lanczos = nullptr;
-  if (base == IPA_INTER_LANCZOS4) {
+  if (base == IPA_INTER_LANCZOS4 ||
+      (base == IPA_INTER_CUBIC_CV && a.src_dt == IPA_U8 && a.dst_dt == IPA_U8)) {
     rc = ipa_lanczos_table(ctx, &p.lanczos);
     if (rc) return rc;
   }

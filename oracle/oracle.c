@@ -314,6 +314,115 @@ static uint8_t sample_u8_fixed(const sampler_t* s, double sx, double sy, uint8_t
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
 }
 
+/* OpenCV's uint8 bicubic (A = -0.75) and Lanczos4 (imgwarp.cpp: initInterTab1D / initInterTab2D with
+ * fixpt = true, remapBicubic / remapLanczos4 with FixedPtCast<int, uchar, INTER_REMAP_COEF_BITS>),
+ * restated from the published algorithm - cv2 cannot be installed here, so this is unpinned like
+ * the other cv2 modes:
+ *   1-D weights in float32 for the 32 fractions (interpolateCubic / interpolateLanczos4);
+ *   2-D weights  saturate_cast<short>(wy[k1] * wx[k2] * 32768)  (float products, cvRound);
+ *   if their sum is not 32768 the difference goes to ONE weight of the 2 x 2 block starting at
+ *   (ksize/2, ksize/2): the largest of the block when the sum is too small, the smallest when
+ *   it is too large (first such entry in row-major order);
+ *   integer accumulation, (sum + 2^14) >> 15, saturate to uint8. */
+static float g_tab_cubic[32][4], g_tab_lanczos[32][8];
+static int g_tabs_ready = 0;
+
+static void interpolate_cubic_f32(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+static void init_fixed_tabs(void) {
+  if (g_tabs_ready) return;
+  const float scale = 1.f / 32;
+  for (int i = 0; i < 32; i++) {
+    interpolate_cubic_f32(i * scale, g_tab_cubic[i]);
+    orc_lanczos4_weights(i * scale, g_tab_lanczos[i]);
+  }
+  g_tabs_ready = 1;
+}
+
+/* the 1-D float tables (for the tests): which = 0 bicubic (32 x 4), 1 Lanczos4 (32 x 8) */
+void orc_fixed_tab1d(int which, float* out) {
+  init_fixed_tabs();
+  if (which == 0) memcpy(out, g_tab_cubic, sizeof(g_tab_cubic));
+  else memcpy(out, g_tab_lanczos, sizeof(g_tab_lanczos));
+}
+
+static inline int sat_short(float v) {
+  double r = nearbyint((double)v); /* cvRound: half to even */
+  if (r < -32768.0) r = -32768.0;
+  if (r > 32767.0) r = 32767.0;
+  return (int)r;
+}
+
+/* the ks x ks integer weights of fraction pair (fy, fx) */
+void orc_fixed_weights_2d(int ks, int fy, int fx, int* itab) {
+  init_fixed_tabs();
+  const float* ty = ks == 4 ? g_tab_cubic[fy] : g_tab_lanczos[fy];
+  const float* tx = ks == 4 ? g_tab_cubic[fx] : g_tab_lanczos[fx];
+  int isum = 0;
+  for (int k1 = 0; k1 < ks; k1++) {
+    float vy = ty[k1];
+    for (int k2 = 0; k2 < ks; k2++) {
+      float v = vy * tx[k2];
+      isum += itab[k1 * ks + k2] = sat_short(v * 32768.f);
+    }
+  }
+  if (isum != 32768) {
+    int diff = isum - 32768;
+    int h = ks / 2, Mk1 = h, Mk2 = h, mk1 = h, mk2 = h;
+    for (int k1 = h; k1 < h + 2; k1++)
+      for (int k2 = h; k2 < h + 2; k2++) {
+        if (itab[k1 * ks + k2] < itab[mk1 * ks + mk2]) { mk1 = k1; mk2 = k2; }
+        else if (itab[k1 * ks + k2] > itab[Mk1 * ks + Mk2]) { Mk1 = k1; Mk2 = k2; }
+      }
+    if (diff < 0) itab[Mk1 * ks + Mk2] = (short)(itab[Mk1 * ks + Mk2] - diff);
+    else itab[mk1 * ks + mk2] = (short)(itab[mk1 * ks + mk2] - diff);
+  }
+}
+
+static uint8_t sample_u8_tab(const sampler_t* s, double sx, double sy, uint8_t cv8) {
+  const int ks = s->interp == ORC_LANCZOS4 ? 8 : 4;
+  if (!(sx > -1e6 && sx < 1e6 && sy > -1e6 && sy < 1e6)) {
+    if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return cv8;
+    sx = sx < -1e6 ? -1e6 : (sx > 1e6 ? 1e6 : sx);
+    sy = sy < -1e6 ? -1e6 : (sy > 1e6 ? 1e6 : sy);
+  }
+  long qx = (long)nearbyint(sx * 32.0), qy = (long)nearbyint(sy * 32.0);
+  long ix0 = (qx >> 5) - (ks / 2 - 1), iy0 = (qy >> 5) - (ks / 2 - 1);
+  if (s->border == ORC_CONSTANT &&
+      (ix0 >= s->w || ix0 + ks <= 0 || iy0 >= s->h || iy0 + ks <= 0))
+    return cv8; /* whole footprint outside */
+  int itab[64];
+  orc_fixed_weights_2d(ks, (int)(qy & 31), (int)(qx & 31), itab);
+  int acc = 0;
+  for (int r = 0; r < ks; r++) {
+    long yy = resolve_idx(iy0 + r, s->h, s->border);
+    for (int c = 0; c < ks; c++) {
+      long xx = resolve_idx(ix0 + c, s->w, s->border);
+      int v = (yy < 0 || xx < 0) ? cv8 : ((const uint8_t*)s->src)[yy * s->pitch + xx];
+      acc += v * itab[r * ks + c];
+    }
+  }
+  int o = (acc + (1 << 14)) >> 15;
+  return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
+/* uint8 -> uint8: 0 = floating point path, 1 = bilinear fixed point, 2 = table fixed point */
+static int fixed_kind(const sampler_t* s, int src_dt, int dst_dt) {
+  if (src_dt != ORC_U8 || dst_dt != ORC_U8) return 0;
+  if (s->interp == ORC_LINEAR) return 1;
+  if (s->interp == ORC_CUBIC_CV || s->interp == ORC_LANCZOS4) {
+    init_fixed_tabs();
+    return 2;
+  }
+  return 0;
+}
+
 static inline uint8_t sat_u8(double v) {
   double r = nearbyint(v);
   if (!(r > 0)) r = 0;
@@ -336,14 +445,15 @@ int orc_remap(const void* src, int src_dt, long sh, long sw, long src_pitch, con
               long dst_pitch, int interp, int border, double cval) {
   sampler_t s;
   init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
-  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++) {
     for (long u = 0; u < dw; u++) {
       double sx = mapx[v * map_pitch + u], sy = mapy[v * map_pitch + u];
       if (fixed)
-        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+        ((uint8_t*)dst)[v * dst_pitch + u] =
+            fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else
         store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
     }
@@ -404,7 +514,7 @@ int orc_undistort(const void* src, int src_dt, long sh, long sw, long src_pitch,
   init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
   double ir[9];
   if (inv3(newK, ir)) return -1;
-  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++)
@@ -414,7 +524,8 @@ int orc_undistort(const void* src, int src_dt, long sh, long sw, long src_pitch,
       sx = (double)(float)sx; /* CV_32FC1 map storage */
       sy = (double)(float)sy;
       if (fixed)
-        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+        ((uint8_t*)dst)[v * dst_pitch + u] =
+            fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else
         store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
     }
@@ -430,7 +541,7 @@ int orc_warp_perspective(const void* src, int src_dt, long sh, long sw, long src
                          int interp, int border, double cval) {
   sampler_t s;
   init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
-  int fixed = (src_dt == ORC_U8 && dst_dt == ORC_U8 && s.interp == ORC_LINEAR);
+  int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++)
@@ -442,7 +553,8 @@ int orc_warp_perspective(const void* src, int src_dt, long sh, long sw, long src
       if (W != 0) { double iw = 1.0 / W; sx = X * iw; sy = Y * iw; }
       else { sx = 0; sy = 0; } /* cv2: W ? 1/W : 0 */
       if (fixed)
-        ((uint8_t*)dst)[v * dst_pitch + u] = sample_u8_fixed(&s, sx, sy, cv8);
+        ((uint8_t*)dst)[v * dst_pitch + u] =
+            fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else
         store_px(dst, dst_dt, v * dst_pitch + u, sample(&s, sx, sy));
     }

@@ -80,7 +80,7 @@ if __name__ == '__main__':
             a = rng.random((B, h, w), dtype=np.float32)
             isrc = ctx.to_device((a * (255 if dt == np.uint8 else 4095)).astype(dt))
             idst = ctx.empty((B, h, w), dt)
-            for interp in ('linear', 'linear_cv_q5', 'cubic', 'lanczos4'):
+            for interp in ('linear', 'linear_cv_q5', 'cubic', 'cubic_cv', 'lanczos4'):
                 t1 = timeit(ctx, lambda: ops.remap(isrc, dmx, dmy, interp, out=idst))
                 t2 = timeit(ctx, lambda: ops.warp_perspective(isrc, Hm, (h, w), interp, out=idst))
                 print('%-7s %-13s remap(maps) %8.1f us   warp %8.1f us  (%6.1f Gpx/s)'

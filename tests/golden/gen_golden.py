@@ -475,6 +475,83 @@ def remap_u8_fixed_np(img8, mx, my, cval8=0):
     return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
 
 
+def cv_fixed_tables_np(kind):
+    """OpenCV's tables for remap on CV_8U with INTER_CUBIC / INTER_LANCZOS4, written from the
+    published scheme in float32 numpy arithmetic: 1-D weights of the 32 fractions, then per
+    fraction pair the ks x ks weights round(wy * wx * 2^15) as shorts; where they do not sum to
+    2^15 the difference goes to one weight of the 2 x 2 block starting at (ks/2, ks/2) - the
+    largest when the sum is short, the smallest when it is over (first one in row-major order).
+    Returns (tab1d (32, ks) float32, itab (32, 32, ks, ks) int64)."""
+    f = np.float32
+    x = np.arange(32, dtype=f) * f(1.0 / 32)
+    if kind == 'cubic':
+        A = f(-0.75)
+        x1 = x + f(1)
+        u = f(1) - x
+        c0 = ((A * x1 - f(5) * A) * x1 + f(8) * A) * x1 - f(4) * A
+        c1 = ((A + f(2)) * x - (A + f(3))) * x * x + f(1)
+        c2 = ((A + f(2)) * u - (A + f(3))) * u * u + f(1)
+        c3 = f(1) - c0 - c1 - c2
+        tab = np.stack([c0, c1, c2, c3], axis=1).astype(f)
+    else:
+        # Lanczos a = 4 at the 8 taps -3..4, float32 coefficients, normalised in float32 with a
+        # sequentially accumulated float32 sum; fraction 0 is the unit impulse
+        t = x.astype(np.float64)[:, None] - np.arange(-3, 5)[None, :]
+        w = lanczos4_kernel(t).astype(f)
+        tab = np.zeros((32, 8), f)
+        for i in range(32):
+            if x[i] < np.finfo(f).eps:
+                tab[i, 3] = 1
+                continue
+            ssum = f(0)
+            for k in range(8):
+                ssum = f(ssum + w[i, k])
+            inv = f(1) / ssum
+            tab[i] = w[i] * inv
+    ks = tab.shape[1]
+    prod = (tab[:, None, :, None] * tab[None, :, None, :]).astype(f)   # [fy, fx, k1, k2]
+    itab = np.clip(np.rint((prod * f(32768)).astype(np.float64)), -32768, 32767).astype(np.int64)
+    isum = itab.sum(axis=(2, 3))
+    h = ks // 2
+    blk = itab[:, :, h:h + 2, h:h + 2].reshape(32, 32, 4)      # row-major scan order
+    imin, imax = blk.argmin(axis=2), blk.argmax(axis=2)          # first occurrence
+    diff = isum - 32768
+    target = np.where(diff < 0, imax, imin)
+    for fy in range(32):
+        for fx in range(32):
+            if diff[fy, fx] != 0:
+                k1, k2 = h + target[fy, fx] // 2, h + target[fy, fx] % 2
+                v = itab[fy, fx, k1, k2] - diff[fy, fx]
+                itab[fy, fx, k1, k2] = ((v + 32768) % 65536) - 32768    # (short)
+    return tab, itab
+
+
+def remap_u8_tab_np(img8, mx, my, kind, cval8=0):
+    """cv2.remap on CV_8U with INTER_CUBIC / INTER_LANCZOS4 and BORDER_CONSTANT: coordinates to
+    1/32 px, integer weights from cv_fixed_tables_np, (sum + 2^14) >> 15, saturated"""
+    _, itab = cv_fixed_tables_np(kind)
+    ks = itab.shape[2]
+    qx = np.rint(mx.astype(np.float64) * 32).astype(np.int64)
+    qy = np.rint(my.astype(np.float64) * 32).astype(np.int64)
+    ix0, iy0, fx, fy = (qx >> 5) - (ks // 2 - 1), (qy >> 5) - (ks // 2 - 1), qx & 31, qy & 31
+    src = img8.astype(np.int64)
+    h, w = src.shape
+    acc = np.zeros(mx.shape, np.int64)
+    wts = itab[fy, fx]                                            # (H, W, ks, ks)
+    for r in range(ks):
+        for c in range(ks):
+            yy, xx = iy0 + r, ix0 + c
+            ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+            v = np.full(yy.shape, int(cval8), np.int64)
+            v[ok] = src[yy[ok], xx[ok]]
+            acc += v * wts[:, :, r, c]
+    out = np.clip((acc + (1 << 14)) >> 15, 0, 255)
+    # a footprint wholly outside the source is the border value itself
+    outside = (ix0 >= w) | (ix0 + ks <= 0) | (iy0 >= h) | (iy0 + ks <= 0)
+    out[outside] = int(cval8)
+    return out.astype(np.uint8)
+
+
 def optimal_new_camera_matrix_np(K, d, size, alpha):
     """cv2.getOptimalNewCameraMatrix(K, d, (w, h), alpha, (w, h)), OpenCV 4.x definition:
     a 9 x 9 grid of image points is undistorted to ideal coordinates; `outer` bounds all of
@@ -557,10 +634,18 @@ def gen_cv_modes():
                                                        normalise=True).astype(np.float32)
         out['u8fix_%s' % name] = remap_u8_fixed_np(img8, mx, my, 0)
         out['u8fix17_%s' % name] = remap_u8_fixed_np(img8, mx, my, 17)
+        for kind in ('cubic', 'lanczos4'):
+            out['u8tab_%s_%s' % (kind, name)] = remap_u8_tab_np(img8, mx, my, kind, 0)
+            out['u8tab17_%s_%s' % (kind, name)] = remap_u8_tab_np(img8, mx, my, kind, 17)
     # the Lanczos4 table itself: rows k / 32, taps -3..4, normalised
     t = np.arange(32) / 32.0
     tab = np.stack([lanczos4_kernel(t - o) for o in range(-3, 5)], axis=1)
     out['lanczos_tab'] = tab / tab.sum(axis=1, keepdims=True)
+    # OpenCV's 8U tables (1-D float32 weights, 2-D short weights with the sum fix-up)
+    for kind in ('cubic', 'lanczos4'):
+        t1, t2 = cv_fixed_tables_np(kind)
+        out['fixtab1d_' + kind] = t1
+        out['fixtab2d_' + kind] = t2.astype(np.int16)
     # getOptimalNewCameraMatrix(alpha = 0, 1) for three cameras
     cams = {'barrel': (640, 480, [[600., 0, 319.5], [0, 600., 239.5], [0, 0, 1]],
                        [-0.2, 0.05, 0, 0, 0]),

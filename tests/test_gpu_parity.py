@@ -758,3 +758,19 @@ def test_cv_modes_vs_independent_restatements(ia, oracle):
                     key + ' ' + name, scale=1.0)
         assert np.array_equal(ia.ops.remap(img8, mx, my), g['u8fix_' + name])
         assert np.array_equal(ia.ops.remap(img8, mx, my, border_value=17), g['u8fix17_' + name])
+        # uint8 bicubic (a=-0.75) / Lanczos4 = OpenCV's short-weight tables: equal to the oracle
+        # for every coordinate source and border, and to the independent numpy restatement
+        # (Lanczos4: its float32 1-D weights differ from the oracle's in the last bit - two of
+        # the 1024 integer tables differ by one in one entry)
+        for kind, iname, frac in (('cubic', 'cubic_cv', 0.0), ('lanczos4', 'lanczos4', 0.01)):
+            got = ia.ops.remap(img8, mx, my, iname)
+            iid = oracle.CUBIC_CV if kind == 'cubic' else oracle.LANCZOS4
+            assert np.array_equal(got, oracle.remap(img8, mx, my, iid))
+            for bname, bid in (('replicate', oracle.REPLICATE), ('reflect101', oracle.REFLECT101),
+                               ('wrap', oracle.WRAP)):
+                assert np.array_equal(ia.ops.remap(img8, mx, my, iname, bname),
+                                      oracle.remap(img8, mx, my, iid, bid)), (kind, bname)
+            for key, cv in (('u8tab', 0), ('u8tab17', 17)):
+                want = g['%s_%s_%s' % (key, kind, name)]
+                d = np.abs(ia.ops.remap(img8, mx, my, iname, border_value=cv).astype(np.int32) - want)
+                assert d.max() <= 1 and (d != 0).mean() <= frac, (kind, name, key)

@@ -354,3 +354,49 @@ def test_cv_modes_independent_restatements(oracle):
     tab = _lanczos_table(oracle)
     assert_close(tab, g['lanczos_tab'], 0, 2e-7, 'Lanczos4 table')
     print('max |oracle - independent restatement|:', worst)
+
+
+def _close_u8(got, want, what, max_frac):
+    """uint8 results: equal, or (Lanczos4: the two restatements' float32 1-D weights differ in
+    the last bit, 2 of the 1024 integer tables in one entry) off by one on a few pixels"""
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1, '%s: max |diff| %d' % (what, d.max())
+    frac = float((d != 0).mean())
+    assert frac <= max_frac, '%s: %.4f %% of the pixels differ' % (what, 100 * frac)
+    return frac
+
+
+def test_cv_u8_fixed_point_tables(oracle):
+    """OpenCV's 8U bicubic / Lanczos4 (short weights with the sum fix-up, integer accumulation):
+    the oracle against the independent numpy restatement - tables and remapped images"""
+    import ctypes as C
+    g = load_golden('cv_modes.npz')
+    lib = oracle.lib()
+    for which, kind, ks in ((0, 'cubic', 4), (1, 'lanczos4', 8)):
+        t = np.zeros((32, ks), np.float32)
+        lib.orc_fixed_tab1d(which, t.ctypes.data_as(C.c_void_p))
+        if kind == 'cubic':
+            assert np.array_equal(t, g['fixtab1d_cubic'])
+        else:
+            assert_close(t, g['fixtab1d_lanczos4'], 0, 2.5e-7, 'Lanczos4 float32 weights')
+        bad = 0
+        it = np.zeros(ks * ks, np.int32)
+        for fy in range(32):
+            for fx in range(32):
+                lib.orc_fixed_weights_2d(ks, fy, fx, it.ctypes.data_as(C.c_void_p))
+                assert int(it.sum()) == 32768, (kind, fy, fx)
+                d = np.abs(it.reshape(ks, ks) - g['fixtab2d_' + kind][fy, fx])
+                assert d.max() <= 1
+                bad += int(d.max() != 0)
+        assert bad <= (0 if kind == 'cubic' else 8), (kind, bad)
+    img8 = g['img8']
+    for name in ('radial', 'strong'):
+        mx, my = g['mapx_' + name], g['mapy_' + name]
+        for kind, iid, frac in (('cubic', oracle.CUBIC_CV, 0.0), ('lanczos4', oracle.LANCZOS4, 0.01)):
+            _close_u8(oracle.remap(img8, mx, my, iid), g['u8tab_%s_%s' % (kind, name)],
+                      kind + ' ' + name, frac)
+            _close_u8(oracle.remap(img8, mx, my, iid, cval=17), g['u8tab17_%s_%s' % (kind, name)],
+                      kind + ' cval 17 ' + name, frac)
+            # the 1/32-px flag changes nothing: 8U coordinates are always rounded
+            assert np.array_equal(oracle.remap(img8, mx, my, iid | oracle.Q5),
+                                  oracle.remap(img8, mx, my, iid))
