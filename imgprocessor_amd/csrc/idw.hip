@@ -22,7 +22,9 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
-template <typename T>
+// ROWS: lanes over the columns of a window row with batched loads (windows of 17..64 columns);
+// otherwise lanes strided over the taps (small windows: fewer idle lanes; wide ones: any size)
+template <typename T, bool ROWS>
 __global__ void __launch_bounds__(256)
 idw_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int h, int w, long pitch,
            int ksize, const double* __restrict__ weights, int segs_x) {
@@ -39,14 +41,52 @@ idw_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int h, int w,
     todo &= todo - 1;
     const int j = xs + b;  // masked pixel (row, j)
     double sw = 0.0, sv = 0.0;
-    for (int t = lane; t < ntap; t += 64) {
-      int dy = t / kw, dx = t - dy * kw;
-      int yy = row + dy - ksize, xx = j + dx - ksize;
-      if (yy >= 0 && yy < h && xx >= 0 && xx < w && !(dy == ksize && dx == ksize) &&
-          mask[(long)yy * w + xx] == 0) {
-        double wi = weights[t];
-        sw += wi;
-        sv += wi * (double)grid[(long)yy * pitch + xx];
+    if constexpr (ROWS) {
+      // lanes over the columns of a window row (two rows per pass when the window is at most
+      // 32 wide); mask, value and weight of 8 passes are loaded back to back, the value whether
+      // or not it is used: no division per tap, no dependent mask -> weight -> value chain per
+      // pass (4K, 5 % masked, kernel 15: 947 -> see profiles/r02_micro.txt)
+      const bool two = kw <= 32;
+      const int half = two ? lane >> 5 : 0, step = two ? 2 : 1;
+      const int dx = two ? (lane & 31) : lane;
+      const bool col_ok = dx < kw;
+      const int xx = j + dx - ksize;
+      const bool col_in = col_ok && xx >= 0 && xx < w;
+      const int xxc = xx < 0 ? 0 : (xx >= w ? w - 1 : xx);
+      const int dxc = col_ok ? dx : 0;
+      for (int dy0 = half; dy0 - half < kw; dy0 += 8 * step) {
+        uint8_t m[8];
+        T g[8];
+        double wt[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int dy = dy0 + u * step < kw ? dy0 + u * step : kw - 1;
+          const int yy = row + dy - ksize;
+          const int yyc = yy < 0 ? 0 : (yy >= h ? h - 1 : yy);
+          m[u] = mask[(long)yyc * w + xxc];
+          g[u] = grid[(long)yyc * pitch + xxc];
+          wt[u] = weights[dy * kw + dxc];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int dy = dy0 + u * step;
+          const int yy = row + dy - ksize;
+          if (col_in && dy < kw && yy >= 0 && yy < h && !(dy == ksize && dx == ksize) && m[u] == 0) {
+            sw += wt[u];
+            sv += wt[u] * (double)g[u];
+          }
+        }
+      }
+    } else {
+      for (int t = lane; t < ntap; t += 64) {
+        int dy = t / kw, dx = t - dy * kw;
+        int yy = row + dy - ksize, xx = j + dx - ksize;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w && !(dy == ksize && dx == ksize) &&
+            mask[(long)yy * w + xx] == 0) {
+          double wi = weights[t];
+          sw += wi;
+          sv += wi * (double)grid[(long)yy * pitch + xx];
+        }
       }
     }
     sw = wave_sum(sw);
@@ -128,12 +168,17 @@ int ipa_idw_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* d_mas
   int segs_x = (w + 63) / 64;
   long segs = (long)segs_x * h;
   dim3 grid((unsigned)((segs + 3) / 4)), block(256);
-  if (dtype == IPA_F32)
-    hipLaunchKernelGGL((idw_kernel<float>), grid, block, 0, ctx->stream, (float*)d_grid, d_mask, h,
-                       w, pitch, ksize, (const double*)dw, segs_x);
-  else
-    hipLaunchKernelGGL((idw_kernel<double>), grid, block, 0, ctx->stream, (double*)d_grid, d_mask,
-                       h, w, pitch, ksize, (const double*)dw, segs_x);
+  const int kw = 2 * ksize + 1;
+  const bool rows = kw > 16 && kw <= 64;
+#define IPA_IDW(T, R)                                                                          \
+  hipLaunchKernelGGL((idw_kernel<T, R>), grid, block, 0, ctx->stream, (T*)d_grid, d_mask, h, w, \
+                     pitch, ksize, (const double*)dw, segs_x)
+  if (dtype == IPA_F32) {
+    if (rows) IPA_IDW(float, true); else IPA_IDW(float, false);
+  } else {
+    if (rows) IPA_IDW(double, true); else IPA_IDW(double, false);
+  }
+#undef IPA_IDW
   IPA_HIP(ctx, hipGetLastError());
   return IPA_OK;
 }
