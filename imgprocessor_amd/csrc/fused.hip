@@ -16,6 +16,7 @@ int ipa_fused_group_launch(ipa_ctx*, const FusedCall&, int K, int use_ring);
 // fused_ring.hip: plans the strips, runs the clean ones on the ring kernel and sets f.p.skip for
 // the per-frame kernel launched afterwards; 1 = not covered (f untouched)
 int ipa_fused_ring_launch(ipa_ctx*, FusedCall&, int K);
+int ipa_fused_pair_launch(ipa_ctx*, const FusedCall&, int K);      // fused_pair.hip; 1 = not covered
 int ipa_fused_ring_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_ring_big.hip; 1 = not covered
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
@@ -140,6 +141,14 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   if (ctx->tune.ring && n_frames >= ctx->tune.ring_min) {
     rc = ipa_fused_ring_launch(ctx, f, kh);
     if (rc < 0) return rc;
+  }
+  if (ctx->tune.pair && !f.p.skip) {
+    rc = ipa_fused_pair_launch(ctx, f, kh);
+    if (rc < 0) return rc;
+    if (rc == 0) {
+      IPA_HIP(ctx, hipGetLastError());
+      return IPA_OK;
+    }
   }
   switch (kh) {
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;

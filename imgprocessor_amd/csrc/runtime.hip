@@ -71,6 +71,7 @@ const TuneName kTuneNames[] = {
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"ring_big", "IPA_RING_BIG", &ipa_tuning::ring_big},
+    {"pair", "IPA_PAIR", &ipa_tuning::pair},
 };
 }  // namespace
 

@@ -499,6 +499,44 @@ __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], 
       TapLoad<ST, CT>::template row<NT>(s, e[k] + r * s.pitch, b.v[k][r]);
 }
 
+// The two halves of batch_issue() for callers that sample SEVERAL frames at the same
+// coordinates (wave_pair.hpp): footprints once, the tap loads per frame.  Bilinear float frames
+// in the lane-interleaved order (dword pairs).
+template <int N, int QM, typename C>
+__device__ __forceinline__ void batch_footprint_linear(const SrcView& s, const C (&sx)[N],
+                                                       const C (&sy)[N], float (&tx)[N],
+                                                       float (&ty)[N], int (&e)[N],
+                                                       unsigned& interior) {
+  constexpr int NT = 2;
+  interior = 0;
+  const unsigned xlim = s.w - NT + 1 > 0 ? (unsigned)(s.w - NT + 1) : 0u;
+  const unsigned ylim = s.h - NT + 1 > 0 ? (unsigned)(s.h - NT + 1) : 0u;
+#pragma unroll
+  for (int k = 0; k < N; k++) {
+    const bool ok = ipa_abs(sx[k]) < (C)kCoordLimit && ipa_abs(sy[k]) < (C)kCoordLimit;
+    int ix0, iy0;
+    axis_frac<kLinear, float, C, QM>(s, ok ? sx[k] : (C)0, ix0, tx[k]);
+    axis_frac<kLinear, float, C, QM>(s, ok ? sy[k] : (C)0, iy0, ty[k]);
+    const bool in = ok && (unsigned)ix0 < xlim && (unsigned)iy0 < ylim;
+    interior |= in ? (1u << k) : 0u;
+    e[k] = __mul24(iy0, s.pitch) + ix0;
+  }
+}
+template <int N>
+__device__ __forceinline__ void batch_loads_linear(const SrcView& s, const int (&e)[N],
+                                                   BatchTaps<float, kLinear, N>& b) {
+  int four = 4;
+  asm("" : "+s"(four));  // (see TapLoad<float, float>::row: keeps the two dwords apart)
+#pragma unroll
+  for (int k = 0; k < N; k++)
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int o = (e[k] + r * s.pitch) << 2;
+      b.v[k][r][0] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, o, 0, 0));
+      b.v[k][r][1] = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, o + four, 0, 0));
+    }
+}
+
 // blend footprint k of an issued batch (same arithmetic / order as sample())
 template <typename ST, int INTERP, int N>
 __device__ __forceinline__ typename compute_of<ST>::type batch_blend_one(

@@ -189,3 +189,27 @@ def test_group_4k_strip_geometry(ia, oracle):
     sub = slice(1000, 1200)
     want = oracle.conv2d(oracle.remap(src[4], mx, my), k)
     assert_close(ring[4][sub], want[sub], 1e-5, 1e-5 * np.abs(want).max(), '4K vs oracle')
+
+
+@pytest.mark.parametrize('n', [2, 3, 5, 8])
+@pytest.mark.parametrize('K', [3, 5])
+def test_frame_pair_kernel_matches_per_frame(ia, K, n):
+    """one wave per strip of a frame PAIR (csrc/wave_pair.hpp): the bits of the per-frame kernel"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    for (h, w), q5 in (((200, 1030), False), ((131, 517), True), ((330, 780), False)):
+        src = frames(n, h, w)
+        mx, my, _, _ = radial_maps(h, w)
+        mx = mx.copy()
+        mx[h // 2, 40:60] = np.nan
+        d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+        interp = 'linear_cv_q5' if q5 else 'linear'
+        for kw in ({}, {'conv_mode': 'constant'}, {'border_mode': 'reflect', 'conv_mode': 'wrap'}):
+            old = ctx.set_tuning(pair=0, ring=0, group=0)
+            try:
+                ref = ops.remap_conv2d(d_src, dmx, dmy, kern(K), interp, **kw).get()
+                ctx.set_tuning(pair=1)
+                got = ops.remap_conv2d(d_src, dmx, dmy, kern(K), interp, **kw).get()
+            finally:
+                ctx.set_tuning(**old)
+            same_bits(got, ref, 'pair kernel K=%d n=%d %r %r' % (K, n, (h, w), kw))
