@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Randomised check of the remap family against the CPU oracle (GPU box): float32 within
+1e-5 of the data range, integer results bit for bit.  Not collected by pytest (run by hand on
+the GPU box).  usage: python tests/fuzz_oracle.py [n] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, R)
+import imgprocessor_amd as ia  # noqa: E402
+from imgprocessor_amd import ops  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+INTERPS = {'nearest': oracle.NEAREST, 'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS,
+           'cubic_cv': oracle.CUBIC_CV, 'linear_cv_q5': oracle.LINEAR | oracle.Q5,
+           'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5, 'lanczos4': oracle.LANCZOS4}
+BORDERS = {'constant': oracle.CONSTANT, 'replicate': oracle.REPLICATE, 'reflect': oracle.REFLECT,
+           'wrap': oracle.WRAP, 'reflect101': oracle.REFLECT101}
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ctx = ia.default_context(0)
+    fails = 0
+    worst = 0.0
+    for case in range(n_cases):
+        h, w = int(rng.integers(20, 300)), int(rng.integers(40, 700))
+        dh, dw = (h, w) if rng.random() < 0.6 else (int(rng.integers(20, 300)), int(rng.integers(40, 700)))
+        n = int(rng.integers(1, 5))
+        dt = rng.choice([np.float32, np.float32, np.uint8, np.uint16])
+        a = rng.random((n, h, w))
+        src = a.astype(np.float32) if dt == np.float32 else np.round(
+            a * (255 if dt == np.uint8 else 4095)).astype(dt)
+        ang = np.deg2rad(rng.choice([0, 0, 3, -8, 45, 90]) + rng.normal(0, 0.5))
+        sc = rng.choice([1.0, 0.9, 1.15, 0.5, 2.0])
+        yy, xx = np.mgrid[0:dh, 0:dw].astype(np.float64)
+        x0, y0 = xx - dw / 2, yy - dh / 2
+        mx = (sc * (np.cos(ang) * x0 - np.sin(ang) * y0) + w / 2 + rng.normal(0, 10) +
+              2 * np.sin(yy / 31.0)).astype(np.float32)
+        my = (sc * (np.sin(ang) * x0 + np.cos(ang) * y0) + h / 2 + rng.normal(0, 10) +
+              2 * np.cos(xx / 47.0)).astype(np.float32)
+        if rng.random() < 0.15:
+            mx[dh // 2, dw // 3:dw // 3 + 5] = np.nan
+        iname = str(rng.choice(list(INTERPS)))
+        bname = str(rng.choice(list(BORDERS)))
+        cval = float(rng.choice([0.0, 0.3, 17.0])) if dt != np.float32 else float(rng.choice([0.0, 0.3]))
+        got = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), iname, bname,
+                        cval).get()
+        for f in range(n):
+            want = oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval)
+            if dt == np.float32:
+                ok = np.isnan(got[f]) == np.isnan(want)
+                d = np.abs(np.nan_to_num(got[f]) - np.nan_to_num(want)).max() if ok.all() else np.inf
+                worst = max(worst, float(d))
+                bad = d > 1e-5 * max(1.0, float(np.abs(np.nan_to_num(want)).max()))
+            else:
+                bad = not np.array_equal(got[f], want)
+            if bad:
+                fails += 1
+                print('MISMATCH case %d frame %d: %s %dx%d -> %dx%d %s %s cval %g'
+                      % (case, f, np.dtype(dt).name, h, w, dh, dw, iname, bname, cval))
+                break
+        if (case + 1) % 50 == 0:
+            print('%d cases, %d mismatches, worst float error %.2e' % (case + 1, fails, worst), flush=True)
+    print('done: %d cases, %d mismatches, worst float error %.2e' % (n_cases, fails, worst))
+    return 1 if fails else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
