@@ -3,7 +3,7 @@ accumulation), GPU box: max |gpu - oracle| / max|oracle| (the form the 1e-5 tole
 parity tests takes: rtol 1e-5 + atol 1e-5 * max|oracle|) and the max pointwise relative error
 over pixels with |oracle| >= 1e-3 * max|oracle|.
 
-    python tools/rel_err.py
+    python tests/rel_err.py
 """
 import os
 import sys
