@@ -100,26 +100,6 @@ __device__ __forceinline__ void wave_span(int& xmn, int& xmx, int& ymn, int& ymx
   ymx = wave_minmax<true>(ymx);
 }
 
-// v_pk_fma_f32 / v_pk_mul_f32 with ONE coefficient of an SGPR pair broadcast to both halves
-// (op_sel): the K * K coefficients then take K * K scalar registers, not 2 * K * K as the
-// {w, w} pairs the compiler forms on its own
-template <int HI> __device__ __forceinline__ v2f pk_fma_coef(v2f wp, v2f x, v2f c) {
-  v2f d;
-  if constexpr (HI)
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
-  else
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
-  return d;
-}
-template <int HI> __device__ __forceinline__ v2f pk_mul_coef(v2f wp, v2f x) {
-  v2f d;
-  if constexpr (HI)
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "s"(wp), "v"(x));
-  else
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(wp), "v"(x));
-  return d;
-}
-
 // LDS-only workgroup barrier: __syncthreads() would also drain the vector-memory counter,
 // i.e. wait for the prefetched source rows and the output stores at every chunk
 __device__ __forceinline__ void lds_barrier() {

@@ -325,6 +325,26 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(4)))* kernarg_f32;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// v_pk_fma_f32 / v_pk_mul_f32 with ONE coefficient of an SGPR pair broadcast to both halves
+// (op_sel): the K * K coefficients then take K * K scalar registers, not 2 * K * K as the
+// {w, w} pairs the compiler forms on its own
+template <int HI> __device__ __forceinline__ v2f pk_fma_coef(v2f wp, v2f x, v2f c) {
+  v2f d;
+  if constexpr (HI)
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
+  else
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "s"(wp), "v"(x), "v"(c));
+  return d;
+}
+template <int HI> __device__ __forceinline__ v2f pk_mul_coef(v2f wp, v2f x) {
+  v2f d;
+  if constexpr (HI)
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(d) : "s"(wp), "v"(x));
+  else
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(d) : "s"(wp), "v"(x));
+  return d;
+}
+
 template <bool FAST, typename Src, int K, int QM = -1, bool STREAM = false>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                    const Weights<float, K * K>& wts, float* xp,
@@ -399,23 +419,37 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
                            "n"((i - 1) * 48 + 32));
           }
         }
+        static_for<0, K>([&](auto Jj) {
+          constexpr int j = decltype(Jj)::value;
+          if constexpr (STREAM) {
+            // the coefficient is one half of an SGPR pair, broadcast by op_sel: no scalar move
+            // (and its wait state) per odd tap
+            const v2f wp2 = v2f{cc[i][j >> 2][j & 2], cc[i][j >> 2][(j & 2) + 1]};
 #pragma unroll
-        for (int j = 0; j < K; j++) {
-          float w;
-          if constexpr (STREAM) w = cc[i][j >> 2][j & 3];
-          else w = wts.w[i * K + j];
-          const v2f w2 = v2f{w, w};
+            for (int h = 0; h < 2; h++) {
+              if constexpr (i == 0) {
+                if constexpr (j == 0) acc[0][h] = pk_mul_coef<0>(wp2, pair[2 * h]);
+                else acc[0][h] = pk_fma_coef<(j & 1)>(wp2, pair[j + 2 * h], acc[0][h]);
+              } else {
+                if constexpr (j == 0) acc[i][h] = pk_fma_coef<0>(wp2, pair[2 * h], acc[i - 1][h]);
+                else acc[i][h] = pk_fma_coef<(j & 1)>(wp2, pair[j + 2 * h], acc[i][h]);
+              }
+            }
+          } else {
+            const float w = wts.w[i * K + j];
+            const v2f w2 = v2f{w, w};
 #pragma unroll
-          for (int h = 0; h < 2; h++) {
-            if constexpr (i == 0) {
-              acc[0][h] = j == 0 ? w2 * pair[2 * h]
-                                 : __builtin_elementwise_fma(w2, pair[j + 2 * h], acc[0][h]);
-            } else {
-              acc[i][h] = __builtin_elementwise_fma(w2, pair[j + 2 * h],
-                                                    j == 0 ? acc[i - 1][h] : acc[i][h]);
+            for (int h = 0; h < 2; h++) {
+              if constexpr (i == 0) {
+                acc[0][h] = j == 0 ? w2 * pair[2 * h]
+                                   : __builtin_elementwise_fma(w2, pair[j + 2 * h], acc[0][h]);
+              } else {
+                acc[i][h] = __builtin_elementwise_fma(w2, pair[j + 2 * h],
+                                                      j == 0 ? acc[i - 1][h] : acc[i][h]);
+              }
             }
           }
-        }
+        });
         // keep the next kernel row's scalar loads below this row's fmas
         if constexpr (STREAM) __builtin_amdgcn_sched_barrier(0);
       });
