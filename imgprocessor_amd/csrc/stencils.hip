@@ -507,6 +507,52 @@ nan_max_kernel(const T* __restrict__ src, int gx, int gy, long pitch, int k, T* 
   dst[(long)i * dpitch + j] = m;
 }
 
+// The same in two separable passes through LDS (nanmax over a rectangle = nanmax over its rows
+// of the row-wise nanmax; the scan order row-major, first maximum kept, is preserved): a block
+// of 64 x RB outputs stages its (RB + 2k) x (64 + 2k) source tile once, reduces every tile row
+// horizontally into a second plane, then every output column vertically.  2k + 2k LDS reads per
+// output instead of 4 k^2 global loads (4K frame, ksize 7: 150 -> see profiles/r02_micro.txt).
+template <typename T>
+__global__ void __launch_bounds__(256)
+nan_max_sep_kernel(const T* __restrict__ src, int gx, int gy, long pitch, int k, int rb,
+                   T* __restrict__ dst, long dpitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nanmax_lds[];
+  const int tw = 64 + 2 * k, th = rb + 2 * k;
+  T* tile = reinterpret_cast<T*>(nanmax_lds);  // th x tw source values
+  T* hmax = tile + th * tw;                    // th x 64 row-wise maxima
+  const int j0 = blockIdx.x * 64, i0 = blockIdx.y * rb;
+  const T nanv = (T)__builtin_nan("");
+  for (int e = threadIdx.x; e < th * tw; e += 256) {
+    const int ty = e / tw, tx = e - ty * tw;
+    const int ii = i0 - k + ty, jj = j0 - k + tx;
+    tile[e] = (ii >= 0 && ii < gx && jj >= 0 && jj < gy) ? src[(long)ii * pitch + jj] : nanv;
+  }
+  __syncthreads();
+  // row-wise: output column j0 + c covers source columns [j - k, j + k) = tile columns [c, c + 2k)
+  for (int e = threadIdx.x; e < th * 64; e += 256) {
+    const int ty = e >> 6, c = e & 63;
+    const T* tp = tile + ty * tw + c;
+    T m = nanv;
+    for (int q = 0; q < 2 * k; q++) {
+      const T v = tp[q];
+      if (v == v && !(m >= v)) m = v;
+    }
+    hmax[e] = m;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < rb * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const int i = i0 + r, j = j0 + c;
+    if (i >= gx || j >= gy) continue;
+    T m = nanv;
+    for (int q = 0; q < 2 * k; q++) {  // source rows [i - k, i + k) = tile rows [r, r + 2k)
+      const T v = hmax[(r + q) * 64 + c];
+      if (v == v && !(m >= v)) m = v;
+    }
+    dst[(long)i * dpitch + j] = m;
+  }
+}
+
 // render/closestDirectDistance.py:17-41: distance to the closest non-zero pixel within the
 // +-ksize window (centre excluded), 2*ksize when there is none, 0 on non-zero pixels.  The
 // minimum is taken over the integer squared distances; one sqrt at the end gives the same
@@ -846,6 +892,22 @@ int ipa_nan_max_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, lo
     IPA_UNSUPPORTED(ctx, "nan_max supports float32/float64 (got dtype %d)", dtype);
   dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
+  {
+    const int k = ksize / 2, rb = 32;
+    const size_t esz = dtype == IPA_F32 ? 4 : 8;
+    const size_t lds = ((size_t)(rb + 2 * k) * (64 + 2 * k) + (size_t)(rb + 2 * k) * 64) * esz;
+    if (k >= 1 && lds <= 60 * 1024) {
+      dim3 sgrid((w + 63) / 64, (h + rb - 1) / rb), sblock(256);
+      if (dtype == IPA_F32)
+        hipLaunchKernelGGL((nan_max_sep_kernel<float>), sgrid, sblock, lds, ctx->stream,
+                           (const float*)d_arr, h, w, pitch, k, rb, (float*)d_out, out_pitch);
+      else
+        hipLaunchKernelGGL((nan_max_sep_kernel<double>), sgrid, sblock, lds, ctx->stream,
+                           (const double*)d_arr, h, w, pitch, k, rb, (double*)d_out, out_pitch);
+      IPA_HIP(ctx, hipGetLastError());
+      return IPA_OK;
+    }
+  }
   if (dtype == IPA_F32)
     hipLaunchKernelGGL((nan_max_kernel<float>), grid, block, 0, ctx->stream, (const float*)d_arr,
                        h, w, pitch, ksize / 2, (float*)d_out, out_pitch);
