@@ -584,6 +584,55 @@ closest_distance_kernel(const unsigned char* __restrict__ arr, int s0, int s1, l
   out[(long)i * opitch + j] = (OT)md;  // uint16: truncation, like numba's store
 }
 
+// The same minimum in two passes: g(i, j) = distance along row i from column j to the nearest
+// non-zero pixel within +-ksize (255 = none), then d^2(i, j) = min over the rows i + dy of
+// dy^2 + g(i + dy, j)^2 - the minimum over a row of dy^2 + dx^2 is reached at the smallest |dx|.
+// 2 ksize + 1 byte reads per pixel and pass instead of (2 ksize + 1)^2; integer squared
+// distances, so the result is the same number (4K frame, ksize 30: 6.8 ms -> see r02_micro.txt).
+__global__ void __launch_bounds__(256)
+closest_rowdist_kernel(const unsigned char* __restrict__ arr, int s0, int s1, long pitch, int ksize,
+                       unsigned char* __restrict__ g) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= s0 || j >= s1) return;
+  const unsigned char* row = arr + (long)i * pitch;
+  int best = 255;
+  for (int d = 0; d <= ksize; d++) {
+    const bool l = j - d >= 0 && row[j - d] != 0, r = j + d < s1 && row[j + d] != 0;
+    if (l || r) {
+      best = d;
+      break;
+    }
+  }
+  g[(long)i * s1 + j] = (unsigned char)best;
+}
+
+template <typename OT>
+__global__ void __launch_bounds__(256)
+closest_coldist_kernel(const unsigned char* __restrict__ arr, const unsigned char* __restrict__ g,
+                       int s0, int s1, long pitch, int ksize, OT* __restrict__ out, long opitch) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y * 4 + threadIdx.y;
+  if (i >= s0 || j >= s1) return;
+  double md = 0.0;
+  if (!arr[(long)i * pitch + j]) {
+    const int big = 0x7fffffff;
+    int best = big;
+    const int xmn = i - ksize < 0 ? 0 : i - ksize, xmx = i + ksize >= s0 ? s0 - 1 : i + ksize;
+    for (int xi = xmn; xi <= xmx; xi++) {
+      const int gd = g[(long)xi * s1 + j];
+      if (gd != 255) {
+        const int d2 = (xi - i) * (xi - i) + gd * gd;
+        best = d2 < best ? d2 : best;
+      }
+    }
+    md = 2.0 * (double)ksize;
+    if (best != big) {
+      const double d = sqrt((double)best);
+      if (d < md) md = d;
+    }
+  }
+  out[(long)i * opitch + j] = (OT)md;  // uint16: truncation, like numba's store
+}
+
 // uncertainty/positionToIntensityUncertainty.py:7-49: square root of the PSF-weighted mean of
 // the squared differences to the centre pixel.  The Gaussian is equations/numbaGaussian2d.py
 // as that file is called there (first sigma on the row axis), evaluated per pixel: the constant
@@ -767,6 +816,21 @@ int ipa_closest_distance_dev(ipa_ctx* ctx, const unsigned char* d_arr, int h, in
     IPA_UNSUPPORTED(ctx, "closest_distance writes uint16 or float64 (got dtype %d)", out_dtype);
   dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (ksize <= 254) {  // (row distances fit a byte; the distances go through the context workspace)
+    int rc = ipa_ws_reserve(ctx, (size_t)h * w);
+    if (rc) return rc;
+    unsigned char* g = (unsigned char*)ctx->ws;
+    hipLaunchKernelGGL(closest_rowdist_kernel, grid, block, 0, ctx->stream, d_arr, h, w, pitch, ksize,
+                       g);
+    if (out_dtype == IPA_U16)
+      hipLaunchKernelGGL((closest_coldist_kernel<unsigned short>), grid, block, 0, ctx->stream, d_arr,
+                         g, h, w, pitch, ksize, (unsigned short*)d_out, out_pitch);
+    else
+      hipLaunchKernelGGL((closest_coldist_kernel<double>), grid, block, 0, ctx->stream, d_arr, g, h, w,
+                         pitch, ksize, (double*)d_out, out_pitch);
+    IPA_HIP(ctx, hipGetLastError());
+    return IPA_OK;
+  }
   if (out_dtype == IPA_U16)
     hipLaunchKernelGGL((closest_distance_kernel<unsigned short>), grid, block, 0, ctx->stream,
                        d_arr, h, w, pitch, ksize, (unsigned short*)d_out, out_pitch);
