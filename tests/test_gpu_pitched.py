@@ -27,9 +27,10 @@ def _embed(a, pad_x, pad_rows, fill):
     return big
 
 
+@pytest.mark.parametrize('odd', [0, 1])
 @pytest.mark.parametrize('interp', ['linear', 'cubic', 'lanczos4'])
 @pytest.mark.parametrize('tune', [dict(ring_remap=0), dict(ring_remap=2)])
-def test_remap_with_pitches(ia, interp, tune):
+def test_remap_with_pitches(ia, interp, tune, odd):
     from imgprocessor_amd import ops
     from imgprocessor_amd.device import dtype_id
     ctx = ia.default_context(0)
@@ -39,7 +40,8 @@ def test_remap_with_pitches(ia, interp, tune):
     old = ctx.set_tuning(ring_min=1, **tune)
     try:
         want = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), interp).get()
-        sp, dp, mp = w + 24, w + 8, w + 12          # pitches (elements), rows stay 16-byte aligned
+        # pitches (elements): rows 16-byte aligned, or (odd) at every 4-byte alignment
+        sp, dp, mp = w + 24 + odd, w + 8 + 3 * odd, w + 12 + odd
         sbig = ctx.to_device(_embed(src, sp - w, 5, 7.0))
         mbx = ctx.to_device(_embed(mx[None], mp - w, 0, -1e9)[0])
         mby = ctx.to_device(_embed(my[None], mp - w, 0, -1e9)[0])
@@ -55,9 +57,10 @@ def test_remap_with_pitches(ia, interp, tune):
     assert (got[:, h:, :] == -5.0).all() and (got[:, :, w:] == -5.0).all(), 'wrote outside'
 
 
+@pytest.mark.parametrize('odd', [0, 1])
 @pytest.mark.parametrize('K', [5, 9])
 @pytest.mark.parametrize('tune', [dict(), dict(pair=1), dict(ring=1), dict(ring_big=2)])
-def test_remap_conv_with_pitches(ia, K, tune):
+def test_remap_conv_with_pitches(ia, K, tune, odd):
     from imgprocessor_amd import ops
     from imgprocessor_amd.device import dtype_id
     ctx = ia.default_context(0)
@@ -68,7 +71,7 @@ def test_remap_conv_with_pitches(ia, K, tune):
     old = ctx.set_tuning(ring_min=1, **tune)
     try:
         want = ops.remap_conv2d(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), k).get()
-        sp, dp, mp = w + 20, w + 4, w + 16
+        sp, dp, mp = w + 20 + odd, w + 4 + odd, w + 16 + 3 * odd
         sbig = ctx.to_device(_embed(src, sp - w, 2, 3.0))
         mbx = ctx.to_device(_embed(mx[None], mp - w, 0, -1e9)[0])
         mby = ctx.to_device(_embed(my[None], mp - w, 0, -1e9)[0])
