@@ -369,9 +369,7 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
       else vv[d] = resolve_idx(y0 - G::H + tb + d, p.dh, p.cby);
     }
     typename Src::template Chunk<D> ch;
-    __builtin_amdgcn_s_setprio(2);  // the wave that is about to request memory goes first
     src.template load_chunk<FAST, D, QM>(c, vv, ch);
-    __builtin_amdgcn_s_setprio(0);
     src.template stage_rows<FAST, D>(c, vv, ch, xp);
     // wave-private LDS rows: the wave's own ds_write / ds_read execute in order
     __builtin_amdgcn_wave_barrier();
