@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised differential check of the alternative kernels against the plain ones (GPU):
 ring remap, ring big, frame-pair kernel, lens map cache - every result must have the bits of
-the per-frame / gather kernels.  usage: python tools/fuzz_paths.py [n_cases] [seed]"""
+the per-frame / gather kernels.  usage: python tools/fuzz_paths.py [n_cases] [seed] [big]
+(big: frames up to 2200 x 3900 instead of 420 x 1300)"""
 import os
 import sys
 
@@ -28,14 +29,16 @@ def main():
     n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
+    big = len(sys.argv) > 3 and sys.argv[3] == 'big'
+    hmax, wmax = (2200, 3900) if big else (420, 1300)
     ctx = ia.default_context(0)
     fails = 0
     for case in range(n_cases):
-        h = int(rng.integers(40, 420))
-        w = int(rng.integers(70, 1300))
-        n = int(rng.integers(1, 9))
-        dh = h if rng.random() < 0.7 else int(rng.integers(30, 420))
-        dw = w if rng.random() < 0.7 else int(rng.integers(60, 1300))
+        h = int(rng.integers(40, hmax))
+        w = int(rng.integers(70, wmax))
+        n = int(rng.integers(1, 5 if big else 9))
+        dh = h if rng.random() < 0.7 else int(rng.integers(30, hmax))
+        dw = w if rng.random() < 0.7 else int(rng.integers(60, wmax))
         src = rng.random((n, h, w), dtype=np.float32)
         if rng.random() < 0.1:
             src[0, h // 2, w // 3] = np.nan
