@@ -86,6 +86,67 @@ int ipa_lanczos_table(ipa_ctx* ctx, const float** out) {
   return IPA_OK;
 }
 
+// OpenCV's 8U bicubic weights as a table (imgwarp.cpp initInterTab2D, fixpt): per fraction pair
+// (fy, fx) the 4 x 4 shorts saturate_cast<short>(wy[k1] * wx[k2] * 2^15), their sum forced to 2^15
+// on one entry of the 2 x 2 block at (2, 2).  Device layout: row fy * 32 + fx = 8 dwords, per tap
+// row {w0 | w2 << 16, w1 | w3 << 16} - the operands of v_dot2_i32_i16 against the tap bytes
+// (b0, b2) and (b1, b3).  32 KB: remap_kernel keeps it in LDS.
+static int sat_short_f(float v) {
+  double r = nearbyint((double)v);  // cvRound: half to even
+  if (r < -32768.0) r = -32768.0;
+  if (r > 32767.0) r = 32767.0;
+  return (int)r;
+}
+
+static int* g_cubic2d_dev[64] = {};
+
+int ipa_u8_cubic_tab2d(ipa_ctx* ctx, const int** out) {
+#pragma clang fp contract(off)
+  std::lock_guard<std::mutex> lk(g_lz_mu);
+  const int dev = ctx->device;
+  IPA_REQUIRE(ctx, dev >= 0 && dev < 64, "device id out of range");
+  if (!g_cubic2d_dev[dev]) {
+    float t1[32][4];
+    for (int k = 0; k < 32; k++) cubic_row_f32((float)k * (1.f / 32), t1[k]);
+    static int packed[1024 * 8];
+    for (int fy = 0; fy < 32; fy++)
+      for (int fx = 0; fx < 32; fx++) {
+        int itab[16], isum = 0;
+        for (int k1 = 0; k1 < 4; k1++) {
+          const float vy = t1[fy][k1];
+          for (int k2 = 0; k2 < 4; k2++) {
+            const float v = vy * t1[fx][k2];
+            isum += itab[k1 * 4 + k2] = sat_short_f(v * 32768.f);
+          }
+        }
+        if (isum != 32768) {
+          const int diff = isum - 32768;
+          int Mk1 = 2, Mk2 = 2, mk1 = 2, mk2 = 2;
+          for (int k1 = 2; k1 < 4; k1++)
+            for (int k2 = 2; k2 < 4; k2++) {
+              if (itab[k1 * 4 + k2] < itab[mk1 * 4 + mk2]) { mk1 = k1; mk2 = k2; }
+              else if (itab[k1 * 4 + k2] > itab[Mk1 * 4 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+            }
+          if (diff < 0) itab[Mk1 * 4 + Mk2] = (short)(itab[Mk1 * 4 + Mk2] - diff);
+          else itab[mk1 * 4 + mk2] = (short)(itab[mk1 * 4 + mk2] - diff);
+        }
+        int* row = packed + (fy * 32 + fx) * 8;
+        for (int r = 0; r < 4; r++) {
+          const int* w = itab + r * 4;
+          row[r * 2 + 0] = (w[0] & 0xffff) | (int)((unsigned)w[2] << 16);
+          row[r * 2 + 1] = (w[1] & 0xffff) | (int)((unsigned)w[3] << 16);
+        }
+      }
+    int* d = nullptr;
+    IPA_HIP(ctx, hipSetDevice(dev));
+    IPA_HIP(ctx, hipMalloc((void**)&d, sizeof(packed)));
+    IPA_HIP(ctx, hipMemcpy(d, packed, sizeof(packed), hipMemcpyHostToDevice));
+    g_cubic2d_dev[dev] = d;
+  }
+  *out = g_cubic2d_dev[dev];
+  return IPA_OK;
+}
+
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border) {
   int base = interp & 0xff;
   IPA_REQUIRE(ctx, (interp & ~(0xff | IPA_INTER_Q5)) == 0, "unknown interpolation flags 0x%x",

@@ -39,6 +39,7 @@ struct RemapParams {
   int dst_vec, map_vec;
   int frames_inner;  // n_frames when the grid is 1-D with the frame index fastest, else 0
   // tiles the ring kernel computes (ring_remap.hpp): skip[strip row * tiles_x + tile column]
+  const int* tab2d;    // uint8 -> uint8 bicubic (a = -0.75): OpenCV's short weights, 1024 x 8 dwords
   const unsigned* skip;
   unsigned tile_rows;  // groups of 4 rows per workgroup (1; a strip of the skip mask behind it)
 };
@@ -116,25 +117,37 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   if (REST && p.skip[tyb * p.tiles_x + txi]) return;
   // Lanczos4: the 32 x 8 weight table is read four float4 per sample - from LDS, not through
   // the vector-memory path the 16 tap-row gathers of the sample already load
-  constexpr bool kTabFixed = FIXED && INTERP != kLinear;  // uint8 bicubic / Lanczos4 by tables
+  // uint8 Lanczos4: OpenCV's short weights formed per sample from the float32 1-D table;
+  // uint8 bicubic: the whole 2-D short table (32 KB) in LDS, a workgroup then works on
+  // p.tile_rows groups of rows
+  constexpr bool kTabFixed = FIXED && INTERP == kLanczos4;
+  constexpr bool kTabLds = FIXED && INTERP == kCubic;
   __shared__ __attribute__((aligned(16)))
   float lz_tab[kTabFixed ? 384 : (INTERP == kLanczos4 ? 256 : 4)];
-  if constexpr (INTERP == kLanczos4 || kTabFixed) {
+  __shared__ __attribute__((aligned(16))) int4 tab_lds[kTabLds ? 2048 : 1];
+  if constexpr (INTERP == kLanczos4) {
     const unsigned tid = threadIdx.y * 64 + threadIdx.x;
     lz_tab[tid] = p.lanczos[tid];
     if constexpr (kTabFixed)
       if (tid < 128u) lz_tab[256 + tid] = p.lanczos[256 + tid];
     __syncthreads();
   }
+  if constexpr (kTabLds) {
+    const unsigned tid = threadIdx.y * 64 + threadIdx.x;
+    const int4* gt = reinterpret_cast<const int4*>(p.tab2d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) tab_lds[tid + 256u * i] = gt[tid + 256u * i];
+    __syncthreads();
+  }
   SrcView s;
   s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
   s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
   s.border = p.border; s.q5 = p.q5; s.cubic_a = p.cubic_a;
-  s.lanczos = (INTERP == kLanczos4 || kTabFixed) ? lz_tab : p.lanczos;
+  s.lanczos = INTERP == kLanczos4 ? lz_tab : p.lanczos;
   const int x0 = (int)((txi * 64 + threadIdx.x) * 4);
   if (x0 >= p.dw) return;
   const int n = p.dw - x0 < 4 ? p.dw - x0 : 4;
-  const unsigned tile_rows = REST ? p.tile_rows : 1u;
+  const unsigned tile_rows = (REST || kTabLds) ? p.tile_rows : 1u;
   for (unsigned sub = 0; sub < tile_rows; sub++) {
   const int y = (int)((tyb * tile_rows + sub) * 4 + threadIdx.y);
   if (y >= p.dh) return;
@@ -205,6 +218,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       if constexpr (INTERP == kLinear) out[k] = k < n ? sample_u8_fixed(s, sx[k], sy[k], cv8) : 0;
+      else if constexpr (kTabLds) out[k] = k < n ? sample_u8_cubic_lds(s, tab_lds, sx[k], sy[k], cv8) : 0;
       else out[k] = k < n ? sample_u8_tab<INTERP>(s, sx[k], sy[k], cv8) : 0;
     }
   } else {
@@ -257,6 +271,7 @@ using namespace ipa;
 
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 int ipa_lanczos_table(ipa_ctx* ctx, const float** out);               // remap.hip
+int ipa_u8_cubic_tab2d(ipa_ctx* ctx, const int** out);                // remap.hip
 
 struct RemapCall {
   const void* src; int src_dt; int sh, sw; long spitch;
@@ -398,8 +413,13 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   p.q5 = (a.interp & IPA_INTER_Q5) ? 1 : 0;
   p.cubic_a = base == IPA_INTER_CUBIC_KEYS ? -0.5f : -0.75f;
   p.lanczos = nullptr;
-  if (base == IPA_INTER_LANCZOS4 ||
-      (base == IPA_INTER_CUBIC_CV && a.src_dt == IPA_U8 && a.dst_dt == IPA_U8)) {
+  p.tab2d = nullptr;
+  const bool u8_cubic_tab = base == IPA_INTER_CUBIC_CV && a.src_dt == IPA_U8 && a.dst_dt == IPA_U8;
+  if (u8_cubic_tab) {
+    rc = ipa_u8_cubic_tab2d(ctx, &p.tab2d);
+    if (rc) return rc;
+  }
+  if (base == IPA_INTER_LANCZOS4) {
     rc = ipa_lanczos_table(ctx, &p.lanczos);
     if (rc) return rc;
   }
@@ -421,6 +441,12 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   p.skip = nullptr;
   p.tile_rows = 1;
+  if (u8_cubic_tab) {
+    // the 32 KB table is staged per workgroup: 16 row groups (64 rows x 256 px) each
+    p.tile_rows = 16;
+    p.tiles = p.tiles_x * ((tiles_y + p.tile_rows - 1) / p.tile_rows);
+    grid = inner ? dim3(p.tiles * (unsigned)a.n_frames, 1) : dim3(p.tiles, (unsigned)a.n_frames);
+  }
   // batches of float32 frames: the clean strips on the ring kernel (taps from LDS), the rest
   // below behind the skip mask
   // (ring_remap = 1: where it measured faster - 16 x 4K frames, gather -> ring + rest (+ plan):

@@ -699,6 +699,61 @@ __device__ __forceinline__ uint8_t sample_u8_tab(const SrcView& s, C sx, C sy, u
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
 }
 
+// The same for bicubic with the 1024 x 16 short weights of OpenCV's table resident in LDS
+// (tab2d: row fy * 32 + fx = 8 dwords {w0 | w2 << 16, w1 | w3 << 16} per tap row): two 16-byte LDS
+// reads and 8 v_dot2_i32_i16 per sample instead of forming 16 weights (the formed-per-sample
+// version is VALU-bound at 184 instructions per sample).
+typedef short v2s __attribute__((ext_vector_type(2)));
+template <typename C>
+__device__ __forceinline__ uint8_t sample_u8_cubic_lds(const SrcView& s, const int4* tab2d, C sx,
+                                                       C sy, uint8_t cv8) {
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cv8;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
+  const int ix0 = (qx >> 5) - 1, iy0 = (qy >> 5) - 1;
+  if (s.border == IPA_BORDER_CONSTANT && (ix0 >= s.w || ix0 + 4 <= 0 || iy0 >= s.h || iy0 + 4 <= 0))
+    return cv8;  // whole footprint outside
+  const int4* wrow = tab2d + ((((qy & 31) << 5) | (qx & 31)) << 1);
+  const int4 wa = wrow[0], wb = wrow[1];
+  const int wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+  unsigned taps[4];
+  if (ix0 >= 0 && iy0 >= 0 && ix0 + 4 <= s.w && iy0 + 4 <= s.h) {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      taps[r] = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (iy0 + r) * s.pitch + ix0, 0, 0);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int yy = resolve_idx(iy0 + r, s.h, s.border);
+      unsigned t = 0;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const int xx = resolve_idx(ix0 + c, s.w, s.border);
+        const unsigned b = (yy < 0 || xx < 0) ? (unsigned)cv8
+                                              : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(
+                                                    s.rsrc, yy * s.pitch + xx, 0, 0) & 0xffu;
+        t |= b << (8 * c);
+      }
+      taps[r] = t;
+    }
+  }
+  int acc = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const unsigned even = taps[r] & 0x00ff00ffu, odd = (taps[r] >> 8) & 0x00ff00ffu;
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, even), __builtin_bit_cast(v2s, wv[2 * r]), acc,
+                                 false);
+    acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, odd), __builtin_bit_cast(v2s, wv[2 * r + 1]),
+                                 acc, false);
+  }
+  const int o = (acc + (1 << 14)) >> 15;
+  return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
 // ------------------------------------------------------- coordinate sources --
 // Each provides  coord_t  and  get(u, v, sx, sy)  for destination pixel (u,v).
 
