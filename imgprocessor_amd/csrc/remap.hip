@@ -147,6 +147,59 @@ int ipa_u8_cubic_tab2d(ipa_ctx* ctx, const int** out) {
   return IPA_OK;
 }
 
+// The same table for Lanczos4: per fraction pair 8 x 8 shorts = 32 dwords, per tap row
+// {w0 | w2 << 16, w1 | w3 << 16, w4 | w6 << 16, w5 | w7 << 16}.  128 KB: remap_u8_lz_kernel keeps
+// it in the LDS of a 1024-thread workgroup.
+static int* g_lz2d_dev[64] = {};
+
+int ipa_u8_lanczos_tab2d(ipa_ctx* ctx, const int** out) {
+#pragma clang fp contract(off)
+  std::lock_guard<std::mutex> lk(g_lz_mu);
+  const int dev = ctx->device;
+  IPA_REQUIRE(ctx, dev >= 0 && dev < 64, "device id out of range");
+  if (!g_lz2d_dev[dev]) {
+    float t1[32][8];
+    for (int k = 0; k < 32; k++) lanczos4_row((float)k * (1.f / 32), t1[k]);
+    static int packed[1024 * 32];
+    for (int fy = 0; fy < 32; fy++)
+      for (int fx = 0; fx < 32; fx++) {
+        int itab[64], isum = 0;
+        for (int k1 = 0; k1 < 8; k1++) {
+          const float vy = t1[fy][k1];
+          for (int k2 = 0; k2 < 8; k2++) {
+            const float v = vy * t1[fx][k2];
+            isum += itab[k1 * 8 + k2] = sat_short_f(v * 32768.f);
+          }
+        }
+        if (isum != 32768) {
+          const int diff = isum - 32768;
+          int Mk1 = 4, Mk2 = 4, mk1 = 4, mk2 = 4;
+          for (int k1 = 4; k1 < 6; k1++)
+            for (int k2 = 4; k2 < 6; k2++) {
+              if (itab[k1 * 8 + k2] < itab[mk1 * 8 + mk2]) { mk1 = k1; mk2 = k2; }
+              else if (itab[k1 * 8 + k2] > itab[Mk1 * 8 + Mk2]) { Mk1 = k1; Mk2 = k2; }
+            }
+          if (diff < 0) itab[Mk1 * 8 + Mk2] = (short)(itab[Mk1 * 8 + Mk2] - diff);
+          else itab[mk1 * 8 + mk2] = (short)(itab[mk1 * 8 + mk2] - diff);
+        }
+        int* row = packed + (fy * 32 + fx) * 32;
+        for (int r = 0; r < 8; r++)
+          for (int q = 0; q < 2; q++) {
+            const int* w = itab + r * 8 + 4 * q;
+            row[r * 4 + q * 2 + 0] = (w[0] & 0xffff) | (int)((unsigned)w[2] << 16);
+            row[r * 4 + q * 2 + 1] = (w[1] & 0xffff) | (int)((unsigned)w[3] << 16);
+          }
+      }
+    int* d = nullptr;
+    IPA_HIP(ctx, hipSetDevice(dev));
+    IPA_HIP(ctx, hipMalloc((void**)&d, sizeof(packed)));
+    IPA_HIP(ctx, hipMemcpy(d, packed, sizeof(packed), hipMemcpyHostToDevice));
+    g_lz2d_dev[dev] = d;
+  }
+  *out = g_lz2d_dev[dev];
+  return IPA_OK;
+}
+
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border) {
   int base = interp & 0xff;
   IPA_REQUIRE(ctx, (interp & ~(0xff | IPA_INTER_Q5)) == 0, "unknown interpolation flags 0x%x",

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   constexpr bool kTabLds = FIXED && INTERP == kCubic;
   __shared__ __attribute__((aligned(16)))
   float lz_tab[kTabFixed ? 384 : (INTERP == kLanczos4 ? 256 : 4)];
-  __shared__ __attribute__((aligned(16))) int4 tab_lds[kTabLds ? 2048 : 1];
+  __shared__ __attribute__((aligned(16))) int4 tab_lds[kTabLds ? 1024 * kU8CubicRow : 1];
   if constexpr (INTERP == kLanczos4) {
     const unsigned tid = threadIdx.y * 64 + threadIdx.x;
     lz_tab[tid] = p.lanczos[tid];
@@ -136,7 +136,10 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
     const unsigned tid = threadIdx.y * 64 + threadIdx.x;
     const int4* gt = reinterpret_cast<const int4*>(p.tab2d);
 #pragma unroll
-    for (int i = 0; i < 8; i++) tab_lds[tid + 256u * i] = gt[tid + 256u * i];
+    for (int i = 0; i < 8; i++) {
+      const unsigned e = tid + 256u * i;
+      tab_lds[(e >> 1) * kU8CubicRow + (e & 1u)] = gt[e];
+    }
     __syncthreads();
   }
   SrcView s;
@@ -272,6 +275,7 @@ using namespace ipa;
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 int ipa_lanczos_table(ipa_ctx* ctx, const float** out);               // remap.hip
 int ipa_u8_cubic_tab2d(ipa_ctx* ctx, const int** out);                // remap.hip
+int ipa_u8_lanczos_tab2d(ipa_ctx* ctx, const int** out);              // remap.hip
 
 struct RemapCall {
   const void* src; int src_dt; int sh, sw; long spitch;
@@ -304,6 +308,66 @@ static void launch_interp(ipa_ctx* ctx, const RemapParams& p, const Coord& c, in
       hipLaunchKernelGGL((remap_kernel<ST, DT, kLanczos4, Coord, FIXED>), grid, block, 0,
                          ctx->stream, p, c);
       break;
+  }
+}
+
+// uint8 -> uint8 Lanczos4 (cv2.warpPerspective / remap on the camera's 8-bit frames, the default of
+// PerspectiveCorrection.correct, camera/PerspectiveCorrection.py:401-405): OpenCV's whole 8U weight
+// table (1024 fraction pairs x 64 shorts = 128 KB) in the LDS of a 1024-thread workgroup that works
+// on p.tile_rows groups of 16 rows x 256 px.  Full 256-px segments sample lane-interleaved (lane L
+// = pixels L + 64 k: the tap dwords of neighbouring lanes share cache lines) and go through a
+// wave-private byte row back to 4 pixels per lane for the store.
+template <typename Coord>
+__global__ void __launch_bounds__(1024) remap_u8_lz_kernel(RemapParams p, Coord coord) {
+  __shared__ __attribute__((aligned(16))) int4 tab[1024 * kU8LzRow];  // 147 KB
+  __shared__ __attribute__((aligned(16))) uint8_t xrow[16][256];
+  const unsigned tid = threadIdx.x;
+  {
+    const int4* gt = reinterpret_cast<const int4*>(p.tab2d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const unsigned e = tid + 1024u * i;  // int4 e of the packed table = row e / 8, part e % 8
+      tab[(e >> 3) * kU8LzRow + (e & 7u)] = gt[e];
+    }
+    __syncthreads();
+  }
+  const unsigned lane = tid & 63u, wave = tid >> 6;
+  const unsigned t = blockIdx.x, frame = blockIdx.y;
+  const unsigned tyb = t / p.tiles_x, txi = t - tyb * p.tiles_x;
+  SrcView s;
+  s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
+  s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
+  s.border = p.border; s.q5 = 1; s.cubic_a = p.cubic_a; s.lanczos = nullptr;
+  const double rv = rint(p.cval);
+  const uint8_t cv8 = (uint8_t)(rv > 0 ? (rv < 255 ? rv : 255) : 0);
+  const int xw = (int)(txi * 256u);
+  const bool whole = xw + 256 <= p.dw && p.dst_vec;
+  uint8_t* dst = reinterpret_cast<uint8_t*>(p.dst) + (long)frame * p.dst_frame_elems;
+  for (unsigned it = 0; it < p.tile_rows; it++) {
+    const int y = (int)((tyb * p.tile_rows + it) * 16u + wave);
+    if (y >= p.dh) return;
+    if (whole) {
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) {  // one sample at a time: 16 tap dwords + 32 weight dwords live
+        typename Coord::coord_t sx, sy;
+        coord.get(xw + (int)lane + 64 * k, y, sx, sy);
+        xrow[wave][64u * k + lane] = sample_u8_lanczos_lds(s, tab, sx, sy, cv8);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const unsigned q = *reinterpret_cast<const unsigned*>(&xrow[wave][4u * lane]);
+      *reinterpret_cast<unsigned*>(dst + (long)y * p.dpitch + xw + 4u * lane) = q;
+      __builtin_amdgcn_wave_barrier();
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int x = xw + 4 * (int)lane + k;
+        if (x < p.dw) {
+          typename Coord::coord_t sx, sy;
+          coord.get(x, y, sx, sy);
+          dst[(long)y * p.dpitch + x] = sample_u8_lanczos_lds(s, tab, sx, sy, cv8);
+        }
+      }
+    }
   }
 }
 
@@ -419,6 +483,12 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
     rc = ipa_u8_cubic_tab2d(ctx, &p.tab2d);
     if (rc) return rc;
   }
+  const bool u8_lz_tab = base == IPA_INTER_LANCZOS4 && a.src_dt == IPA_U8 && a.dst_dt == IPA_U8 &&
+                         ctx->tune.u8_lz_lds;
+  if (u8_lz_tab) {
+    rc = ipa_u8_lanczos_tab2d(ctx, &p.tab2d);
+    if (rc) return rc;
+  }
   if (base == IPA_INTER_LANCZOS4) {
     rc = ipa_lanczos_table(ctx, &p.lanczos);
     if (rc) return rc;
@@ -468,6 +538,15 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
     }
   }
 
+  if (u8_lz_tab) {
+    // 16 rows per pass and workgroup, 8 passes: 128 rows x 256 px per staging of the table
+    p.tile_rows = 8;
+    const unsigned bands = ((unsigned)a.dh + 16u * p.tile_rows - 1u) / (16u * p.tile_rows);
+    hipLaunchKernelGGL((remap_u8_lz_kernel<Coord>), dim3(p.tiles_x * bands, (unsigned)a.n_frames),
+                       dim3(1024), 0, ctx->stream, p, coord);
+    IPA_HIP(ctx, hipGetLastError());
+    return IPA_OK;
+  }
   int s = a.src_dt, d = a.dst_dt;
   if (p.skip) {
     launch_rest<Coord>(ctx, p, coord, base, grid);

@@ -72,6 +72,7 @@ const TuneName kTuneNames[] = {
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"ring_big", "IPA_RING_BIG", &ipa_tuning::ring_big},
     {"pair", "IPA_PAIR", &ipa_tuning::pair},
+    {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };
 }  // namespace
 

@@ -562,6 +562,9 @@ template <int INTERP> struct batch_of { static constexpr int value = 4; };
 template <> struct batch_of<kCubic> { static constexpr int value = 2; };
 template <> struct batch_of<kLanczos4> { static constexpr int value = 1; };
 
+#ifndef IPA_U8_LZ_PLAIN
+#define IPA_U8_LZ_PLAIN 0
+#endif
 // cv2's uint8 bilinear: q5 coordinates, exact 15-bit integer weights
 // ((32-fx)(32-fy)*32 ...), rounded shift.  Integer arithmetic: bit-exact.
 template <typename C>
@@ -704,6 +707,10 @@ __device__ __forceinline__ uint8_t sample_u8_tab(const SrcView& s, C sx, C sy, u
 // reads and 8 v_dot2_i32_i16 per sample instead of forming 16 weights (the formed-per-sample
 // version is VALU-bound at 184 instructions per sample).
 typedef short v2s __attribute__((ext_vector_type(2)));
+#ifndef IPA_U8_CUBIC_ROW
+#define IPA_U8_CUBIC_ROW 2
+#endif
+constexpr int kU8CubicRow = IPA_U8_CUBIC_ROW;  // int4 per fraction pair in LDS (2 used)
 template <typename C>
 __device__ __forceinline__ uint8_t sample_u8_cubic_lds(const SrcView& s, const int4* tab2d, C sx,
                                                        C sy, uint8_t cv8) {
@@ -717,7 +724,7 @@ __device__ __forceinline__ uint8_t sample_u8_cubic_lds(const SrcView& s, const i
   const int ix0 = (qx >> 5) - 1, iy0 = (qy >> 5) - 1;
   if (s.border == IPA_BORDER_CONSTANT && (ix0 >= s.w || ix0 + 4 <= 0 || iy0 >= s.h || iy0 + 4 <= 0))
     return cv8;  // whole footprint outside
-  const int4* wrow = tab2d + ((((qy & 31) << 5) | (qx & 31)) << 1);
+  const int4* wrow = tab2d + (((qy & 31) << 5) | (qx & 31)) * kU8CubicRow;
   const int4 wa = wrow[0], wb = wrow[1];
   const int wv[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
   unsigned taps[4];
@@ -749,6 +756,82 @@ __device__ __forceinline__ uint8_t sample_u8_cubic_lds(const SrcView& s, const i
                                  false);
     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, odd), __builtin_bit_cast(v2s, wv[2 * r + 1]),
                                  acc, false);
+  }
+  const int o = (acc + (1 << 14)) >> 15;
+  return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+
+// uint8 Lanczos4 with OpenCV's 1024 x 64 short weights resident in LDS (remap_u8_lz_kernel: 128 KB,
+// row fy * 32 + fx = 8 int4, one per tap row): eight 16-byte LDS reads, 16 tap dwords and 32
+// v_dot2_i32_i16 per sample instead of forming 64 weights.
+constexpr int kU8LzRow = 9;  // int4 per fraction pair in LDS
+template <typename C>
+__device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const int4* tab2d, C sx,
+                                                         C sy, uint8_t cv8) {
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cv8;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
+  const int ix0 = (qx >> 5) - 3, iy0 = (qy >> 5) - 3;
+  if (s.border == IPA_BORDER_CONSTANT && (ix0 >= s.w || ix0 + 8 <= 0 || iy0 >= s.h || iy0 + 8 <= 0))
+    return cv8;  // whole footprint outside
+  // rows of the LDS table are 9 int4 apart (8 used): fraction pairs then start on 16 different
+  // bank groups instead of 2
+  const int4* wrow = tab2d + (((qy & 31) << 5) | (qx & 31)) * kU8LzRow;
+  unsigned taps[8][2];
+  if (ix0 >= 0 && iy0 >= 0 && ix0 + 8 <= s.w && iy0 + 8 <= s.h) {
+    // three ALIGNED dwords per tap row, shifted into place (v_alignbyte_b32): a dword gather at
+    // an odd byte offset costs the texture addresser several times an aligned one
+    const int sh = ix0 & 3;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int a = (iy0 + r) * s.pitch + (ix0 & ~3);
+#if IPA_U8_LZ_PLAIN
+      taps[r][0] = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + sh, 0, 0);
+      taps[r][1] = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + sh + 4, 0, 0);
+      continue;
+#endif
+      const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a, 0, 0);
+      const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 4, 0, 0);
+      const unsigned d2 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 8, 0, 0);
+      taps[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      taps[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const int yy = resolve_idx(iy0 + r, s.h, s.border);
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        unsigned t = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int xx = resolve_idx(ix0 + 4 * q + c, s.w, s.border);
+          const unsigned b = (yy < 0 || xx < 0) ? (unsigned)cv8
+                                                : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(
+                                                      s.rsrc, yy * s.pitch + xx, 0, 0) & 0xffu;
+          t |= b << (8 * c);
+        }
+        taps[r][q] = t;
+      }
+    }
+  }
+  int acc = 0;
+#pragma unroll
+  for (int r = 0; r < 8; r++) {
+    const int4 wq = wrow[r];
+    const int wv[4] = {wq.x, wq.y, wq.z, wq.w};
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const unsigned even = taps[r][q] & 0x00ff00ffu, odd = (taps[r][q] >> 8) & 0x00ff00ffu;
+      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, even), __builtin_bit_cast(v2s, wv[2 * q]), acc,
+                                   false);
+      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, odd), __builtin_bit_cast(v2s, wv[2 * q + 1]),
+                                   acc, false);
+    }
   }
   const int o = (acc + (1 << 14)) >> 15;
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
