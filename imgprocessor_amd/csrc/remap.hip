@@ -186,8 +186,8 @@ int ipa_u8_lanczos_tab2d(ipa_ctx* ctx, const int** out) {
         for (int r = 0; r < 8; r++)
           for (int q = 0; q < 2; q++) {
             const int* w = itab + r * 8 + 4 * q;
-            row[r * 4 + q * 2 + 0] = (w[0] & 0xffff) | (int)((unsigned)w[2] << 16);
-            row[r * 4 + q * 2 + 1] = (w[1] & 0xffff) | (int)((unsigned)w[3] << 16);
+            row[r * 4 + q * 2 + 0] = (w[0] & 0xffff) | (int)((unsigned)w[1] << 16);
+            row[r * 4 + q * 2 + 1] = (w[2] & 0xffff) | (int)((unsigned)w[3] << 16);
           }
       }
     int* d = nullptr;

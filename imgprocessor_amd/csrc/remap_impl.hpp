@@ -332,7 +332,9 @@ __global__ void __launch_bounds__(1024) remap_u8_lz_kernel(RemapParams p, Coord 
     __syncthreads();
   }
   const unsigned lane = tid & 63u, wave = tid >> 6;
-  const unsigned t = blockIdx.x, frame = blockIdx.y;
+  // the frames of a tile are neighbours in the grid: their workgroups read the tile's map rows
+  // at about the same time (placing them on one XCD as well measured the same)
+  const unsigned nf = (unsigned)p.frames_inner, t = blockIdx.x / nf, frame = blockIdx.x - t * nf;
   const unsigned tyb = t / p.tiles_x, txi = t - tyb * p.tiles_x;
   SrcView s;
   s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
@@ -541,8 +543,9 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   if (u8_lz_tab) {
     // 16 rows per pass and workgroup, 8 passes: 128 rows x 256 px per staging of the table
     p.tile_rows = 8;
+    p.frames_inner = a.n_frames;
     const unsigned bands = ((unsigned)a.dh + 16u * p.tile_rows - 1u) / (16u * p.tile_rows);
-    hipLaunchKernelGGL((remap_u8_lz_kernel<Coord>), dim3(p.tiles_x * bands, (unsigned)a.n_frames),
+    hipLaunchKernelGGL((remap_u8_lz_kernel<Coord>), dim3(p.tiles_x * bands * (unsigned)a.n_frames),
                        dim3(1024), 0, ctx->stream, p, coord);
     IPA_HIP(ctx, hipGetLastError());
     return IPA_OK;

@@ -562,9 +562,6 @@ template <int INTERP> struct batch_of { static constexpr int value = 4; };
 template <> struct batch_of<kCubic> { static constexpr int value = 2; };
 template <> struct batch_of<kLanczos4> { static constexpr int value = 1; };
 
-#ifndef IPA_U8_LZ_PLAIN
-#define IPA_U8_LZ_PLAIN 0
-#endif
 // cv2's uint8 bilinear: q5 coordinates, exact 15-bit integer weights
 // ((32-fx)(32-fy)*32 ...), rounded shift.  Integer arithmetic: bit-exact.
 template <typename C>
@@ -781,24 +778,24 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
   // rows of the LDS table are 9 int4 apart (8 used): fraction pairs then start on 16 different
   // bank groups instead of 2
   const int4* wrow = tab2d + (((qy & 31) << 5) | (qx & 31)) * kU8LzRow;
-  unsigned taps[8][2];
+  // pr[r][j] = taps 2j, 2j+1 of row r as two 16-bit lanes (the table packs its shorts the same way)
+  unsigned pr[8][4];
   if (ix0 >= 0 && iy0 >= 0 && ix0 + 8 <= s.w && iy0 + 8 <= s.h) {
-    // three ALIGNED dwords per tap row, shifted into place (v_alignbyte_b32): a dword gather at
-    // an odd byte offset costs the texture addresser several times an aligned one
-    const int sh = ix0 & 3;
+    // three ALIGNED dwords per tap row (two dwords at the sample's odd byte offset cost the
+    // texture addresser a third more); one v_perm_b32 per tap pair picks bytes sh + 2j, sh + 2j + 1
+    // out of two of them and widens them to 16 bits
+    const unsigned sh = (unsigned)ix0 & 3u;
+    const unsigned sel01 = 0x0c010c00u + sh * 0x00010001u, sel23 = sel01 + 0x00020002u;
 #pragma unroll
     for (int r = 0; r < 8; r++) {
       const int a = (iy0 + r) * s.pitch + (ix0 & ~3);
-#if IPA_U8_LZ_PLAIN
-      taps[r][0] = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + sh, 0, 0);
-      taps[r][1] = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + sh + 4, 0, 0);
-      continue;
-#endif
       const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a, 0, 0);
       const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 4, 0, 0);
       const unsigned d2 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 8, 0, 0);
-      taps[r][0] = __builtin_amdgcn_alignbyte(d1, d0, sh);
-      taps[r][1] = __builtin_amdgcn_alignbyte(d2, d1, sh);
+      pr[r][0] = __builtin_amdgcn_perm(d1, d0, sel01);
+      pr[r][1] = __builtin_amdgcn_perm(d1, d0, sel23);
+      pr[r][2] = __builtin_amdgcn_perm(d2, d1, sel01);
+      pr[r][3] = __builtin_amdgcn_perm(d2, d1, sel23);
     }
   } else {
 #pragma unroll
@@ -815,7 +812,8 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
                                                       s.rsrc, yy * s.pitch + xx, 0, 0) & 0xffu;
           t |= b << (8 * c);
         }
-        taps[r][q] = t;
+        pr[r][2 * q] = (t & 0xffu) | ((t & 0xff00u) << 8);
+        pr[r][2 * q + 1] = ((t >> 16) & 0xffu) | ((t >> 24) << 16);
       }
     }
   }
@@ -825,13 +823,9 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
     const int4 wq = wrow[r];
     const int wv[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-      const unsigned even = taps[r][q] & 0x00ff00ffu, odd = (taps[r][q] >> 8) & 0x00ff00ffu;
-      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, even), __builtin_bit_cast(v2s, wv[2 * q]), acc,
+    for (int j = 0; j < 4; j++)
+      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, pr[r][j]), __builtin_bit_cast(v2s, wv[j]), acc,
                                    false);
-      acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, odd), __builtin_bit_cast(v2s, wv[2 * q + 1]),
-                                   acc, false);
-    }
   }
   const int o = (acc + (1 << 14)) >> 15;
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
