@@ -207,7 +207,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
                budget_launches // 2, 3)
     entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
-          ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weights, formed per sample (integer-exact)")
+          ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weight table resident in LDS (integer-exact)")
     del u8, d8
 
     # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here
