@@ -151,6 +151,42 @@ def test_remap_uint8_bit_exact(ia, oracle):
             assert got.dtype == np.uint8 and np.array_equal(got, want), (iname, bname)
 
 
+def test_uint8_tables_on_edge_shapes(ia, oracle):
+    """the uint8 table kernels (bicubic / Lanczos4 weights in LDS, aligned tap dwords) on shapes
+    that leave every fast path: sources smaller than a footprint, destination widths that are not
+    multiples of 4 / 256, odd pitches, several frames, coordinates far outside, NaN coordinates"""
+    rng = np.random.default_rng(77)
+    borders = (('constant', oracle.CONSTANT), ('replicate', oracle.REPLICATE),
+               ('reflect', oracle.REFLECT), ('wrap', oracle.WRAP),
+               ('reflect101', oracle.REFLECT101))
+    interps = (('cubic_cv', oracle.CUBIC_CV), ('lanczos4', oracle.LANCZOS4),
+               ('linear_cv_q5', oracle.LINEAR | oracle.Q5))
+    shapes = (((3, 5), (7, 9)), ((8, 8), (8, 8)), ((9, 257), (9, 257)), ((33, 261), (40, 515)),
+              ((130, 513), (129, 1031)), ((21, 1023), (17, 256)), ((6, 2), (5, 300)))
+    for (h, w), (dh, dw) in shapes:
+        n = 3
+        src = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+        yy, xx = np.mgrid[0:dh, 0:dw].astype(np.float64)
+        mx = (xx * (w / dw) * 1.07 - 2.3 + 1.5 * np.sin(yy / 5.0)).astype(np.float32)
+        my = (yy * (h / dh) * 1.05 - 1.9 + 1.5 * np.cos(xx / 9.0)).astype(np.float32)
+        mx[0, 0] = np.nan
+        my[-1, -1] = 1e9
+        mx[dh // 2, dw // 2] = -1e7
+        for (iname, iid) in interps:
+            for (bname, bid) in borders:
+                got = ia.ops.remap(src, mx, my, iname, bname, 7.0)
+                for f in range(n):
+                    want = oracle.remap(src[f], mx, my, iid, bid, 7.0)
+                    assert np.array_equal(got[f], want), (h, w, dh, dw, iname, bname, f)
+        # the homography's double coordinates through the same kernels
+        M = np.array([[w / dw * 0.97, 0.02, -0.6], [-0.015, h / dh * 1.03, 0.4], [1e-5, -2e-5, 1.0]])
+        for (iname, iid) in interps[:2]:
+            got = ia.ops.warp_perspective(src, M, (dh, dw), iname, 'reflect')
+            for f in range(n):
+                want = oracle.warp_perspective(src[f], M, (dh, dw), iid, oracle.REFLECT)
+                assert np.array_equal(got[f], want), (h, w, dh, dw, iname, f)
+
+
 def test_known_answers(ia):
     rng = np.random.default_rng(5)
     img = rng.random((33, 47)).astype(np.float32)
