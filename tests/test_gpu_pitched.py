@@ -58,6 +58,33 @@ def test_remap_with_pitches(ia, interp, tune, odd):
 
 
 @pytest.mark.parametrize('odd', [0, 1])
+@pytest.mark.parametrize('interp', ['linear', 'linear_cv_q5', 'cubic_cv', 'lanczos4'])
+def test_uint8_remap_with_pitches(ia, interp, odd):
+    """the uint8 kernels (fixed-point bilinear, bicubic / Lanczos4 tables in LDS) on regions of
+    larger byte buffers: row pitches at any byte alignment, frame strides larger than a frame"""
+    from imgprocessor_amd import ops
+    from imgprocessor_amd.device import dtype_id
+    ctx = ia.default_context(0)
+    n, h, w = 3, 150, 777
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, 256, (n, h, w), dtype=np.uint8)
+    mx, my, _, _ = radial_maps(h, w)
+    want = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), interp, 'reflect').get()
+    sp, dp, mp = w + 23 + odd, w + 8 + 3 * odd, w + 12 + odd
+    sbig = ctx.to_device(_embed(src, sp - w, 5, 7))
+    mbx = ctx.to_device(_embed(mx[None], mp - w, 0, -1e9)[0])
+    mby = ctx.to_device(_embed(my[None], mp - w, 0, -1e9)[0])
+    dbig = ctx.to_device(np.full((n, h + 3, dp), 99, np.uint8))
+    ctx._check(ctx._lib.ipa_remap_dev(
+        ctx.handle, sbig.ptr, dtype_id(np.uint8), h, w, sp, mbx.ptr, mby.ptr, mp, dbig.ptr,
+        dtype_id(np.uint8), h, w, dp, n, (h + 5) * sp, (h + 3) * dp, ops.interp_id(interp),
+        ops.border_id('reflect'), 0.0), 'remap')
+    got = dbig.get()
+    assert np.array_equal(got[:, :h, :w], want), 'pitched uint8 remap ' + interp
+    assert (got[:, h:, :] == 99).all() and (got[:, :, w:] == 99).all(), 'wrote outside'
+
+
+@pytest.mark.parametrize('odd', [0, 1])
 @pytest.mark.parametrize('K', [5, 9])
 @pytest.mark.parametrize('tune', [dict(), dict(pair=1), dict(ring=1), dict(ring_big=2)])
 def test_remap_conv_with_pitches(ia, K, tune, odd):
