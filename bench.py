@@ -400,6 +400,10 @@ def main():
         value = world * px * args.steps / el / 1e6
         step_s = ev_ms * 1e-3 / args.steps
         ach = compulsory / step_s / 1e9
+        # what a plain device copy of the same buffers reaches in this run (read + write): the
+        # practical ceiling of a streaming kernel on this box, next to the 8 TB/s of the guide
+        copy_ms = timed(ctx, lambda: d_dst.copy_from(d_src), 20, 3)
+        copy_gbs = 2.0 * d_src.nbytes / (copy_ms * 1e-3) / 1e9
         traffic, traffic_src = pmc_traffic(args.variant, B, h, w)
         line = {
             'metric': 'Mpix/s undistort+5x5 filter, 4K f32',
@@ -434,7 +438,13 @@ def main():
                              'frac': round(literal_px * px / step_s / 1e9 / HBM_PEAK_GBS, 4),
                              'note': 'charges the map pair to every frame; NOT the roofline '
                                      'fraction'},
-                         'no_settle_frac': round(compulsory / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                         'no_settle_frac': round(compulsory / (ns_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         'device_copy': {
+                             'achieved': round(copy_gbs, 1), 'unit': 'GB/s',
+                             'kernel_vs_copy': round(ach / copy_gbs, 4),
+                             'note': 'hipMemcpyAsync device-to-device of the source batch into '
+                                     'the result batch in this run, read + write bytes; context '
+                                     'for `peak`, not a substitute for it'}},
         }
         if world == 1 and not args.no_configs and (h, w) == (H4K, W4K):
             del d_src, d_dst, d_tmp
