@@ -428,8 +428,9 @@ def main():
                          'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
                          'compulsory_bytes_per_step': compulsory,
-                         'limiter': 'vector-memory front end of the CU (texture addresser busy '
-                                    '~80 %), not HBM: DESIGN.md section 5',
+                         'limiter': 'vector-memory path of the CU, not HBM: texture addresser busy '
+                                    '74 %, and a wave\'s map loads, gathers and stores complete '
+                                    'one after the other (DESIGN.md section 5)',
                          'kernel': kname, 'launches_per_step': launches,
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
                          'literal_survey_8d': {
