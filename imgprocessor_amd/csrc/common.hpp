@@ -28,7 +28,8 @@ struct ipa_tuning {
   int ring_min = 2;
   int ring_ablate = 0;    // measurement only: parts of the ring kernel switched off (wrong results)
   int u8_lz_lds = 1;      // uint8 Lanczos4: OpenCV's 128 KB weight table in LDS (0: weights formed per sample)
-  int pair = 0;           // fused bilinear map remap + 3x3 / 5x5 of batches: one wave per frame PAIR
+  int pair = 0;           // fused bilinear map remap + 3x3 / 5x5 of batches: 1 = one wave per frame PAIR
+                          // (wave_pair.hpp), 2 = sampler wave + filter wave per strip (wave_split.hpp)
   int ring_big = 0;       // batches, 7x7..11x11 after a remap in one kernel with the taps in LDS (1: bicubic, 2: all; measured slower)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always

@@ -99,6 +99,7 @@ struct WaveParams {
   int frames_inner;    // 0: grid.y = frame; n: 1-D grid, frame index fastest (see the kernel)
   // strips another kernel computes (ring_stencil.hpp): skip[strip] != 0 -> nothing to do here
   const unsigned* skip = nullptr;
+  int rim_only = 0;    // 1: the interior (FAST) strips belong to another kernel (wave_split.hpp)
 };
 
 // grid for a launch over n_frames; fills p.frames_inner
@@ -536,6 +537,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   const bool fast = src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
                     y0 - G::H >= 0 &&
                     y0 - G::H + rows_touched <= p.dh;
+  if (fast && p.rim_only) return;
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;

@@ -193,8 +193,10 @@ def test_group_4k_strip_geometry(ia, oracle):
 
 @pytest.mark.parametrize('n', [2, 3, 5, 8])
 @pytest.mark.parametrize('K', [3, 5])
-def test_frame_pair_kernel_matches_per_frame(ia, K, n):
-    """one wave per strip of a frame PAIR (csrc/wave_pair.hpp): the bits of the per-frame kernel"""
+@pytest.mark.parametrize('knob', [1, 2])
+def test_frame_pair_kernel_matches_per_frame(ia, K, n, knob):
+    """one wave per strip of a frame PAIR (csrc/wave_pair.hpp, pair=1) and a sampler wave + a filter
+    wave per strip (csrc/wave_split.hpp, pair=2): the bits of the per-frame kernel"""
     from imgprocessor_amd import ops
     ctx = ia.default_context(0)
     for (h, w), q5 in (((200, 1030), False), ((131, 517), True), ((330, 780), False)):
@@ -208,8 +210,8 @@ def test_frame_pair_kernel_matches_per_frame(ia, K, n):
             old = ctx.set_tuning(pair=0, ring=0, group=0)
             try:
                 ref = ops.remap_conv2d(d_src, dmx, dmy, kern(K), interp, **kw).get()
-                ctx.set_tuning(pair=1)
+                ctx.set_tuning(pair=knob)
                 got = ops.remap_conv2d(d_src, dmx, dmy, kern(K), interp, **kw).get()
             finally:
                 ctx.set_tuning(**old)
-            same_bits(got, ref, 'pair kernel K=%d n=%d %r %r' % (K, n, (h, w), kw))
+            same_bits(got, ref, 'pair=%d kernel K=%d n=%d %r %r' % (knob, K, n, (h, w), kw))

@@ -37,8 +37,10 @@ def main():
     k5 = np.outer(g, g)
     dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
     rng = np.random.default_rng(0)
-    variants = [('per-frame', dict(group=0, ring=0)),
-                ('ring+per-frame', dict(group=0, ring=1))]
+    variants = [('per-frame', dict(group=0, ring=0, pair=0)),
+                ('sampler+filter', dict(group=0, ring=0, pair=2))]
+    if os.environ.get('AB_RING'):
+        variants += [('ring+per-frame', dict(group=0, ring=1, pair=0))]
     if os.environ.get('AB_GROUP'):
         variants += [('group/gather', dict(group=1, ring=0, group_ring=0)),
                      ('group/ring', dict(group=1, ring=0, group_ring=1))]
