@@ -70,6 +70,7 @@ const TuneName kTuneNames[] = {
     {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
+    {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"ring_big", "IPA_RING_BIG", &ipa_tuning::ring_big},
     {"pair", "IPA_PAIR", &ipa_tuning::pair},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},

@@ -131,6 +131,10 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& s
   }
 }
 
+template <typename Src> struct sep_shares_maps : std::false_type {};
+template <typename ST, int I, typename Coord>
+struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> : coord_is_table<Coord> {};
+
 template <typename Src, int K>
 __global__ void __launch_bounds__(256)
 wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
@@ -145,7 +149,13 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     b /= (unsigned)p.frames_inner;
   }
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // scalar
-  const unsigned sid = b * 4 + wave;
+  unsigned sid = b * 4 + wave;
+  if (p.frames_wg) {  // the waves of a workgroup are 4 frames of one strip (WaveParams::frames_wg)
+    const unsigned groups = (unsigned)p.frames_inner / 4u;
+    b = xcd_swizzle(blockIdx.x, gridDim.x);
+    frame = (b % groups) * 4u + wave;
+    sid = b / groups;
+  }
   float* xp = xpose + (kRegs ? 0 : wave * kRowStride * D);
   if (sid >= p.strips) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
@@ -191,7 +201,7 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
   p.strips_x = (p.dw + 247) / 248;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid = wave_grid(ctx, p, n_frames, 4, true), block(256);
+  dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 

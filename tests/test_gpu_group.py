@@ -191,6 +191,32 @@ def test_group_4k_strip_geometry(ia, oracle):
     assert_close(ring[4][sub], want[sub], 1e-5, 1e-5 * np.abs(want).max(), '4K vs oracle')
 
 
+@pytest.mark.parametrize('n', [4, 8, 12])
+@pytest.mark.parametrize('K', [3, 5, 7, 9, 11])
+def test_frames_of_a_strip_in_one_workgroup(ia, K, n):
+    """WaveParams::frames_wg (the waves of a workgroup = consecutive frames of one strip, map-based
+    fused kernels): the bits of the strip-per-wave order, dense and separable chains"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    for (h, w) in ((200, 1030), (131, 517)):
+        src = frames(n, h, w)
+        mx, my, _, _ = radial_maps(h, w)
+        d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+        g = kern(K)[K // 2].copy()
+        g /= g.sum()
+        res = []
+        for knob in (0, 1):
+            old = ctx.set_tuning(frames_wg=knob, pair=0, ring=0, group=0)
+            try:
+                res.append((ops.remap_conv2d(d_src, dmx, dmy, kern(K)).get(),
+                            ops.remap_sepconv2d(d_src, dmx, dmy, g, g).get() if K <= 9 else None))
+            finally:
+                ctx.set_tuning(**old)
+        same_bits(res[1][0], res[0][0], 'frames_wg dense K=%d n=%d %r' % (K, n, (h, w)))
+        if K <= 9:
+            same_bits(res[1][1], res[0][1], 'frames_wg separable K=%d n=%d %r' % (K, n, (h, w)))
+
+
 @pytest.mark.parametrize('n', [2, 3, 5, 8])
 @pytest.mark.parametrize('K', [3, 5])
 @pytest.mark.parametrize('knob', [1, 2])

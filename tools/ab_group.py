@@ -1,5 +1,7 @@
-"""A/B timing of the fused 4K headline on the per-frame kernel vs the frame-group kernel
-(gather records only / LDS ring), alternated inside one process.  GPU box only.
+"""A/B timing of the fused 4K headline on the per-frame kernel with the waves of a workgroup on four
+strips of a frame / on four frames of a strip (knob frames_wg); AB_SPLIT=1 adds the sampler + filter
+wave pair, AB_RING=1 the ring kernel, AB_GROUP=1 the frame-group kernel.  Alternated inside one
+process.  GPU box only.
 
     python tools/ab_group.py [batch ...]
 """
@@ -37,8 +39,10 @@ def main():
     k5 = np.outer(g, g)
     dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
     rng = np.random.default_rng(0)
-    variants = [('per-frame', dict(group=0, ring=0, pair=0)),
-                ('sampler+filter', dict(group=0, ring=0, pair=2))]
+    variants = [('strips in WG', dict(group=0, ring=0, pair=0, frames_wg=0)),
+                ('frames in WG', dict(group=0, ring=0, pair=0, frames_wg=1))]
+    if os.environ.get('AB_SPLIT'):
+        variants += [('sampler+filter', dict(group=0, ring=0, pair=2, frames_wg=0))]
     if os.environ.get('AB_RING'):
         variants += [('ring+per-frame', dict(group=0, ring=1, pair=0))]
     if os.environ.get('AB_GROUP'):
@@ -48,7 +52,7 @@ def main():
         src = ctx.to_device(rng.random((B, h, w), dtype=np.float32))
         dst = ctx.empty((B, h, w), np.float32)
         n = max(10, 1600 // B)
-        for rep in range(2):
+        for rep in range(4):
             for name, knobs in variants:
                 ctx.set_tuning(**knobs)
                 t = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst), n, n // 4)
