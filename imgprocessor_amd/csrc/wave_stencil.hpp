@@ -60,6 +60,10 @@
 #include "conv_tile.hpp"
 #include "sampler.hpp"
 
+#ifndef IPA_PIPE
+#define IPA_PIPE 1   // FAST strips on the hand-scheduled memory pipeline of wave_pipe.hpp
+#endif
+
 namespace ipa {
 
 // lane i <- lane i-1 (lane 0 keeps its own value)
@@ -152,8 +156,10 @@ struct LoadRowSrc {
 #ifndef IPA_K7_DEPTH
 #define IPA_K7_DEPTH 2
 #endif
+  // (with the hand-scheduled FAST path of wave_pipe.hpp the chunked loop only runs the rim
+  // strips of K <= 7: a shallow chunk keeps its registers and LDS rows out of the kernel's way)
   template <int K> struct depth {
-    static constexpr int value = K >= 7 ? IPA_K7_DEPTH : IPA_LOAD_DEPTH;
+    static constexpr int value = K >= 7 ? IPA_K7_DEPTH : (IPA_PIPE ? 2 : IPA_LOAD_DEPTH);
   };
   template <int D> struct Chunk { float v[D][4]; };
   const float* base;   // frame 0
@@ -208,8 +214,12 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #ifndef IPA_SAMPLE_DEPTH_BIG
 #define IPA_SAMPLE_DEPTH_BIG IPA_SAMPLE_DEPTH
 #endif
+    // float32 frames sampled bilinearly from a coordinate table run their FAST strips on
+    // wave_pipe.hpp for K <= 5 (K = 7 streams its coefficients: wave_stencil_big_kernel); the chunked loop is then the rim strips only: depth 1
+    static constexpr bool kPiped = IPA_PIPE && K <= 5 && INTERP == kLinear &&
+                                   std::is_same<ST, float>::value && coord_is_table<Coord>::value;
     static constexpr int value =
-        INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : IPA_SAMPLE_DEPTH) : 1;
+        INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kPiped ? 1 : IPA_SAMPLE_DEPTH)) : 1;
   };
   template <int D> struct Chunk { BatchTaps<ST, INTERP, 4> t[D]; };
 
@@ -225,9 +235,11 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
   float ccval;           // filter border value
   int map_vec;
   SrcView s;             // built by set_frame
+  const char* fbase;     // this wave's frame (set_frame)
 
   __device__ __forceinline__ void set_frame(unsigned f) {
-    s.rsrc = make_rsrc(src + (long)f * src_frame_bytes, src_bytes);
+    fbase = src + (long)f * src_frame_bytes;
+    s.rsrc = make_rsrc(fbase, src_bytes);
     s.h = sh; s.w = sw; s.pitch = spitch;
     s.border = border; s.q5 = q5; s.cubic_a = cubic_a; s.lanczos = lanczos;
     s.pair_split = 1;  // strips sample lane-interleaved
@@ -499,6 +511,10 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
   }
 }
 
+}  // namespace ipa
+#include "wave_pipe.hpp"  // FAST strips with a hand-scheduled memory pipeline (round 3)
+namespace ipa {
+
 #ifndef IPA_WAVE_MIN_WAVES
 #define IPA_WAVE_MIN_WAVES 1
 #endif
@@ -559,7 +575,14 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
-    if constexpr (Src::kHasQ5) {
+    if constexpr (IPA_PIPE && !STREAM && pipe_capable<Src, K>::value) {
+      if constexpr (Src::kHasQ5) {
+        if (src.q5) wave_run_strip_pipe<K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        else wave_run_strip_pipe<K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst);
+      } else {
+        wave_run_strip_pipe<K>(p, src, wts, xp, c, y0, nrows, writer, dst);
+      }
+    } else if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
       if (src.q5) wave_run_strip<true, Src, K, 1, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
       else wave_run_strip<true, Src, K, 0, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);

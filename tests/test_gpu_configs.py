@@ -347,12 +347,14 @@ def test_strip_geometry_sweep(ia, orc):
 
 def test_tall_strips_of_large_launches(ia, orc):
     """launches of many frames march in 48- and 72-row strips (wave_strip_height); the same
-    geometry forced on small frames through the library's IPA_STRIP_H knob, against the oracle"""
+    geometry forced on small frames through the context's strip_h knob, against the oracle"""
     ctx = ia.default_context(0)
     rng = np.random.default_rng(23)
+    old = ctx.set_tuning(strip_h=0)
     try:
         for sh in (48, 64, 72):
-            os.environ['IPA_STRIP_H'] = str(sh)
+            ctx.set_tuning(strip_h=sh)
+            assert ctx.get_tuning('strip_h') == sh
             for n, (h, w) in enumerate(((sh - 1, 249), (sh, 505), (sh + 1, 256), (2 * sh + 3, 760))):
                 img = synth((h, w), 70 + n)
                 ksz = {48: (3, 5, 7, 9), 64: (9, 11, 9, 11), 72: (7, 3, 5, 11)}[sh][n]
@@ -377,7 +379,8 @@ def test_tall_strips_of_large_launches(ia, orc):
                                                mode).get(),
                         orc.sepconv2d(want_r, g, g, mode), 'fused sep strip %d %dx%d' % (sh, h, w))
     finally:
-        os.environ.pop('IPA_STRIP_H', None)
+        ctx.set_tuning(**old)
+    assert ctx.get_tuning('strip_h') == old['strip_h']
 
 
 def test_big_kernels_on_the_marching_wave(ia, orc):

@@ -195,3 +195,28 @@ def test_c4_full_batch_every_frame(ia, orc):
         close32(got[i], want, 'C4 frame %d' % i)
         worst = max(worst, float(np.max(np.abs(got[i] - want) / np.maximum(np.abs(want), 1.0))))
     print('C4 64 frames: max relative error %.3g' % worst)
+
+
+def test_headline_64x4k_every_frame(ia, orc):
+    """the launch bench.py times - 64 x 4K float32, map-based undistort (bilinear, constant 0) +
+    5x5 Gaussian ('reflect'), default knobs, ONE launch - every frame against the oracle"""
+    import bench
+    h, w, n = bench.H4K, bench.W4K, 64
+    K, d = bench.camera(h, w)
+    k5 = bench.gauss5()
+    frames = bench.synth_frames(n, h, w)
+    ctx = ia.default_context(0)
+    assert ctx.get_tuning('strip_h') == 0 and ctx.get_tuning('frames_wg') == 1
+    dmx, dmy = ia.ops.build_undistort_map(K, d, K, h, w, device=True)
+    mx, my = dmx.get(), dmy.get()
+    got = ia.ops.remap_conv2d(ctx.to_device(frames), dmx, dmy, k5, 'linear', 'constant', 0.0,
+                              'reflect').get()
+    assert got.dtype == np.float32 and got.shape == (n, h, w)
+    worst = 0.0
+    for i in range(n):
+        want = orc.conv2d(orc.remap(frames[i], mx, my, orc.LINEAR, orc.CONSTANT, 0.0), k5,
+                          'reflect')
+        close32(got[i], want, 'headline frame %d' % i)
+        worst = max(worst, float(np.max(np.abs(got[i] - want)) / np.max(np.abs(want))))
+    print('headline 64 x 4K: max |err| / max |ref| = %.3g' % worst)
+    assert worst < 1e-5

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Static check of the hand-scheduled kernels (wave_pipe.hpp) in a gfx950 assembly file:
+no instruction may touch a register whose asm-issued load is still in flight, i.e. between the
+load (inside an ASMSTART/ASMEND block) and the `; pin` statement that releases it after a
+counted wait.  A forward "may be in flight" dataflow over the kernel's control-flow graph (basic
+blocks from the labels and branches of the assembly text), so loop back-edges and the branches
+around the border-aware sampler are followed.
+
+    tools/check_pipe_asm.py file.s [name filter ...]       exit 1 on a violation
+"""
+import re
+import sys
+
+REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def check(name, lines):
+    """forward may-be-in-flight dataflow over the kernel's control-flow graph"""
+    # --- instructions: (line no, kind, text, regs) with kind in load/pin/use/label/branch/end
+    ins, in_asm = [], False
+    cur_loop, parent, pending_label = None, {}, None   # innermost loop header of the current block
+    loop_of = []
+    for ln, l in lines:
+        t = l.strip()
+        # LLVM's block comments: "in Loop: Header=BB0_729 Depth=1", "=>This Loop Header: Depth=1",
+        # "Parent Loop BB0_729 Depth=1" + "=> This Inner Loop Header: Depth=2"
+        if re.match(r'^(\.LBB\d+_\d+):|^; %bb\.\d+:', t):
+            cur_loop = None
+            pending_label = re.match(r'^\.L(BB\d+_\d+):', t).group(1) if t.startswith('.') else None
+        mm = re.search(r'in Loop: Header=(BB\d+_\d+) Depth=(\d+)', t)
+        if mm:
+            cur_loop = mm.group(1)
+        if 'Loop Header: Depth=' in t and pending_label:
+            cur_loop = pending_label
+        mm = re.search(r'Parent Loop (BB\d+_\d+) Depth=(\d+)', t)
+        if mm and pending_label:
+            parent.setdefault(pending_label, mm.group(1))
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        m = re.match(r'^(\.LBB\d+_\d+):', t)
+        if m:
+            ins.append((ln, 'label', m.group(1), None)); loop_of.append(None)
+            continue
+        if in_asm and t.startswith('; pin'):
+            ins.append((ln, 'pin', t, regs_of(t))); loop_of.append(cur_loop)
+            continue
+        if not t or t.startswith((';', '.')):
+            continue
+        code = t.split(';')[0].strip()
+        op = code.split()[0]
+        if in_asm and op.startswith(('buffer_load', 'global_load')):
+            dst = code.split()[1].rstrip(',')
+            ins.append((ln, 'load', code, (regs_of(dst), regs_of(' '.join(code.split()[2:]))))); loop_of.append(cur_loop)
+        elif op == 's_endpgm':
+            ins.append((ln, 'end', code, None)); loop_of.append(cur_loop)
+        elif op == 's_branch' or op.startswith('s_cbranch'):
+            ins.append((ln, 'branch', code, (op == 's_branch', code.split()[-1]))); loop_of.append(cur_loop)
+        else:
+            ins.append((ln, 'use', code, regs_of(code))); loop_of.append(cur_loop)
+    # --- basic blocks
+    starts = {0}
+    for i, (ln, k, t, r) in enumerate(ins):
+        if k == 'label':
+            starts.add(i)
+        if k in ('branch', 'end') and i + 1 < len(ins):
+            starts.add(i + 1)
+    starts = sorted(starts)
+    block_of = {}
+    for bi, st in enumerate(starts):
+        en = starts[bi + 1] if bi + 1 < len(starts) else len(ins)
+        for i in range(st, en):
+            block_of[i] = bi
+    label_block = {ins[st][2]: bi for bi, st in enumerate(starts) if ins[st][1] == 'label'}
+    nb = len(starts)
+
+    def succ(bi):
+        st = starts[bi]
+        en = starts[bi + 1] if bi + 1 < nb else len(ins)
+        last = ins[en - 1]
+        out = []
+        if last[1] == 'end':
+            return out
+        if last[1] == 'branch':
+            uncond, tgt = last[3]
+            if tgt in label_block:
+                out.append(label_block[tgt])
+            if not uncond and bi + 1 < nb:
+                out.append(bi + 1)
+            return out
+        if bi + 1 < nb:
+            out.append(bi + 1)
+        return out
+
+    def transfer(bi, inset, report):
+        cur = dict(inset)
+        st = starts[bi]
+        en = starts[bi + 1] if bi + 1 < nb else len(ins)
+        for i in range(st, en):
+            ln, k, t, r = ins[i]
+            if k == 'load':
+                dst, addr = r
+                for x in addr:
+                    if x in cur and report is not None:
+                        report.append((ln, t, x, cur[x]))
+                for x in dst:
+                    cur[x] = ln
+            elif k == 'pin':
+                for x in r:
+                    cur.pop(x, None)
+            elif k == 'use':
+                if report is not None:
+                    for x in r:
+                        if x in cur:
+                            report.append((ln, t, x, cur[x]))
+        return cur
+
+    def outer(h):
+        seen_h = set()
+        while h in parent and h not in seen_h:
+            seen_h.add(h)
+            h = parent[h]
+        return h
+
+    def block_loop(bi):
+        st = starts[bi]
+        en = starts[bi + 1] if bi + 1 < nb else len(ins)
+        for i in range(st, en):
+            if loop_of[i] is not None:
+                return outer(loop_of[i])
+            if ins[i][1] == 'label' and i + 1 < en and loop_of[i + 1] is not None:
+                return outer(loop_of[i + 1])
+        return None
+
+    bloop = [block_loop(bi) for bi in range(nb)]
+    inn = [dict() for _ in range(nb)]
+    work = [0]
+    seen = {0}
+    while work:
+        bi = work.pop()
+        out = transfer(bi, inn[bi], None)
+        for sb in succ(bi):
+            # leaving the strip loop: the wave is done with its strip, nothing is used afterwards
+            # (the uniform if/else of the two coordinate rules is laid out as loop A -> Flow -> loop B)
+            if bloop[bi] is not None and bloop[sb] != bloop[bi]:
+                continue
+            merged = dict(inn[sb])
+            changed = sb not in seen
+            for x, ln in out.items():
+                if x not in merged:
+                    merged[x] = ln
+                    changed = True
+            if changed:
+                inn[sb] = merged
+                seen.add(sb)
+                work.append(sb)
+    bad = []
+    for bi in sorted(seen):
+        transfer(bi, inn[bi], bad)
+    nload = sum(1 for x in ins if x[1] == 'load')
+    npin = sum(1 for x in ins if x[1] == 'pin')
+    return bad, nload, npin
+
+
+def main():
+    s = open(sys.argv[1]).read().split('\n')
+    flts = sys.argv[2:]
+    rc = 0
+    i = 0
+    while i < len(s):
+        l = s[i]
+        if l.startswith('_Z') and l.split(';')[0].rstrip().endswith(':') and 'wave_stencil' in l:
+            name = l.split(':')[0]
+            j = i
+            while 's_endpgm' not in s[j]:
+                j += 1
+            if not flts or any(f in name for f in flts):
+                body = list(enumerate(s[i:j], i + 1))
+                if any('; pin' in x for _, x in body):
+                    bad, nload, npin = check(name, body)
+                    print('%s: %d asm loads, %d pins, %d violations'
+                          % (name[:100], nload, npin, len(bad)))
+                    for ln, t, r, src in bad[:20]:
+                        print('   line %d: v%d (loaded at line %d) may still be in flight: %s'
+                              % (ln, r, src, t))
+                    rc |= 1 if bad else 0
+            i = j
+        i += 1
+    sys.exit(rc)
+
+
+if __name__ == '__main__':
+    main()
