@@ -11,6 +11,9 @@ int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
+#ifndef IPA_EXPERIMENTAL
+#define IPA_EXPERIMENTAL 0   // make EXPERIMENTAL=1: the shelved round-2 batch kernels
+#endif
 // fused_group.hip: batches, one workgroup per strip of 4 frames; 1 = not covered
 int ipa_fused_group_launch(ipa_ctx*, const FusedCall&, int K, int use_ring);
 // fused_ring.hip: plans the strips, runs the clean ones on the ring kernel and sets f.p.skip for
@@ -97,6 +100,9 @@ static int ring_big_try(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
                         int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
                         long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
                         double border_value, int cbx, int cby) {
+#if !IPA_EXPERIMENTAL
+  return 1;
+#else
   if (!ctx->tune.ring_big || n_frames < ctx->tune.ring_min || kh != kw || !kernel ||
       !(kh == 7 || kh == 9 || kh == 11) || src_dtype != IPA_F32 || dst_dtype != IPA_F32)
     return 1;
@@ -113,6 +119,7 @@ static int ring_big_try(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   rc = ipa_fused_ring_big_launch(ctx, f, kh);
   if (rc == 0) IPA_HIP(ctx, hipGetLastError());
   return rc;
+#endif
 }
 
 static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
@@ -130,6 +137,7 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   if (rc) return rc;
   f.kernel = kernel;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
+#if IPA_EXPERIMENTAL
   if (ctx->tune.group && n_frames >= ctx->tune.group_min) {
     rc = ipa_fused_group_launch(ctx, f, kh, ctx->tune.group_ring);
     if (rc < 0) return rc;
@@ -150,6 +158,7 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
       return IPA_OK;
     }
   }
+#endif
   switch (kh) {
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;
     case 5: rc = ipa_fused_launch_k5(ctx, f); break;

@@ -77,10 +77,40 @@ const TuneName kTuneNames[] = {
 };
 }  // namespace
 
+#ifndef IPA_EXPERIMENTAL
+#define IPA_EXPERIMENTAL 0
+#endif
+// knobs of kernels that only exist in a `make EXPERIMENTAL=1` build
+static bool tune_is_experimental(const char* name) {
+  for (const char* n : {"group", "ring", "pair", "ring_big", "ring_ablate"})
+    if (strcmp(n, name) == 0) return true;
+  return false;
+}
+// accepted range of a knob (everything else is an error, not a silent launch-shape surprise)
+static bool tune_in_range(const char* name, int v) {
+  if (strcmp(name, "strip_h") == 0) return v >= 0 && v <= 4096;
+  if (strcmp(name, "stream_k") == 0) return v >= 7 && v <= 99;
+  if (strcmp(name, "ring_min") == 0 || strcmp(name, "group_min") == 0) return v >= 1;
+  if (strcmp(name, "ring_remap") == 0 || strcmp(name, "ring_big") == 0 ||
+      strcmp(name, "pair") == 0)
+    return v >= 0 && v <= 2;
+  if (strcmp(name, "ring_ablate") == 0) return v >= 0;
+  return v == 0 || v == 1;
+}
+
 int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return IPA_ERR_BAD_ARG;
   for (const TuneName& t : kTuneNames)
     if (strcmp(t.name, name) == 0) {
+      if (!tune_in_range(name, value)) {
+        ipa_set_error(ctx, "tuning knob '%s': value %d out of range", name, value);
+        return IPA_ERR_BAD_ARG;
+      }
+      if (!IPA_EXPERIMENTAL && value != 0 && tune_is_experimental(name)) {
+        ipa_set_error(ctx, "tuning knob '%s' selects a kernel this build does not carry "
+                           "(make EXPERIMENTAL=1)", name);
+        return IPA_ERR_UNSUPPORTED;
+      }
       ctx->tune.*(t.field) = value;
       return IPA_OK;
     }
@@ -90,6 +120,10 @@ int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
 
 int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
+  if (strcmp(name, "experimental") == 0) {  // read-only: is this a make EXPERIMENTAL=1 build?
+    *value = IPA_EXPERIMENTAL;
+    return IPA_OK;
+  }
   for (const TuneName& t : kTuneNames)
     if (strcmp(t.name, name) == 0) {
       *value = ctx->tune.*(t.field);
@@ -123,8 +157,13 @@ int ipa_ctx_create(int device_id, ipa_ctx** out) {
   }
   ipa_ctx* c = new ipa_ctx();
   // environment defaults of the tuning knobs: read here, once per context
+  // (out-of-range values and knobs of kernels this build does not carry are ignored)
   for (const TuneName& t : kTuneNames)
-    if (const char* e = getenv(t.env)) c->tune.*(t.field) = atoi(e);
+    if (const char* e = getenv(t.env)) {
+      const int v = atoi(e);
+      if (tune_in_range(t.name, v) && (IPA_EXPERIMENTAL || v == 0 || !tune_is_experimental(t.name)))
+        c->tune.*(t.field) = v;
+    }
   c->device = device_id;
   c->cu_count = prop.multiProcessorCount;
   if (hipSetDevice(device_id) != hipSuccess ||

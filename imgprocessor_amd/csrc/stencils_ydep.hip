@@ -61,6 +61,17 @@ ydep_gauss_cols_kernel(int h, int ky, double mn, double mx, double truncate, dou
   cols[idx] = acc;
 }
 
+// kernels[r][ii][jj] = cols[r][ii] * rowk[jj]: the reference's whole table, for windows the LDS
+// tile of conv_ydep_sep_kernel cannot hold (the generic kernels of stencils.hip read it)
+__global__ void __launch_bounds__(256)
+ydep_outer_kernel(const double* __restrict__ cols, const double* __restrict__ rowk, long n_cols,
+                  int kx, double* __restrict__ table) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_cols * kx) return;
+  const long rc = idx / kx;
+  table[idx] = cols[rc] * rowk[idx - rc * kx];
+}
+
 constexpr int kYdepTW = 256;  // output pixels per workgroup row (4 per lane)
 
 // K1 = kx when it is 1, 3 or 5 (window of a lane read once per tile row, loops unrolled),
@@ -319,18 +330,6 @@ int ipa_var_y_gauss_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w
   if (dtype != IPA_F32 && dtype != IPA_F64)
     IPA_UNSUPPORTED(ctx, "varYSizeGaussianFilter supports float32/float64 (got dtype %d)", dtype);
   const size_t esz = dtype == IPA_F32 ? 4 : 8;
-  // tables in the context's plan scratch: cols (h * ky doubles) + rowk (kx doubles)
-  const size_t cols_b = (size_t)h * ky * sizeof(double);
-  int rc = ipa_plan_reserve(ctx, cols_b + (size_t)kx * sizeof(double));
-  if (rc) return rc;
-  double* d_cols = reinterpret_cast<double*>(ctx->plan);
-  double* d_rowk = d_cols + (size_t)h * ky;
-  IPA_HIP(ctx, hipSetDevice(ctx->device));
-  IPA_HIP(ctx, hipMemcpyAsync(d_rowk, rowk, (size_t)kx * sizeof(double), hipMemcpyHostToDevice,
-                              ctx->stream));
-  // rowk is caller memory: the copy above must have read it before we return
-  hipLaunchKernelGGL(ydep_gauss_cols_kernel, dim3((h * ky + 255) / 256), dim3(256), 0, ctx->stream,
-                     h, ky, sig_min, sig_max, 4.0, d_cols);
   // rows per workgroup: ~2 x the kernel height (read amplification <= 1.5) while the tile stays
   // below ~30 KB (5 workgroups per CU), never above 60 KB
   const int tw = kYdepTW + kx - 1 + 3;
@@ -341,8 +340,35 @@ int ipa_var_y_gauss_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w
   if (rb > 64) rb = 64;
   while (rb > 8 && lds_of(rb) > 30 * 1024) rb -= 4;
   while (rb > 4 && lds_of(rb) > 60 * 1024) rb -= 4;
-  if (lds_of(rb) > 64 * 1024)
-    IPA_UNSUPPORTED(ctx, "varYSizeGaussianFilter: a %d x %d window does not fit the LDS tile", ky, kx);
+  // windows beyond the tile (stdyrange above ~23 for float32, ~11 for float64): the whole
+  // h x ky x kx table is expanded on the device and the generic entry point runs it - any
+  // stdyrange the reference accepts works, as before the tiled kernel existed
+  const bool tiled = lds_of(rb) <= 64 * 1024;
+  // tables in the context's plan scratch: cols (h * ky doubles) + rowk (kx doubles) [+ table]
+  const size_t cols_b = (size_t)h * ky * sizeof(double);
+  const size_t table_b = tiled ? 0 : cols_b * kx;
+  int rc = ipa_plan_reserve(ctx, cols_b + (size_t)kx * sizeof(double) + table_b);
+  if (rc) return rc;
+  double* d_cols = reinterpret_cast<double*>(ctx->plan);
+  double* d_rowk = d_cols + (size_t)h * ky;
+  double* d_table = d_rowk + kx;
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  IPA_HIP(ctx, hipMemcpyAsync(d_rowk, rowk, (size_t)kx * sizeof(double), hipMemcpyHostToDevice,
+                              ctx->stream));
+  // rowk is caller memory: the copy above must have read it before we return
+  hipLaunchKernelGGL(ydep_gauss_cols_kernel, dim3((h * ky + 255) / 256), dim3(256), 0, ctx->stream,
+                     h, ky, sig_min, sig_max, 4.0, d_cols);
+  if (!tiled) {
+    const long n = (long)h * ky * kx;
+    hipLaunchKernelGGL(ydep_outer_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       ctx->stream, d_cols, d_rowk, (long)h * ky, kx, d_table);
+    IPA_HIP(ctx, hipGetLastError());
+    rc = ipa_conv_ydep_dev(ctx, d_src, dtype, h, w, src_pitch, d_table, ky, kx, border_x,
+                           border_y, d_dst, dst_pitch);
+    if (rc) return rc;
+    IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rowk (host) may be reused by the caller
+    return IPA_OK;
+  }
   const int vec_out = (((uintptr_t)d_dst) % 16 == 0) && ((dst_pitch * (long)esz) % 16 == 0);
   dim3 grid((w + kYdepTW - 1) / kYdepTW, (h + rb - 1) / rb), block(256);
 #define IPA_YDEP_LAUNCH(T, K1)                                                                 \

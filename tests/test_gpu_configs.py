@@ -72,6 +72,22 @@ def test_var_y_gauss_golden(ia):
             assert_close(got, want, tol, tol, 'device tables %s %s %s' % (dt.__name__, rng, stdx))
 
 
+def test_var_y_gauss_large_window(ia, orc):
+    """stdyrange beyond the LDS tile of the separable kernel (ky > 57 float32 / > 27 float64):
+    the whole table is expanded on the device and the generic kernel runs it; the reference
+    accepts any stdyrange (filters/varYSizeGaussianFilter.py:9-50)"""
+    from imgprocessor_amd.filters import varYSizeGaussianFilter
+    img = synth((150, 300), 31, np.float64)
+    img[40, 100:120] = np.nan
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-6)):
+        for rng, stdx in (((0, 30), 1), (30, 0), ((5, 12), 2)):
+            b = img.astype(dt)
+            got = varYSizeGaussianFilter(b, rng, stdx)
+            assert got.dtype == dt and got.shape == b.shape
+            want = orc.varYSizeGaussianFilter(b, rng, stdx)
+            assert_close(got, want, tol, tol, 'large window %s %s %s' % (dt.__name__, rng, stdx))
+
+
 def test_std2d_golden(ia):
     from imgprocessor_amd.filters import standardDeviation2d
     g = load_golden('std2d.npz')

@@ -229,6 +229,87 @@ strip_pipe(const float* a, float* d, int sh, int strips_y, int frames) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// the geometry of wave_stencil.hpp's 5x5: strips step 248 px (read 256 px from x = 248 sxi - 4,
+// lanes 1..62 store), 76 input rows per 72 output rows; WORK 0: copy only, 1: + the LDS row
+// (ds_write_b128, 7 pair reads), 2: + 50 v_pk_fma_f32 per row.  ALIGNED: the same work on
+// 256-px-aligned strips (all 64 lanes store) for comparison.
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int P, int WORK, bool ALIGNED>
+__global__ void __launch_bounds__(256)
+conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) {
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const int strips_x = ALIGNED ? 15 : 16;
+  const unsigned groups = frames / 4;
+  const unsigned frame = (b % groups) * 4 + wave;
+  const unsigned sid = b / groups;
+  const unsigned syi = sid / strips_x, sxi = sid % strips_x;
+  if (syi >= (unsigned)strips_y) return;
+  const unsigned lane = threadIdx.x & 63;
+  int xs = ALIGNED ? (int)sxi * 256 : (int)sxi * 248 - 4;
+  if (xs < 0) xs = 0;
+  if (xs > W - 256) xs = W - 256;
+  const bool writer = ALIGNED || (lane >= 1 && lane < 63);
+  const int y0 = (int)syi * sh;
+  const int T = ALIGNED ? sh : sh + 4;
+  const int yin = ALIGNED ? y0 : (y0 - 2 < 0 ? 0 : (y0 - 2 + T > H ? H - T : y0 - 2));
+  const float* ap = a + (long)frame * W * H + (long)yin * W + xs;
+  float* dp = d + (long)frame * W * H + (long)y0 * W + xs;
+  const unsigned voff = 16u * lane;
+  __shared__ __attribute__((aligned(16))) float lds[4][264];
+  float* xp = lds[wave];
+  v4f buf[P];
+  v2f acc[5][2];
+#pragma unroll
+  for (int i = 0; i < 5; i++) acc[i][0] = acc[i][1] = v2f{0.f, 0.f};
+  static_for<0, P>([&](auto K) { constexpr int k = decltype(K)::value; gload4(buf[k], voff, ap + (long)k * W); });
+  const int lag = ALIGNED ? 0 : 4;
+#pragma unroll 1
+  for (int r = 0; r < T; r += P) {
+    static_for<0, P>([&](auto K) {
+      constexpr int k = decltype(K)::value;
+      const int t = r + k;
+      if (t < T) {
+        if (t >= P + lag) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P - 1));
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P - 1));
+        asm volatile("; pin %0" : "+v"(buf[k]));
+        v4f q = buf[k];
+        if constexpr (WORK >= 1) {
+          *reinterpret_cast<v4f*>(xp + 4 + 4u * lane) = buf[k];
+        }
+        const int tn = t + P < T ? t + P : T - 1;
+        gload4(buf[k], voff, ap + (long)tn * W);
+        if constexpr (WORK >= 1) {
+          __builtin_amdgcn_wave_barrier();
+          v2f pair[7];
+#pragma unroll
+          for (int m = 0; m < 7; m++) pair[m] = v2f{xp[2 + 4u * lane + m], xp[3 + 4u * lane + m]};
+          if constexpr (WORK >= 2) {
+#pragma unroll
+            for (int i = 4; i >= 0; i--)
+#pragma unroll
+              for (int j = 0; j < 5; j++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                  const v2f w2 = v2f{w0 + (float)(i * 5 + j), w0 + (float)(i * 5 + j)};
+                  acc[i][h] = __builtin_elementwise_fma(w2, pair[j + 2 * h], (j == 0 && i > 0) ? acc[i - 1][h] : acc[i][h]);
+                }
+            q = v4f{acc[4][0].x, acc[4][0].y, acc[4][1].x, acc[4][1].y};
+          } else {
+            q = v4f{pair[2].x, pair[2].y, pair[4].x, pair[4].y};
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        const int o = t - lag;
+        if (o >= 0) {
+          if (writer) gstore4<true>(q, voff, dp + (long)o * W);
+        }
+      }
+    });
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ------------------------------------------------------------------ host --
 template <typename F> double timeit(F f, int n = 6) {
   f(); f(); CK(hipDeviceSynchronize());
@@ -327,6 +408,23 @@ int main(int argc, char** argv) {
   run_pipe<8, 3, true>(a, d, sh, frames);
   run_pipe<8, 4, true>(a, d, sh, frames);
   run_pipe<4, 4, true>(a, d, sh, frames);
+  {
+    const int strips_y = H / sh;
+    auto run = [&](const char* nm, auto kern, int sx) {
+      const unsigned blocks = (unsigned)sx * strips_y * (frames / 4);
+      report(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f); }));
+    };
+    for (int rep = 0; rep < 2; rep++) {
+      run("aligned 256-px strips, copy            P=4", conv_like<4, 0, true>, 15);
+      run("aligned 256-px strips, + LDS row       P=4", conv_like<4, 1, true>, 15);
+      run("aligned 256-px strips, + LDS + 50 pkfma P=4", conv_like<4, 2, true>, 15);
+      run("248-px step (halo lanes), copy         P=4", conv_like<4, 0, false>, 16);
+      run("248-px step (halo lanes), + LDS row    P=4", conv_like<4, 1, false>, 16);
+      run("248-px step (halo lanes), + LDS + 50 pkfma P=4", conv_like<4, 2, false>, 16);
+      run("248-px step (halo lanes), + LDS + 50 pkfma P=2", conv_like<2, 2, false>, 16);
+      run("248-px step (halo lanes), + LDS + 50 pkfma P=8", conv_like<8, 2, false>, 16);
+    }
+  }
   // the pipelined copy really copies
   CK(hipMemset(d, 0, bytes));
   {
