@@ -229,56 +229,107 @@ strip_pipe(const float* a, float* d, int sh, int strips_y, int frames) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// the geometry of wave_stencil.hpp's 5x5: strips step 248 px (read 256 px from x = 248 sxi - 4,
-// lanes 1..62 store), 76 input rows per 72 output rows; WORK 0: copy only, 1: + the LDS row
-// (ds_write_b128, 7 pair reads), 2: + 50 v_pk_fma_f32 per row.  ALIGNED: the same work on
-// 256-px-aligned strips (all 64 lanes store) for comparison.
+// the geometry of wave_stencil.hpp's 5x5 and alternatives, as a copy with optional filter work.
+// GEOM 0: 256-px aligned strips (15 per row), no halo rows                     [reference shape]
+//      1: strips step 248 px: read 256 px from x = 248 sxi - 4, lanes 1..62 store, 76 rows in
+//         per 72 rows out                                                       [wave_stencil.hpp today]
+//      2: as 1 without the halo rows (72 in, 72 out)
+//      4: 256-px aligned strips, 76 rows in per 72 out, the 2 + 2 halo pixels of a row by ONE
+//         extra dwordx2 load of lanes 0 and 63 (EXEC-masked), all 64 lanes store   [proposal]
+//      5: as 1 but loads aligned down to 128 B (stores unaligned 992 B)
+//      6: as 1 but stores aligned down to 128 B, all lanes (loads unaligned)
+// ORDER 0: workgroup = 4 frames of one strip, groups fastest (frames_wg); 1: workgroup = 4
+//      adjacent strips of a frame, frame after frame; 2: as 0 within groups of 8 frames, group
+//      after group
+// WORK 0: copy only, 1: + the LDS row (ds_write_b128, 7 pair reads), 2: + 50 v_pk_fma_f32 per row
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int P, int WORK, bool ALIGNED>
+template <int P, int WORK, int GEOM, int ORDER>
 __global__ void __launch_bounds__(256)
 conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
-  const int strips_x = ALIGNED ? 15 : 16;
-  const unsigned groups = frames / 4;
-  const unsigned frame = (b % groups) * 4 + wave;
-  const unsigned sid = b / groups;
+  constexpr bool kAligned = GEOM == 0 || GEOM == 4;
+  constexpr int strips_x = kAligned ? 15 : 16;
+  unsigned frame, sid;
+  if constexpr (ORDER == 0) {
+    const unsigned groups = frames / 4;
+    frame = (b % groups) * 4 + wave;
+    sid = b / groups;
+  } else if constexpr (ORDER == 1) {
+    const unsigned g = b * 4 + wave, strips = strips_x * strips_y;
+    frame = g / strips;
+    sid = g % strips;
+    if (frame >= (unsigned)frames) return;
+  } else {
+    const unsigned per = strips_x * strips_y * 2;  // blocks per group of 8 frames
+    const unsigned grp = b / per, r = b % per;
+    frame = grp * 8 + (r % 2) * 4 + wave;
+    sid = r / 2;
+    if (frame >= (unsigned)frames) return;
+  }
   const unsigned syi = sid / strips_x, sxi = sid % strips_x;
   if (syi >= (unsigned)strips_y) return;
   const unsigned lane = threadIdx.x & 63;
-  int xs = ALIGNED ? (int)sxi * 256 : (int)sxi * 248 - 4;
+  int xs = kAligned ? (int)sxi * 256 : (int)sxi * 248 - 4;
   if (xs < 0) xs = 0;
   if (xs > W - 256) xs = W - 256;
-  const bool writer = ALIGNED || (lane >= 1 && lane < 63);
+  int xl = xs, xst = xs;
+  if (GEOM == 5) xl = xs & ~31;
+  if (GEOM == 6) xst = xs & ~31;
+  const bool writer = kAligned || GEOM == 6 || (lane >= 1 && lane < 63);
   const int y0 = (int)syi * sh;
-  const int T = ALIGNED ? sh : sh + 4;
-  const int yin = ALIGNED ? y0 : (y0 - 2 < 0 ? 0 : (y0 - 2 + T > H ? H - T : y0 - 2));
-  const float* ap = a + (long)frame * W * H + (long)yin * W + xs;
-  float* dp = d + (long)frame * W * H + (long)y0 * W + xs;
+  constexpr bool kHaloRows = GEOM == 1 || GEOM >= 4;
+  const int T = kHaloRows ? sh + 4 : sh;
+  const int yin = !kHaloRows ? y0 : (y0 - 2 < 0 ? 0 : (y0 - 2 + T > H ? H - T : y0 - 2));
+  const float* ap = a + (long)frame * W * H + (long)yin * W + xl;
+  float* dp = d + (long)frame * W * H + (long)y0 * W + xst;
   const unsigned voff = 16u * lane;
-  __shared__ __attribute__((aligned(16))) float lds[4][264];
+  // halo pair of GEOM 4: lane 0 -> the 2 px left of the strip, lane 63 -> the 2 px right of it
+  const int hx = lane == 0 ? (xs >= 2 ? -2 : 0) : (xs + 258 <= W ? 256 : 254);
+  const unsigned hoff = (unsigned)((hx + 2) * 4);   // relative to ap - 2 floats
+  const unsigned long long hmask = 0x8000000000000001ull;
+  __shared__ __attribute__((aligned(16))) float lds[4][272];
   float* xp = lds[wave];
   v4f buf[P];
+  v2f hb[P];
   v2f acc[5][2];
 #pragma unroll
   for (int i = 0; i < 5; i++) acc[i][0] = acc[i][1] = v2f{0.f, 0.f};
-  static_for<0, P>([&](auto K) { constexpr int k = decltype(K)::value; gload4(buf[k], voff, ap + (long)k * W); });
-  const int lag = ALIGNED ? 0 : 4;
+  constexpr int OPS = GEOM == 4 ? 2 : 1;  // loads per row
+  auto issue = [&](v4f& x, v2f& h, int row) {
+    gload4(x, voff, ap + (long)row * W);
+    if constexpr (GEOM == 4) {
+      unsigned long long sv;
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\t"
+                   "global_load_dwordx2 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                   : "=v"(h), "=&s"(sv)
+                   : "v"(hoff), "s"(ap + (long)row * W - 2), "s"(hmask));
+    }
+  };
+  static_for<0, P>([&](auto K) { constexpr int k = decltype(K)::value; issue(buf[k], hb[k], k); });
+  const int lag = kHaloRows ? 4 : 0;
 #pragma unroll 1
   for (int r = 0; r < T; r += P) {
     static_for<0, P>([&](auto K) {
       constexpr int k = decltype(K)::value;
       const int t = r + k;
       if (t < T) {
-        if (t >= P + lag) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * P - 1));
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(P - 1));
+        // younger than row t's loads: the loads of rows t+1 .. t+P-1 and the stores of iterations
+        // t-P .. t-1 (iteration j stores when j >= lag)
+        if (t >= P + lag) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * (P - 1) + P));
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS * (P - 1)));
         asm volatile("; pin %0" : "+v"(buf[k]));
+        if constexpr (GEOM == 4) asm volatile("; pin %0" : "+v"(hb[k]));
         v4f q = buf[k];
         if constexpr (WORK >= 1) {
           *reinterpret_cast<v4f*>(xp + 4 + 4u * lane) = buf[k];
+          if constexpr (GEOM == 4) {
+            if (lane == 0) *reinterpret_cast<v2f*>(xp + 2) = hb[k];
+            if (lane == 63) *reinterpret_cast<v2f*>(xp + 260) = hb[k];
+          }
         }
         const int tn = t + P < T ? t + P : T - 1;
-        gload4(buf[k], voff, ap + (long)tn * W);
+        issue(buf[k], hb[k], tn);
         if constexpr (WORK >= 1) {
           __builtin_amdgcn_wave_barrier();
           v2f pair[7];
@@ -415,14 +466,21 @@ int main(int argc, char** argv) {
       report(nm, timeit([&] { hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f); }));
     };
     for (int rep = 0; rep < 2; rep++) {
-      run("aligned 256-px strips, copy            P=4", conv_like<4, 0, true>, 15);
-      run("aligned 256-px strips, + LDS row       P=4", conv_like<4, 1, true>, 15);
-      run("aligned 256-px strips, + LDS + 50 pkfma P=4", conv_like<4, 2, true>, 15);
-      run("248-px step (halo lanes), copy         P=4", conv_like<4, 0, false>, 16);
-      run("248-px step (halo lanes), + LDS row    P=4", conv_like<4, 1, false>, 16);
-      run("248-px step (halo lanes), + LDS + 50 pkfma P=4", conv_like<4, 2, false>, 16);
-      run("248-px step (halo lanes), + LDS + 50 pkfma P=2", conv_like<2, 2, false>, 16);
-      run("248-px step (halo lanes), + LDS + 50 pkfma P=8", conv_like<8, 2, false>, 16);
+      run("G0 aligned 256 strips, 72 rows, copy, order 0", conv_like<4, 0, 0, 0>, 15);
+      run("G0 aligned 256 strips, 72 rows, 5x5 work, order 0", conv_like<4, 2, 0, 0>, 15);
+      run("G1 248-step, 76 rows (today), copy, order 0", conv_like<4, 0, 1, 0>, 16);
+      run("G1 248-step, 76 rows (today), 5x5 work, order 0", conv_like<4, 2, 1, 0>, 16);
+      run("G2 248-step, 72 rows, copy, order 0", conv_like<4, 0, 2, 0>, 16);
+      run("G4 aligned + halo pair load, 76 rows, copy, order 0", conv_like<4, 0, 4, 0>, 15);
+      run("G4 aligned + halo pair load, 76 rows, 5x5 work, order 0", conv_like<4, 2, 4, 0>, 15);
+      run("G5 248-step, loads aligned down, copy, order 0", conv_like<4, 0, 5, 0>, 16);
+      run("G6 248-step, stores aligned down, copy, order 0", conv_like<4, 0, 6, 0>, 16);
+      run("G0 order 1 (strips of a frame, frame after frame), copy", conv_like<4, 0, 0, 1>, 15);
+      run("G1 order 1, 5x5 work", conv_like<4, 2, 1, 1>, 16);
+      run("G4 order 1, 5x5 work", conv_like<4, 2, 4, 1>, 15);
+      run("G0 order 2 (groups of 8 frames), copy", conv_like<4, 0, 0, 2>, 15);
+      run("G1 order 2, 5x5 work", conv_like<4, 2, 1, 2>, 16);
+      run("G4 order 2, 5x5 work", conv_like<4, 2, 4, 2>, 15);
     }
   }
   // the pipelined copy really copies
