@@ -1,0 +1,83 @@
+"""In-process A/B of context knobs on the 4K headline (map-based undistort + 5x5), the plain 5x5
+filter and the standalone remap: every knob set is timed in turn, several rounds, so that the
+box's clock state is shared.  GPU box only.
+
+    python tools/ab_knobs.py [--batch 64] [--rounds 3] name:knob=v,knob=v ...
+e.g. python tools/ab_knobs.py base: inner0:frames_inner=0 wg0:frames_wg=0 sh48:strip_h=48
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import imgprocessor_amd as ia  # noqa: E402
+from imgprocessor_amd import ops  # noqa: E402
+
+
+def timeit(ctx, fn, n, warm):
+    for _ in range(warm):
+        fn()
+    ctx.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    ctx.synchronize()
+    return e0.elapsed_ms(e1) / n
+
+
+def main():
+    args = sys.argv[1:]
+    batch, rounds, sets, what = 64, 3, [], ['fused5', 'conv5']
+    while args:
+        a = args.pop(0)
+        if a == '--batch':
+            batch = int(args.pop(0))
+        elif a == '--rounds':
+            rounds = int(args.pop(0))
+        elif a == '--what':
+            what = args.pop(0).split(',')
+        else:
+            name, _, kv = a.partition(':')
+            sets.append((name, {k: int(v) for k, v in (x.split('=') for x in kv.split(',') if x)}))
+    sets = sets or [('base', {})]
+    ctx = ia.default_context(0)
+    h, w = 2160, 3840
+    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
+    g /= g.sum()
+    k5 = np.outer(g, g)
+    dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
+    rng = np.random.default_rng(0)
+    one = rng.random((16, h, w), dtype=np.float32)
+    src = ctx.to_device(np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch])
+    dst = ctx.empty((batch, h, w), np.float32)
+    calls = {
+        'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
+        'conv5': lambda: ops.conv2d(src, k5, out=dst),
+        'remap': lambda: ops.remap(src, dmx, dmy, out=dst),
+        'copy': lambda: dst.copy_from(src),
+    }
+    n = max(10, 1600 // batch)
+    base = {k: ctx.get_tuning(k) for _, kn in sets for k in kn}
+    res = {(name, c): [] for name, _ in sets for c in what}
+    for r in range(rounds):
+        for name, knobs in sets:
+            ctx.set_tuning(**base)
+            ctx.set_tuning(**knobs)
+            for c in what:
+                res[(name, c)].append(timeit(ctx, calls[c], n, n // 3))
+    ctx.set_tuning(**base)
+    print('batch %d x 4K float32, ms per launch, %d rounds alternated in one process' % (batch, rounds))
+    for c in what:
+        for name, knobs in sets:
+            v = res[(name, c)]
+            print('%-8s %-10s %-40s %s   min %.4f' % (c, name, knobs, '  '.join('%.4f' % x for x in v),
+                                                      min(v)))
+
+
+if __name__ == '__main__':
+    main()

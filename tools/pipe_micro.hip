@@ -243,7 +243,7 @@ strip_pipe(const float* a, float* d, int sh, int strips_y, int frames) {
 //      after group
 // WORK 0: copy only, 1: + the LDS row (ds_write_b128, 7 pair reads), 2: + 50 v_pk_fma_f32 per row
 typedef float v2f __attribute__((ext_vector_type(2)));
-template <int P, int WORK, int GEOM, int ORDER>
+template <int P, int WORK, int GEOM, int ORDER, bool NT = true>
 __global__ void __launch_bounds__(256)
 conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -353,7 +353,7 @@ conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) 
         }
         const int o = t - lag;
         if (o >= 0) {
-          if (writer) gstore4<true>(q, voff, dp + (long)o * W);
+          if (writer) gstore4<NT>(q, voff, dp + (long)o * W);
         }
       }
     });
@@ -478,6 +478,9 @@ int main(int argc, char** argv) {
       run("G0 order 1 (strips of a frame, frame after frame), copy", conv_like<4, 0, 0, 1>, 15);
       run("G1 order 1, 5x5 work", conv_like<4, 2, 1, 1>, 16);
       run("G4 order 1, 5x5 work", conv_like<4, 2, 4, 1>, 15);
+      run("G1 order 0, 5x5 work, plain (not nt) stores", conv_like<4, 2, 1, 0, false>, 16);
+      run("G1 order 1, 5x5 work, plain (not nt) stores", conv_like<4, 2, 1, 1, false>, 16);
+      run("G4 order 1, 5x5 work, plain (not nt) stores", conv_like<4, 2, 4, 1, false>, 15);
       run("G0 order 2 (groups of 8 frames), copy", conv_like<4, 0, 0, 2>, 15);
       run("G1 order 2, 5x5 work", conv_like<4, 2, 1, 2>, 16);
       run("G4 order 2, 5x5 work", conv_like<4, 2, 4, 2>, 15);
