@@ -206,6 +206,10 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
   asm volatile("" : "+v"(lane4_opaque));
   const unsigned voff = 16u * lane, moff = 4u * lane;
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
+#ifdef IPA_DEBUG_ALIGN_STORES   // measurement only (WRONG results): every store a whole 128-byte line run
+  outs = (float*)((unsigned long long)outs & ~127ull);
+  writer = true;
+#endif
   const int yb = y0 - G::H;                          // first input row of the strip
   const float* mxr = src.coord.mx + ((long)yb * src.coord.pitch + c.xs);
   const float* myr = src.coord.my + ((long)yb * src.coord.pitch + c.xs);

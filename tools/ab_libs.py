@@ -1,96 +1,117 @@
-"""A/B timing of builds of the library (make VARIANT=x DEFS=...): the 4K headline (map-based
-undistort + 5x5), the plain 5x5 filter and the standalone remap, each build in its own process,
-alternated.  GPU box only.
+"""A/B timing of BUILDS of the library (make VARIANT=x DEFS=...) inside ONE process: the package
+is imported once per build under its own name (each with its own library handle, context and
+stream), the calls are alternated round by round, so the builds share the box's clock state.
+The 4K headline (map-based undistort + 5x5), the plain 5x5 filter and a device copy; the fused
+result of every build is compared bit for bit with the first one.  GPU box only.
 
-    python tools/ab_libs.py [--batch 64] [--rounds 3] default nopipe noreuse ...
+    python tools/ab_libs.py [--batch 64] [--rounds 3] [--what fused5,conv5] default nopipe ...
+    (a name may carry knobs: wpb8:strip_h=48)
 """
-import json
+import importlib.util
 import os
-import subprocess
 import sys
+
+import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def child(batch):
-    import numpy as np
-    sys.path.insert(0, ROOT)
-    import imgprocessor_amd as ia
-    from imgprocessor_amd import ops
+def load_build(alias, libname):
+    path = os.path.join(ROOT, 'imgprocessor_amd')
+    os.environ['IMGPROC_HIP_LIB'] = os.path.join(
+        path, 'libimgproc_hip.so' if libname == 'default' else 'libimgproc_hip_%s.so' % libname)
+    spec = importlib.util.spec_from_file_location(alias, os.path.join(path, '__init__.py'),
+                                                  submodule_search_locations=[path])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[alias] = mod
+    spec.loader.exec_module(mod)
+    importlib.import_module(alias + '._lib').lib()  # bind the library now
+    return mod
 
-    def timeit(ctx, fn, n, warm):
-        for _ in range(warm):
-            fn()
-        ctx.synchronize()
-        e0, e1 = ctx.event(), ctx.event()
-        e0.record()
-        for _ in range(n):
-            fn()
-        e1.record()
-        ctx.synchronize()
-        return e0.elapsed_ms(e1) / n
 
-    ctx = ia.default_context(0)
-    h, w = 2160, 3840
-    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
-    dist = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
-    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
-    g /= g.sum()
-    k5 = np.outer(g, g)
-    k3 = np.ones((3, 3)) / 9.0
-    dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
-    rng = np.random.default_rng(0)
-    one = rng.random((16, h, w), dtype=np.float32)
-    src = ctx.to_device(np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch])
-    dst = ctx.empty((batch, h, w), np.float32)
-    n = max(10, 3200 // batch)
-    out = {}
-    out['fused5'] = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst), n, n // 2)
-    out['fused3'] = timeit(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k3, out=dst), n // 2, 5)
-    out['conv5'] = timeit(ctx, lambda: ops.conv2d(src, k5, out=dst), n // 2, 5)
-    out['conv3'] = timeit(ctx, lambda: ops.conv2d(src, k3, out=dst), n // 2, 5)
-    out['copy'] = timeit(ctx, lambda: dst.copy_from(src), n // 2, 5)
-    # a checksum of the fused result: builds must agree bit for bit
-    ops.remap_conv2d(src, dmx, dmy, k5, out=dst)
-    got = dst.frame(batch - 1).get()
-    out['sum'] = float(np.float64(got.astype(np.float64).sum()))
-    out['crc'] = int(np.bitwise_xor.reduce(got.view(np.uint32).ravel()))
-    print('AB ' + json.dumps(out))
+def timeit(ctx, fn, n, warm):
+    for _ in range(warm):
+        fn()
+    ctx.synchronize()
+    e0, e1 = ctx.event(), ctx.event()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    ctx.synchronize()
+    return e0.elapsed_ms(e1) / n
 
 
 def main():
     args = sys.argv[1:]
-    if args and args[0] == '--child':
-        return child(int(args[1]))
-    batch, rounds, names = 64, 3, []
+    batch, rounds, names, what = 64, 3, [], ['fused5', 'conv5', 'copy']
     while args:
         a = args.pop(0)
         if a == '--batch':
             batch = int(args.pop(0))
         elif a == '--rounds':
             rounds = int(args.pop(0))
+        elif a == '--what':
+            what = args.pop(0).split(',')
         else:
             names.append(a)
     names = names or ['default']
-    res = {n: [] for n in names}
+    h, w = 2160, 3840
+    K = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+    g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
+    g /= g.sum()
+    k5 = np.outer(g, g)
+    rng = np.random.default_rng(0)
+    one = rng.random((16, h, w), dtype=np.float32)
+    host = np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch]
+    builds = []
+    libs = {}
+    for i, spec in enumerate(names):
+        lib, _, kv = spec.partition(':')
+        knobs = {k: int(v) for k, v in (x.split('=') for x in kv.split(',') if x)}
+        if lib not in libs:
+            libs[lib] = load_build('ia_build_%d' % i, lib)
+        mod = libs[lib]
+        ops = importlib.import_module(mod.__name__ + '.ops')
+        ctx = mod.default_context(0)
+        if 'src' not in mod.__dict__:
+            mod.src = ctx.to_device(host)
+            mod.dst = ctx.empty((batch, h, w), np.float32)
+            mod.dmx, mod.dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
+        calls = {
+            'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
+            'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
+            'remap': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, out=m.dst),
+            'copy': lambda m=mod: m.dst.copy_from(m.src),
+        }
+        builds.append((spec, mod, ctx, knobs, calls))
+    n = max(10, 1600 // batch)
+    res = {(spec, c): [] for spec, *_ in builds for c in what}
     for r in range(rounds):
-        for n in names:
-            env = dict(os.environ)
-            if n != 'default':
-                env['IMGPROC_HIP_LIB'] = os.path.join(ROOT, 'imgprocessor_amd',
-                                                      'libimgproc_hip_%s.so' % n)
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), '--child', str(batch)],
-                               env=env, capture_output=True, text=True)
-            line = [l for l in p.stdout.splitlines() if l.startswith('AB ')]
-            if not line:
-                print(n, 'FAILED', p.stdout[-2000:], p.stderr[-2000:])
-                continue
-            res[n].append(json.loads(line[0][3:]))
-    print('batch %d x 4K float32, ms per launch (rounds alternated)' % batch)
-    for n in names:
-        for key in ('fused5', 'fused3', 'conv5', 'conv3', 'copy'):
-            print('%-10s %-7s %s' % (n, key, '  '.join('%.4f' % r[key] for r in res[n])))
-        print('%-10s checksum %s' % (n, sorted({(r['sum'], r['crc']) for r in res[n]})))
+        for spec, mod, ctx, knobs, calls in builds:
+            old = ctx.set_tuning(**knobs) if knobs else {}
+            for c in what:
+                res[(spec, c)].append(timeit(ctx, calls[c], n, n // 3))
+            if old:
+                ctx.set_tuning(**old)
+    ref = None
+    print('batch %d x 4K float32, ms per launch, %d rounds alternated in one process' % (batch, rounds))
+    for c in what:
+        for spec, *_ in builds:
+            v = res[(spec, c)]
+            print('%-8s %-24s %s   min %.4f' % (c, spec, '  '.join('%.4f' % x for x in v), min(v)))
+    for spec, mod, ctx, knobs, calls in builds:
+        old = ctx.set_tuning(**knobs) if knobs else {}
+        calls['fused5']()
+        got = mod.dst.frame(batch - 1).get()
+        if old:
+            ctx.set_tuning(**old)
+        if ref is None:
+            ref = got
+        same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        print('%-24s fused5 result %s' % (spec, 'identical bits' if same else
+                                          'DIFFERS from %s (max |d| %.3g)' % (names[0], np.abs(got - ref).max())))
 
 
 if __name__ == '__main__':
