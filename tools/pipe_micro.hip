@@ -401,6 +401,7 @@ __global__ void check_copy(const unsigned* a, const unsigned* d, long n, unsigne
 
 int main(int argc, char** argv) {
   const int frames = argc > 1 ? atoi(argv[1]) : 64;
+  const bool pmc = argc > 2;   // any second argument: counter mode (one launch per shape)
   const long npx = (long)W * H * frames;
   const size_t bytes = npx * 4;
   g_bytes = 2.0 * bytes;
@@ -410,6 +411,20 @@ int main(int argc, char** argv) {
   CK(hipMemset(d, 0, bytes));
   CK(hipDeviceSynchronize());
 
+  if (pmc) {
+    hipLaunchKernelGGL(fill_kernel, dim3((npx + 255) / 256), dim3(256), 0, 0, (unsigned*)a, npx, 1);
+    const long n4 = npx / 4;
+    const int sh = 72, strips_y = H / sh;
+    for (int rep = 0; rep < 2; rep++) {
+      hipLaunchKernelGGL(linear_copy, dim3((n4 + 255) / 256), dim3(256), 0, 0, (const v4f*)a, (v4f*)d, n4);
+      hipLaunchKernelGGL((conv_like<4, 2, 0, 0>), dim3(15u * strips_y * (frames / 4)), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f);
+      hipLaunchKernelGGL((conv_like<4, 2, 1, 0>), dim3(16u * strips_y * (frames / 4)), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f);
+      hipLaunchKernelGGL((conv_like<4, 2, 4, 0>), dim3(15u * strips_y * (frames / 4)), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f);
+      hipLaunchKernelGGL((conv_like<4, 2, 4, 1>), dim3(15u * strips_y * (frames / 4)), dim3(256), 0, 0, a, d, sh, strips_y, frames, 0.01f);
+    }
+    CK(hipDeviceSynchronize());
+    return 0;
+  }
   // ---- probes (table = a, words hash32(i)); 2^29 words = 2 GB
   {
     unsigned mask = (1u << 28) - 1;  // 1 GB window
