@@ -80,6 +80,11 @@ template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, uns
 }
 // the two dwords of a bilinear tap row at byte offset `off` of the frame (range-checked)
 __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v4i rs) {
+#ifdef IPA_DEBUG_ONE_DWORD   // measurement only (WRONG results): one dword per tap row
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+  b = a;
+  return;
+#endif
   asm volatile("buffer_load_dword %0, %2, %3, 0 offen\n\t"
                "buffer_load_dword %1, %2, %3, 0 offen offset:4"
                : "=v"(a), "=v"(b)
@@ -89,6 +94,16 @@ __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v
 __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned off, v4i rs,
                                                     unsigned long long m) {
   unsigned long long sv;
+#ifdef IPA_DEBUG_ONE_DWORD
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, %4\n\t"
+               "buffer_load_dword %0, %2, %3, 0 offen\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(a), "=&s"(sv)
+               : "v"(off), "s"(rs), "s"(m));
+  b = a;
+  return;
+#endif
   asm volatile("s_mov_b64 %2, exec\n\t"
                "s_mov_b64 exec, %5\n\t"
                "buffer_load_dword %0, %3, %4, 0 offen\n\t"
@@ -222,6 +237,18 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 
   // map row r (clamped to the strip) -> m[0..3] = x of pixels lane + 64 k, m[4..7] = y
   auto issue_map = [&](float (&m)[8], int r) {
+#ifdef IPA_DEBUG_NO_MAP   // measurement only (WRONG results): coordinates from arithmetic, no map traffic
+    static_for<0, 4>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      const float fx = (float)(c.xs + (int)lane + 64 * k), fy = (float)(yb + (r < T ? r : T - 1));
+      m[k] = fx * 0.97f + 40.f + fy * 0.004f;
+      m[4 + k] = fy * 0.97f + 30.f + fx * 0.002f;
+      asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+    });
+    // (8 no-ops stand in for the 8 loads so that the counted waits stay valid: nothing is
+    // counted for them, so the waits below are merely more conservative)
+    return;
+#endif
     const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
     static_for<0, 4>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
@@ -242,6 +269,17 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << 2;
   };
 
+  // vector-memory operations per row (the counted waits below)
+#ifdef IPA_DEBUG_NO_MAP
+  constexpr int kMapOps = 0;
+#else
+  constexpr int kMapOps = 8;
+#endif
+#ifdef IPA_DEBUG_ONE_DWORD
+  constexpr int kTapOps = 8;
+#else
+  constexpr int kTapOps = 16;
+#endif
   float m[8];            // map row in flight / being consumed
   float ga[8], gb[8];    // tap rows: [2k], [2k+1] = the two dwords of footprint k
   float txa[4], tya[4], txb[4], tyb[4];
@@ -258,7 +296,7 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
   for (int k = 0; k < 4; k++) pipe_gather2(ga[2 * k], ga[2 * k + 1], offa[k], rs);
 #pragma unroll
   for (int k = 0; k < 4; k++) pipe_gather2(gb[2 * k], gb[2 * k + 1], offa[k] + pitch_b, rs);
-  vm_wait<16>();
+  vm_wait<kTapOps>();
   vm_pin(m);
   footprint(m, txb, tyb, offb, inb);
   issue_map(m, 2);
@@ -274,8 +312,8 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     // (the branch holds operand-less waits only: with the registers as operands of two
     // alternative statements the compiler merges them through copies, and a copy of a register
     // whose load is still in flight reads garbage)
-    if (t >= K) vm_wait<9>();
-    else vm_wait<8>();
+    if (t >= K) vm_wait<kMapOps + 1>();
+    else vm_wait<kMapOps>();
     vm_pin(top);
     vm_pin(bot);
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
@@ -319,15 +357,19 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     for (int k = 0; k < 4; k++) pipe_gather2(top[2 * k], top[2 * k + 1], offn[k] + pitch_b, rs);
     __builtin_amdgcn_wave_barrier();
     // 4. filter + store
+#ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
+    const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
+#else
     const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
+#endif
     const int o = t - (K - 1);
     if (o >= 0) {
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
     // 5. map row t + 2: younger = gathers(t+1) [16] + this iteration's store
-    if (t >= K - 1) vm_wait<17>();
-    else vm_wait<16>();
+    if (t >= K - 1) vm_wait<kTapOps + 1>();
+    else vm_wait<kTapOps>();
     vm_pin(m);
     footprint(m, txnn, tynn, offnn, interiornn);
     issue_map(m, t + 3);
