@@ -80,6 +80,11 @@ template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, uns
 }
 // the two dwords of a bilinear tap row at byte offset `off` of the frame (range-checked)
 __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v4i rs) {
+#ifdef IPA_DEBUG_NO_GATHER   // measurement only (WRONG results): taps from arithmetic
+  a = __uint_as_float(off | 0x3f000000u);
+  b = a;
+  return;
+#endif
 #ifdef IPA_DEBUG_ONE_DWORD   // measurement only (WRONG results): one dword per tap row
   asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
   b = a;
@@ -94,6 +99,11 @@ __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v
 __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned off, v4i rs,
                                                     unsigned long long m) {
   unsigned long long sv;
+#ifdef IPA_DEBUG_NO_GATHER
+  a = __uint_as_float(off | 0x3f000000u);
+  b = a;
+  return;
+#endif
 #ifdef IPA_DEBUG_ONE_DWORD
   asm volatile("s_mov_b64 %1, exec\n\t"
                "s_mov_b64 exec, %4\n\t"
@@ -275,7 +285,9 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 #else
   constexpr int kMapOps = 8;
 #endif
-#ifdef IPA_DEBUG_ONE_DWORD
+#if defined(IPA_DEBUG_NO_GATHER)
+  constexpr int kTapOps = 0;
+#elif defined(IPA_DEBUG_ONE_DWORD)
   constexpr int kTapOps = 8;
 #else
   constexpr int kTapOps = 16;
@@ -363,7 +375,11 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
 #endif
     const int o = t - (K - 1);
+#ifdef IPA_DEBUG_NO_STORE   // measurement only: one store per strip (keeps the work alive)
+    if (o == 0) {
+#else
     if (o >= 0) {
+#endif
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();

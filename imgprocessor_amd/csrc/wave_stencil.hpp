@@ -86,7 +86,11 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 
 template <int K> struct wave_geom {
   static constexpr int H = K / 2;
+#ifdef IPA_DEBUG_G4   // measurement only (WRONG at strip edges): 256-px aligned strips, no halo lanes
+  static constexpr int HL = 0;
+#else
   static constexpr int HL = (H + 3) / 4;     // halo lanes per side
+#endif
   static constexpr int OW = 256 - 8 * HL;    // output pixels per strip row
   static constexpr int NW = 4 + 2 * H;       // window a lane needs per row
 };
