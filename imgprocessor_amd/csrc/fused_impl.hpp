@@ -50,7 +50,7 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   s.border = f.border; s.q5 = f.q5; s.cubic_a = f.cubic_a; s.lanczos = nullptr;
   s.cval = (float)f.cval; s.ccval = (float)f.conv_cval; s.map_vec = f.map_vec;
   WaveParams p = f.p;
-  using G = wave_geom<K>;
+  using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
@@ -118,7 +118,7 @@ int IPA_CAT(ipa_wave_conv_launch_k, IPA_FUSED_K)(ipa_ctx* ctx, const ipa::WavePa
   Weights<float, K * K> w;
   for (int i = 0; i < K * K; i++) w.w[i] = (float)kernel[i];
   WaveParams p = p0;
-  using G = wave_geom<K>;
+  using G = wave_geom<K, geom_halo<LoadRowSrc, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);

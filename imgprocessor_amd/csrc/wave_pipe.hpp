@@ -69,6 +69,19 @@ template <int OFF> __device__ __forceinline__ void pipe_load1(float& x, unsigned
                                                               const float* sbase) {
   asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(x) : "v"(voff), "s"(sbase), "n"(OFF));
 }
+// one dword of the lanes in `m` (the halo lanes); the others keep x
+template <int OFF> __device__ __forceinline__ void pipe_load1_masked(float& x, unsigned voff,
+                                                                     const float* sbase,
+                                                                     unsigned long long m) {
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, %4\n\t"
+               "global_load_dword %0, %2, %3 offset:%5\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(x), "=&s"(sv)
+               : "v"(voff), "s"(sbase), "s"(m), "n"(OFF));
+}
+__device__ __forceinline__ void vm_pin(float& a) { asm volatile("; pin %0" : "+v"(a)); }
 template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, unsigned voff,
                                                                float* sbase) {
   // (the s_nop: a VALU write of the data registers directly behind a 128-bit store needs one
@@ -160,13 +173,14 @@ __device__ __forceinline__ v4f pipe_filter_row(const Weights<float, K * K>& wts,
 }
 
 // ------------------------------------------------------------------ plain rows --
-template <int K>
+template <int K, bool HALO>
 __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const LoadRowSrc& src,
                                                     const Weights<float, K * K>& wts, float* xp,
                                                     const Cols& c, int y0, int nrows, bool writer,
                                                     float* dst) {
-  using G = wave_geom<K>;
+  using G = wave_geom<K, HALO>;
   constexpr int P = IPA_PIPE_ROWS;
+  constexpr int OPS = HALO ? 2 : 1;   // loads per row: the row + (HALO) its 2 H halo pixels
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
   unsigned lane4_opaque = 4u * lane;
@@ -174,10 +188,16 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const L
   const unsigned voff = 16u * lane;
   const float* rows = src.base + ((long)(y0 - G::H) * src.pitch + c.xs);  // scalar: input row 0
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);                      // scalar: output row 0
+  // HALO: lane j < 2H supplies the pixel H - j left of the strip / j - H right of it
+  const unsigned hoff = 4u * halo_pos<G::H>(lane);     // bytes from (row - H floats)
+  const unsigned long long hmask = (1ull << (2 * G::H)) - 1ull;
   v4f buf[P];
+  float hb[P] = {};
   static_for<0, P>([&](auto U) {
     constexpr int u = decltype(U)::value;
-    pipe_load4(buf[u], voff, rows + (long)(u < T ? u : T - 1) * src.pitch);
+    const float* r = rows + (long)(u < T ? u : T - 1) * src.pitch;
+    pipe_load4(buf[u], voff, r);
+    if constexpr (HALO) pipe_load1_masked<0>(hb[u], hoff, r - G::H, hmask);
   });
   v2f acc[K][2];
   int tb = 0;
@@ -187,14 +207,20 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const L
       constexpr int u = decltype(U)::value;
       const int t = tb + u;
       if (t < T) {
-        // younger than load(t): loads t+1 .. t+P-1, and the stores of iterations t-P .. t-1
-        // (iteration j stores when j >= K - 1)
-        if (t >= P + K - 1) vm_wait<2 * P - 1>();
-        else vm_wait<P - 1>();
+        // younger than the loads of row t: the loads of rows t+1 .. t+P-1, and the stores of
+        // iterations t-P .. t-1 (iteration j stores when j >= K - 1)
+        if (t >= P + K - 1) vm_wait<OPS * (P - 1) + P>();
+        else vm_wait<OPS * (P - 1)>();
         vm_pin(buf[u]);
         *reinterpret_cast<v4f*>(xp + kRowPad + 4u * lane) = buf[u];
+        if constexpr (HALO) {
+          vm_pin(hb[u]);
+          if (lane < 2u * G::H) xp[kRowPad - G::H + halo_pos<G::H>(lane)] = hb[u];
+        }
         const int tn = t + P < T ? t + P : T - 1;
-        pipe_load4(buf[u], voff, rows + (long)tn * src.pitch);
+        const float* r = rows + (long)tn * src.pitch;
+        pipe_load4(buf[u], voff, r);
+        if constexpr (HALO) pipe_load1_masked<0>(hb[u], hoff, r - G::H, hmask);
         __builtin_amdgcn_wave_barrier();
         const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
         const int o = t - (K - 1);
@@ -215,21 +241,30 @@ template <int K> struct pipe_capable<LoadRowSrc, K> : std::true_type {};
 template <typename Coord, int K> struct pipe_capable<SampleRowSrc<float, kLinear, Coord>, K> {
   static constexpr bool value = SampleRowSrc<float, kLinear, Coord>::template depth<K>::kPiped;
 };
+// the kernels on this header take the 256-px aligned strip geometry with a halo pass
+template <typename Src, int K, bool STREAM> struct geom_halo {
+  static constexpr bool value = (IPA_PIPE != 0) && (IPA_HALO != 0) && !STREAM && K <= 9 && pipe_capable<Src, K>::value;
+};
 
-template <int K, int QM, typename Coord>
+template <int K, int QM, bool HALO, typename Coord>
 __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
                                                     const SampleRowSrc<float, kLinear, Coord>& src,
                                                     const Weights<float, K * K>& wts, float* xp,
                                                     const Cols& c, int y0, int nrows, bool writer,
                                                     float* dst) {
-  using G = wave_geom<K>;
+  using G = wave_geom<K, HALO>;
   using C = typename Coord::coord_t;
   static_assert(sizeof(C) == 4, "float32 coordinate tables");
+  // samples per lane and row: pixels lane + 64 k (k = 0..3) and, in the HALO geometry, the halo
+  // pixel of lanes 0 .. 2H-1 as a fifth sample under an EXEC mask
+  constexpr int NS = HALO ? 5 : 4;
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
   unsigned lane4_opaque = 4u * lane;
   asm volatile("" : "+v"(lane4_opaque));
-  const unsigned voff = 16u * lane, moff = 4u * lane;
+  // (4 lane doubles as the map rows' byte offset and as the opaque LDS window offset: every
+  // per-lane constant costs a register, and this kernel sits at the 128-register step)
+  const unsigned voff = 16u * lane, moff = lane4_opaque;
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
 #ifdef IPA_DEBUG_ALIGN_STORES   // measurement only (WRONG results): every store a whole 128-byte line run
   outs = (float*)((unsigned long long)outs & ~127ull);
@@ -244,19 +279,35 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
   const v4i rs = v4i{(int)(unsigned)fb, (int)((unsigned)(fb >> 32) & 0xffffu), (int)src.src_bytes,
                      0x00020000};
   const unsigned pitch_b = (unsigned)s.pitch * 4u;
+  // the halo pixel of lane j < 2H: column xs - H + halo_pos(j); its LDS slot; the lanes' mask
+  const unsigned hcol = halo_pos<G::H>(lane);
+#define hoff (4u * hcol)                             /* bytes from (map row - H floats) */
+  const unsigned long long hmask = (1ull << (2 * G::H)) - 1ull;
+  const unsigned allin = lane < 2u * G::H ? 0u : 0x10u;   // lanes without a halo pixel: "inside"
 
-  // map row r (clamped to the strip) -> m[0..3] = x of pixels lane + 64 k, m[4..7] = y
-  auto issue_map = [&](float (&m)[8], int r) {
+  // vector-memory operations per row (the counted waits below)
+#ifdef IPA_DEBUG_NO_MAP
+  constexpr int kMapOps = 0;
+#else
+  constexpr int kMapOps = 2 * NS;
+#endif
+#if defined(IPA_DEBUG_NO_GATHER)
+  constexpr int kTapOps = 0;
+#elif defined(IPA_DEBUG_ONE_DWORD)
+  constexpr int kTapOps = 2 * NS;
+#else
+  constexpr int kTapOps = 4 * NS;
+#endif
+
+  // map row r (clamped to the strip) -> m[k] = x, m[NS + k] = y of sample k
+  auto issue_map = [&](float (&m)[2 * NS], int r) {
 #ifdef IPA_DEBUG_NO_MAP   // measurement only (WRONG results): coordinates from arithmetic, no map traffic
-    static_for<0, 4>([&](auto Kk) {
+    static_for<0, NS>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
       const float fx = (float)(c.xs + (int)lane + 64 * k), fy = (float)(yb + (r < T ? r : T - 1));
       m[k] = fx * 0.97f + 40.f + fy * 0.004f;
-      m[4 + k] = fy * 0.97f + 30.f + fx * 0.002f;
-      asm volatile("s_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0\n\ts_nop 0");
+      m[NS + k] = fy * 0.97f + 30.f + fx * 0.002f;
     });
-    // (8 no-ops stand in for the 8 loads so that the counted waits stay valid: nothing is
-    // counted for them, so the waits below are merely more conservative)
     return;
 #endif
     const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
@@ -264,74 +315,78 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
       constexpr int k = decltype(Kk)::value;
       pipe_load1<256 * k>(m[k], moff, mxr + o);
     });
+    if constexpr (HALO) pipe_load1_masked<0>(m[4], hoff, mxr + o - G::H, hmask);
     static_for<0, 4>([&](auto Kk) {
       constexpr int k = decltype(Kk)::value;
-      pipe_load1<256 * k>(m[4 + k], moff, myr + o);
+      pipe_load1<256 * k>(m[NS + k], moff, myr + o);
     });
+    if constexpr (HALO) pipe_load1_masked<0>(m[NS + 4], hoff, myr + o - G::H, hmask);
+  };
+  auto pin_map = [&](float (&m)[2 * NS]) {
+#pragma unroll
+    for (int k = 0; k < 2 * NS; k++) vm_pin(m[k]);
   };
   // footprints of a map row: fractions, byte offsets of the top-left taps, interior bits
-  auto footprint = [&](const float (&m)[8], float (&tx)[4], float (&ty)[4], unsigned (&off)[4],
-                       unsigned& interior) {
-    const float sx[4] = {m[0], m[1], m[2], m[3]}, sy[4] = {m[4], m[5], m[6], m[7]};
-    int e[4];
-    batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
+  auto footprint = [&](const float (&m)[2 * NS], float (&tx)[NS], float (&ty)[NS],
+                       unsigned (&off)[NS], unsigned& interior) {
+    float sx[NS], sy[NS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << 2;
+    for (int k = 0; k < NS; k++) { sx[k] = m[k]; sy[k] = m[NS + k]; }
+    int e[NS];
+    batch_footprint_linear<NS, QM>(s, sx, sy, tx, ty, e, interior);
+    if constexpr (HALO) interior |= allin;
+#pragma unroll
+    for (int k = 0; k < NS; k++) off[k] = (unsigned)e[k] << 2;
+  };
+  // tap rows of sample k: full wave for the strip's pixels, the halo lanes for sample 4
+  auto gather_row = [&](float (&g)[2 * NS], const unsigned (&off)[NS], unsigned add) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) pipe_gather2(g[2 * k], g[2 * k + 1], off[k] + add, rs);
+    if constexpr (HALO) pipe_gather2_masked(g[8], g[9], off[4] + add, rs, hmask);
+  };
+  auto pin_taps = [&](float (&g)[2 * NS]) {
+#pragma unroll
+    for (int k = 0; k < 2 * NS; k++) vm_pin(g[k]);
   };
 
-  // vector-memory operations per row (the counted waits below)
-#ifdef IPA_DEBUG_NO_MAP
-  constexpr int kMapOps = 0;
-#else
-  constexpr int kMapOps = 8;
-#endif
-#if defined(IPA_DEBUG_NO_GATHER)
-  constexpr int kTapOps = 0;
-#elif defined(IPA_DEBUG_ONE_DWORD)
-  constexpr int kTapOps = 8;
-#else
-  constexpr int kTapOps = 16;
-#endif
-  float m[8];            // map row in flight / being consumed
-  float ga[8], gb[8];    // tap rows: [2k], [2k+1] = the two dwords of footprint k
-  float txa[4], tya[4], txb[4], tyb[4];
-  unsigned offa[4], offb[4], ina, inb;
+  float m[2 * NS] = {};      // map row in flight / being consumed
+  float ga[2 * NS] = {}, gb[2 * NS] = {};   // tap rows: [2k], [2k+1] = the two dwords of footprint k
+  float txa[NS], tya[NS], txb[NS], tyb[NS];
+  unsigned offa[NS], offb[NS], ina, inb;
   v2f acc[K][2];
 
   // prologue: rows 0 and 1 resolved, gathers of row 0 and map row 2 in flight
   issue_map(m, 0);
   vm_wait<0>();
-  vm_pin(m);
+  pin_map(m);
   footprint(m, txa, tya, offa, ina);
   issue_map(m, 1);
-#pragma unroll
-  for (int k = 0; k < 4; k++) pipe_gather2(ga[2 * k], ga[2 * k + 1], offa[k], rs);
-#pragma unroll
-  for (int k = 0; k < 4; k++) pipe_gather2(gb[2 * k], gb[2 * k + 1], offa[k] + pitch_b, rs);
+  gather_row(ga, offa, 0u);
+  gather_row(gb, offa, pitch_b);
   vm_wait<kTapOps>();
-  vm_pin(m);
+  pin_map(m);
   footprint(m, txb, tyb, offb, inb);
   issue_map(m, 2);
-  // from here on, in issue order: ... gathers(t) [16], store(t-1)?, map(t+2) [8] | iteration t
+  // from here on, in issue order: ... gathers(t) [kTapOps], store(t-1)?, map(t+2) [kMapOps] | iteration t
 
   // one iteration: TOP / BOT = tap-row registers of row t (top, bottom); the bottom registers
   // become the top registers of row t + 1
-  auto step = [&](int t, float (&top)[8], float (&bot)[8], const float (&tx)[4],
-                  const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
-                  float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn,
-                  float (&txnn)[4], float (&tynn)[4], unsigned (&offnn)[4], unsigned& interiornn) {
+  auto step = [&](int t, float (&top)[2 * NS], float (&bot)[2 * NS], const float (&tx)[NS],
+                  const float (&ty)[NS], const unsigned (&off)[NS], unsigned interior,
+                  float (&txn)[NS], float (&tyn)[NS], unsigned (&offn)[NS], unsigned& interiorn,
+                  float (&txnn)[NS], float (&tynn)[NS], unsigned (&offnn)[NS], unsigned& interiornn) {
     // 1. the gathers of row t: younger = [store of iteration t-1] + map(t+2)
     // (the branch holds operand-less waits only: with the registers as operands of two
     // alternative statements the compiler merges them through copies, and a copy of a register
     // whose load is still in flight reads garbage)
     if (t >= K) vm_wait<kMapOps + 1>();
     else vm_wait<kMapOps>();
-    vm_pin(top);
-    vm_pin(bot);
+    pin_taps(top);
+    pin_taps(bot);
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
-    float cur[4];
+    float cur[NS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NS; k++) {
       const float wx0 = 1.f - tx[k], wx1 = tx[k], wy0 = 1.f - ty[k], wy1 = ty[k];
       float r0 = wx0 * top[2 * k];
       r0 = ipa_fma(wx1, top[2 * k + 1], r0);
@@ -342,32 +397,39 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
-    if (__builtin_amdgcn_ballot_w64(interior != 0xfu)) {
+    if constexpr (HALO) {
+      if (lane < 2u * G::H) xp[kRowPad - G::H + hcol] = cur[4];
+    }
+    if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
       // footprints touching the source border (rare): redo them tap by tap, straight into the
       // LDS row - ONE copy of the border-aware sampler per step (a loop, not unrolled)
 #pragma unroll 1
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < NS; k++) {
         if (!((interior >> k) & 1u)) {
+          const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
           float sx, sy;
-          src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
-          xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+          src.coord.get(col, yb + t, sx, sy);
+          xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
+              sample<float, kLinear, float>(s, sx, sy, src.cval);
         }
       }
     }
+    __builtin_amdgcn_sched_barrier(0);   // (phases kept apart: interleaved they need more registers)
     // 3. gathers of row t + 1: its top row into `bot` under the mask of the lanes whose
     //    footprint did not move straight down, its bottom row into `top`
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NS; k++) {
 #if IPA_PIPE_REUSE
-      const unsigned long long need = __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b);
-      pipe_gather2_masked(bot[2 * k], bot[2 * k + 1], offn[k], rs, need);
+      unsigned long long need = __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b);
 #else
-      pipe_gather2(bot[2 * k], bot[2 * k + 1], offn[k], rs);
+      unsigned long long need = ~0ull;
 #endif
+      if (k == 4) need &= hmask;
+      pipe_gather2_masked(bot[2 * k], bot[2 * k + 1], offn[k], rs, need);
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) pipe_gather2(top[2 * k], top[2 * k + 1], offn[k] + pitch_b, rs);
+    gather_row(top, offn, pitch_b);
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_sched_barrier(0);
     // 4. filter + store
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
     const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
@@ -375,27 +437,24 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
 #endif
     const int o = t - (K - 1);
-#ifdef IPA_DEBUG_NO_STORE   // measurement only: one store per strip (keeps the work alive)
-    if (o == 0) {
-#else
     if (o >= 0) {
-#endif
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
-    // 5. map row t + 2: younger = gathers(t+1) [16] + this iteration's store
+    __builtin_amdgcn_sched_barrier(0);
+    // 5. map row t + 2: younger = gathers(t+1) [kTapOps] + this iteration's store
     if (t >= K - 1) vm_wait<kTapOps + 1>();
     else vm_wait<kTapOps>();
-    vm_pin(m);
+    pin_map(m);
     footprint(m, txnn, tynn, offnn, interiornn);
     issue_map(m, t + 3);
   };
 
   // rows rotate through three footprint sets (t, t+1, t+2) and two tap-register roles
-  float txc[4], tyc[4];
-  unsigned offc[4], inc = 0xfu;
   // (a do-while: T >= K, and with no path around the loop the prologue's loads provably flow
   // into it - tools/check_pipe_asm.py follows the control-flow graph)
+  float txc[NS], tyc[NS];
+  unsigned offc[NS], inc = (1u << NS) - 1u;
   int tb = 0;
 #pragma unroll 1
   do {
@@ -408,6 +467,7 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     if (tb + 5 < T) step(tb + 5, gb, ga, txc, tyc, offc, inc, txa, tya, offa, ina, txb, tyb, offb, inb);
     tb += 6;
   } while (tb < T);
+#undef hoff
 }
 
 }  // namespace ipa

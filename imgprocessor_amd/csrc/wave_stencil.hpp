@@ -63,6 +63,9 @@
 #ifndef IPA_PIPE
 #define IPA_PIPE 1   // FAST strips on the hand-scheduled memory pipeline of wave_pipe.hpp
 #endif
+#ifndef IPA_PIPE_MIN_WAVES
+#define IPA_PIPE_MIN_WAVES 4
+#endif
 
 namespace ipa {
 
@@ -84,16 +87,26 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
-template <int K> struct wave_geom {
+// Two strip geometries:
+//   HALO = false  strips step 256 - 8 HL px and overlap: lanes 0 .. HL-1 and 64-HL .. 63 only
+//                 supply the horizontal halo (every kernel of rounds 1 and 2);
+//   HALO = true   (round 3) strips are 256 px wide and 256-px ALIGNED, all 64 lanes store, and
+//                 the 2 H halo pixels of a row are fetched / sampled by an extra pass of the
+//                 lanes 0 .. 2H-1 into the pads of the LDS row.  A strip row is then written as
+//                 whole 128-byte lines (the 992-byte rows of the overlapping strips end in
+//                 partial lines shared with the neighbour strip) and a 4K row takes 15 strips,
+//                 not 16: the plain 5x5 ran 1.01 -> 0.85 ms per 64 x 4K with this geometry,
+//                 the fused undistort + 5x5 1.22 -> 1.12 (tools/ab_libs.py, one box).
+template <int K, bool HALO = false> struct wave_geom {
   static constexpr int H = K / 2;
-#ifdef IPA_DEBUG_G4   // measurement only (WRONG at strip edges): 256-px aligned strips, no halo lanes
-  static constexpr int HL = 0;
-#else
-  static constexpr int HL = (H + 3) / 4;     // halo lanes per side
-#endif
-  static constexpr int OW = 256 - 8 * HL;    // output pixels per strip row
-  static constexpr int NW = 4 + 2 * H;       // window a lane needs per row
+  static constexpr bool kHalo = HALO;
+  static constexpr int HL = HALO ? 0 : (H + 3) / 4;  // halo lanes per side
+  static constexpr int OW = 256 - 8 * HL;            // output pixels per strip row
+  static constexpr int NW = 4 + 2 * H;               // window a lane needs per row
 };
+#ifndef IPA_HALO
+#define IPA_HALO 1   // the hand-scheduled kernels (wave_pipe.hpp) use the aligned geometry
+#endif
 
 struct WaveParams {
   char* dst;
@@ -140,7 +153,13 @@ struct Cols {
   int xo;       // first column of the lane = xs + 4*lane (may be < 0 or >= dw at the rim)
   int uu[4];    // border-resolved column per pixel, -1 = constant border
   int uq[4];    // the same for the lane-interleaved pixels xs + lane + 64 k (sampling sources)
+  int uh;       // HALO geometry: border-resolved halo column of lanes 0 .. 2H-1 (-1 = constant)
 };
+// position (floats from the start of a wave's LDS row) of the halo pixel lane j < 2H supplies:
+// H pixels left of the strip, H pixels right of it
+template <int H> __device__ __forceinline__ unsigned halo_pos(unsigned lane) {
+  return lane < (unsigned)H ? lane : 256u + lane;   // + kRowPad - H
+}
 
 // ---------------------------------------------------------------- row sources --
 // load_chunk<FAST, D>() issues the memory traffic of D consecutive rows
@@ -204,6 +223,22 @@ struct LoadRowSrc {
       *reinterpret_cast<float4*>(xp + d * kRowStride + kRowPad + 4u * lane) =
           float4{ch.v[d][0], ch.v[d][1], ch.v[d][2], ch.v[d][3]};
   }
+  // HALO geometry, chunked loop (rim strips): the 2 H halo pixels of every row of the chunk
+  template <int D, int H, int QM = -1>
+  __device__ __forceinline__ void issue_halo(const Cols& c, const int (&vv)[D], Chunk<D>&) const {}
+  template <int D, int H>
+  __device__ __forceinline__ void stage_halo(const Cols& c, const int (&vv)[D], const Chunk<D>&,
+                                             float* xp) const {
+    const unsigned lane = threadIdx.x & 63u;
+    if (lane < 2u * H) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const float* row = base + (long)(vv[d] < 0 ? 0 : vv[d]) * pitch;
+        const float v = row[c.uh < 0 ? 0 : c.uh];
+        xp[d * kRowStride + kRowPad - H + halo_pos<H>(lane)] = (vv[d] < 0 || c.uh < 0) ? cval : v;
+      }
+    }
+  }
 };
 
 // rows of the remapped image, sampled on the fly
@@ -225,7 +260,10 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     static constexpr int value =
         INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kPiped ? 1 : IPA_SAMPLE_DEPTH)) : 1;
   };
-  template <int D> struct Chunk { BatchTaps<ST, INTERP, 4> t[D]; };
+  template <int D> struct Chunk {
+    BatchTaps<ST, INTERP, 4> t[D];
+    BatchTaps<ST, INTERP, 1> th[D];   // HALO geometry: the halo sample of lanes 0 .. 2H-1
+  };
 
   Coord coord;
   const char* src;       // frame 0 of the remap source
@@ -336,6 +374,33 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
       for (int k = 0; k < 4; k++) row[64u * k + lane] = cur[k];
     }
   }
+  // HALO geometry, chunked loop (rim strips): the halo sample of lanes 0 .. 2H-1 through the
+  // same batch machinery (taps issued with the chunk's other loads, blended with its rows)
+  template <int D, int H, int QM = -1>
+  __device__ __forceinline__ void issue_halo(const Cols& c, const int (&vv)[D], Chunk<D>& ch) const {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      C hx[1], hy[1];
+      coord.get(c.uh < 0 ? 0 : c.uh, vv[d] < 0 ? 0 : vv[d], hx[0], hy[0]);
+      batch_issue<ST, INTERP, 1, QM>(s, hx, hy, ch.th[d]);
+    }
+  }
+  template <int D, int H>
+  __device__ __forceinline__ void stage_halo(const Cols& c, const int (&vv)[D], const Chunk<D>& ch,
+                                             float* xp) const {
+    const unsigned lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      float cur = batch_blend_one<ST, INTERP, 1>(s, ch.th[d], 0);
+      if (!(ch.th[d].interior & 1u)) {
+        C hx, hy;
+        coord.get(c.uh < 0 ? 0 : c.uh, vv[d] < 0 ? 0 : vv[d], hx, hy);
+        cur = sample<ST, INTERP, C>(s, hx, hy, cval);
+      }
+      cur = (vv[d] < 0 || c.uh < 0) ? ccval : cur;
+      if (lane < 2u * H) xp[d * kRowStride + kRowPad - H + halo_pos<H>(lane)] = cur;
+    }
+  }
 };
 
 // -------------------------------------------------------------------- kernel --
@@ -374,12 +439,12 @@ template <int HI> __device__ __forceinline__ v2f pk_mul_coef(v2f wp, v2f x) {
   return d;
 }
 
-template <bool FAST, typename Src, int K, int QM = -1, bool STREAM = false>
+template <bool FAST, typename Src, int K, int QM = -1, bool STREAM = false, bool HALO = false>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                    const Weights<float, K * K>& wts, float* xp,
                                                    const Cols& c, int y0, int nrows, bool writer,
                                                    float* dst, kernarg_f32 wk = nullptr) {
-  using G = wave_geom<K>;
+  using G = wave_geom<K, HALO>;
   constexpr int D = Src::template depth<K>::value;
   const int T = nrows + K - 1;  // input rows of this strip
   const unsigned lane = threadIdx.x & 63u;
@@ -399,7 +464,9 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
     }
     typename Src::template Chunk<D> ch;
     src.template load_chunk<FAST, D, QM>(c, vv, ch);
+    if constexpr (HALO) src.template issue_halo<D, G::H, QM>(c, vv, ch);
     src.template stage_rows<FAST, D>(c, vv, ch, xp);
+    if constexpr (HALO) src.template stage_halo<D, G::H>(c, vv, ch, xp);
     // wave-private LDS rows: the wave's own ds_write / ds_read execute in order
     __builtin_amdgcn_wave_barrier();
 
@@ -529,7 +596,8 @@ template <typename Src, int K, bool STREAM = false>
 __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
                                                   const Weights<float, K * K>& wts,
                                                   kernarg_f32 wk) {
-  using G = wave_geom<K>;
+  constexpr bool HALO = geom_halo<Src, K, STREAM>::value;
+  using G = wave_geom<K, HALO>;
   constexpr int D = Src::template depth<K>::value;
   const int lane = threadIdx.x & 63;
   // Two dispatch orders.  grid = (strip blocks, frames): frame after frame.  grid = (strip
@@ -572,7 +640,9 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
 
   // rows touched incl. the overshoot of the last chunk
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
-  const bool fast = src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
+  // (HALO geometry: the halo columns of a FAST strip lie inside the image too)
+  const int hx = HALO ? G::H : 0;
+  const bool fast = src.vectors_ok() && p.vec_out && xs - hx >= 0 && xs + 256 + hx <= p.dw &&
                     y0 - G::H >= 0 &&
                     y0 - G::H + rows_touched <= p.dh;
   if (fast && p.rim_only) return;
@@ -581,10 +651,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
     if constexpr (IPA_PIPE && !STREAM && pipe_capable<Src, K>::value) {
       if constexpr (Src::kHasQ5) {
-        if (src.q5) wave_run_strip_pipe<K, 1>(p, src, wts, xp, c, y0, nrows, writer, dst);
-        else wave_run_strip_pipe<K, 0>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_pipe<K, 1, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        else wave_run_strip_pipe<K, 0, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
       } else {
-        wave_run_strip_pipe<K>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        wave_run_strip_pipe<K, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
       }
     } else if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
@@ -599,12 +669,19 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
     }
-    wave_run_strip<false, Src, K, -1, STREAM>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
+    if constexpr (HALO)
+      c.uh = resolve_idx(xs - G::H + (int)halo_pos<G::H>(lane < 2 * G::H ? (unsigned)lane : 0u), p.dw, p.cbx);
+    wave_run_strip<false, Src, K, -1, STREAM, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
   }
 }
 
+// waves per SIMD the register allocation must leave room for: the hand-scheduled sampling
+// kernels sit right at the 128-register step (4 waves per SIMD)
+template <typename Src, int K> struct wave_min_waves {
+  static constexpr int value = (pipe_capable<Src, K>::value && Src::kHasQ5 && IPA_PIPE) ? IPA_PIPE_MIN_WAVES : IPA_WAVE_MIN_WAVES;
+};
 template <typename Src, int K>
-__global__ void __launch_bounds__(64 * IPA_WPB, IPA_WAVE_MIN_WAVES)
+__global__ void __launch_bounds__(64 * IPA_WPB, (wave_min_waves<Src, K>::value))
 wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
   wave_stencil_body<Src, K>(p, src, wts, nullptr);
 }

@@ -19,11 +19,11 @@ k = s[start:end]
 opens = []
 i = 0
 while i < len(k):
-    if re.search(r's_waitcnt vmcnt\((8|9)\)\s*$', k[i]):
+    if re.search(r's_waitcnt vmcnt\((8|9|10|11)\)\s*$', k[i]):
         opens.append(i)
         # skip the partner wait
         j = i + 1
-        while j < len(k) and j < i + 40 and not re.search(r's_waitcnt vmcnt\((8|9)\)\s*$', k[j]):
+        while j < len(k) and j < i + 40 and not re.search(r's_waitcnt vmcnt\((8|9|10|11)\)\s*$', k[j]):
             j += 1
         i = j + 1
     else:
