@@ -361,6 +361,36 @@ conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// vector-memory issue cost by EXEC mask: 16 dword loads per iteration from an L1-resident window,
+// MODE 0: all 64 lanes, 1: lanes 0..3, 2: EXEC = 0, 3: no loads (loop overhead)
+template <int MODE>
+__global__ void __launch_bounds__(256) exec_probe(const float* base, int iters, float* sink) {
+  const unsigned lane = threadIdx.x & 63;
+  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const float* w = base + wave * 4096;
+  const unsigned long long m = MODE == 0 ? ~0ull : (MODE == 1 ? 0xfull : 0ull);
+  float acc = 0.f;
+  const unsigned voff = 4u * lane;
+  for (int it = 0; it < iters; it++) {
+    float r[16];
+    unsigned long long sv;
+    if constexpr (MODE != 3) {
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1" : "=&s"(sv) : "s"(m));
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        asm volatile("global_load_dword %0, %1, %2" : "=v"(r[k]) : "v"(voff), "s"(w + 256 * (k & 7) + (it & 3)));
+      asm volatile("s_mov_b64 exec, %0\n\ts_waitcnt vmcnt(0)" ::"s"(sv));
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) acc += r[k];
+      }
+    } else {
+      asm volatile("s_nop 0");
+    }
+  }
+  if (acc == 12345.678f) sink[0] = acc;
+}
+
 // ------------------------------------------------------------------ host --
 template <typename F> double timeit(F f, int n = 6) {
   f(); f(); CK(hipDeviceSynchronize());
@@ -439,6 +469,26 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       unsigned hb; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));
       printf("probe %-50s wrong values: %u of %ld\n", names[m], hb, (long)blocks * 256 * iters);
+    }
+  }
+  {
+    int clk_khz; CK(hipDeviceGetAttribute(&clk_khz, hipDeviceAttributeClockRate, 0));
+    const int blocks = 256 * 4, iters = 4000;   // 16 waves per CU
+    const char* nm[4] = {"all 64 lanes", "lanes 0..3", "EXEC = 0", "no loads"};
+    for (int mode = 0; mode < 4; mode++) {
+      auto launch = [&](int n) {
+        if (mode == 0) hipLaunchKernelGGL(exec_probe<0>, dim3(blocks), dim3(256), 0, 0, a, n, (float*)bad + 8);
+        if (mode == 1) hipLaunchKernelGGL(exec_probe<1>, dim3(blocks), dim3(256), 0, 0, a, n, (float*)bad + 8);
+        if (mode == 2) hipLaunchKernelGGL(exec_probe<2>, dim3(blocks), dim3(256), 0, 0, a, n, (float*)bad + 8);
+        if (mode == 3) hipLaunchKernelGGL(exec_probe<3>, dim3(blocks), dim3(256), 0, 0, a, n, (float*)bad + 8);
+      };
+      launch(10); CK(hipDeviceSynchronize());
+      hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+      CK(hipEventRecord(e0)); launch(iters); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+      float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+      const double instr_per_cu = (double)blocks * 4 * iters * 16 / 256;
+      printf("dword load issue cost, %-14s %8.3f ms  %6.2f clk per wave-instruction per CU (at %d MHz)\n",
+             nm[mode], ms, ms * 1e-3 * clk_khz * 1e3 / instr_per_cu, clk_khz / 1000);
     }
   }
   // float data for the streams
