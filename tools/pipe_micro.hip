@@ -366,7 +366,7 @@ conv_like(const float* a, float* d, int sh, int strips_y, int frames, float w0) 
 template <int MODE>
 __global__ void __launch_bounds__(256) exec_probe(const float* base, int iters, float* sink) {
   const unsigned lane = threadIdx.x & 63;
-  const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const long wave = (long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* w = base + wave * 4096;
   const unsigned long long m = MODE == 0 ? ~0ull : (MODE == 1 ? 0xfull : 0ull);
   float acc = 0.f;
