@@ -241,9 +241,18 @@ template <int K> struct pipe_capable<LoadRowSrc, K> : std::true_type {};
 template <typename Coord, int K> struct pipe_capable<SampleRowSrc<float, kLinear, Coord>, K> {
   static constexpr bool value = SampleRowSrc<float, kLinear, Coord>::template depth<K>::kPiped;
 };
-// the kernels on this header take the 256-px aligned strip geometry with a halo pass
+// which kernels take the 256-px aligned strip geometry with a halo pass: the plain filter
+// (one extra EXEC-masked load per row: 64 x 4K 5x5 0.97 -> 0.90 ms, 0.85 with 32-row strips).
+// NOT the sampling source: there the halo costs a fifth sample per lane and row - six more
+// vector-memory instructions, and an instruction costs the CU's vector-memory path ~4.6 clocks
+// WHATEVER its EXEC mask is, EXEC = 0 included (tools/pipe_micro.hip) - 1.30 -> 1.42 ms
+// (IPA_HALO_SAMPLE=1 builds it)
+#ifndef IPA_HALO_SAMPLE
+#define IPA_HALO_SAMPLE 0
+#endif
 template <typename Src, int K, bool STREAM> struct geom_halo {
-  static constexpr bool value = (IPA_PIPE != 0) && (IPA_HALO != 0) && !STREAM && K <= 9 && pipe_capable<Src, K>::value;
+  static constexpr bool value = (IPA_PIPE != 0) && (IPA_HALO != 0) && !STREAM && K <= 9 &&
+                                pipe_capable<Src, K>::value && (IPA_HALO_SAMPLE != 0 || !Src::kHasQ5);
 };
 
 template <int K, int QM, bool HALO, typename Coord>
@@ -468,6 +477,195 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     tb += 6;
   } while (tb < T);
 #undef hoff
+}
+
+// ------------------------------------------------------------------ sampling source, map rows
+// shared by the frames of a workgroup --
+// WaveParams::frames_wg: the IPA_WPB waves of a workgroup work on IPA_WPB frames of ONE strip, so
+// they need the SAME map rows.  A vector-memory instruction costs the CU's vector-memory path
+// ~4.6 clocks whatever it fetches (tools/pipe_micro.hip), and the 8 map dwords per row and wave
+// were a third of the kernel's vector-memory instructions (and 13 % of its time: build with
+// -DIPA_DEBUG_NO_MAP).  Here each map row is loaded ONCE per workgroup - row r by wave r mod
+// IPA_WPB - and handed to the others through a ring of 2 IPA_WPB rows in LDS:
+//
+//   rows are grouped in blocks of W = IPA_WPB; between the barriers of block b-1 and block b
+//   (one s_barrier per W rows, at the top of the block's last step) every wave READS the rows
+//   of block b and the producers WRITE the rows of block b + 1 into the other half of the ring;
+//   a producer issues its row's 8 loads right behind the barrier and writes them to LDS W - 1
+//   iterations later.
+//
+// With the map loads issued BEFORE the row's gathers, the only operation younger than the
+// gathers a wave waits for is its latest store: every wait is vmcnt(1) (0 before the first
+// store), whatever was issued - so a top-row gather whose EXEC mask is empty is branched over
+// instead of issued (43 % of them on the 4K lens map).
+// Same footprints, same words, same blend as wave_run_strip_pipe: identical bits.
+template <int K, int QM, typename Coord>
+__device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
+                                                      const SampleRowSrc<float, kLinear, Coord>& src,
+                                                      const Weights<float, K * K>& wts, float* xp,
+                                                      float* ring, unsigned wave, const Cols& c,
+                                                      int y0, int nrows, bool writer, float* dst) {
+  using G = wave_geom<K, false>;
+  constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
+  constexpr int R = 2 * W;          // ring rows
+  static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
+  const int T = nrows + K - 1;
+  const unsigned lane = threadIdx.x & 63u;
+  unsigned lane4_opaque = 4u * lane;
+  asm volatile("" : "+v"(lane4_opaque));
+  const unsigned voff = 16u * lane, moff = 4u * lane;
+  float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
+  const int yb = y0 - G::H;                          // first input row of the strip
+  const float* mxr = src.coord.mx + ((long)yb * src.coord.pitch + c.xs);
+  const float* myr = src.coord.my + ((long)yb * src.coord.pitch + c.xs);
+  const SrcView& s = src.s;
+  const unsigned long long fb = (unsigned long long)src.fbase;
+  const v4i rs = v4i{(int)(unsigned)fb, (int)((unsigned)(fb >> 32) & 0xffffu), (int)src.src_bytes,
+                     0x00020000};
+  const unsigned pitch_b = (unsigned)s.pitch * 4u;
+  // ring row = {x of pixels lane + 64 k, k = 0..3} for 64 lanes, then the same for y: a lane's
+  // four values are one aligned 16-byte word (conflict-free b128 accesses)
+  float* rlane = ring + 4u * lane;
+
+  // this wave's map row of a block (clamped to the strip) -> pm[k] = x, pm[4 + k] = y
+  float pm[8];
+  auto issue_map = [&](int r) {
+    const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
+    static_for<0, 4>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      pipe_load1<256 * k>(pm[k], moff, mxr + o);
+    });
+    static_for<0, 4>([&](auto Kk) {
+      constexpr int k = decltype(Kk)::value;
+      pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
+    });
+  };
+  auto publish_map = [&](int r) {   // registers -> ring row r mod R (after a wait that covers them)
+    vm_pin(pm);
+    float* slot = rlane + (unsigned)(r % R) * 512u;
+    *reinterpret_cast<v4f*>(slot) = v4f{pm[0], pm[1], pm[2], pm[3]};
+    *reinterpret_cast<v4f*>(slot + 256) = v4f{pm[4], pm[5], pm[6], pm[7]};
+  };
+  // footprints of ring row r: fractions, byte offsets of the top-left taps, interior bits
+  auto footprint = [&](int r, float (&tx)[4], float (&ty)[4], unsigned (&off)[4],
+                       unsigned& interior) {
+    const float* slot = rlane + (unsigned)(r % R) * 512u;
+    const v4f qx = *reinterpret_cast<const v4f*>(slot), qy = *reinterpret_cast<const v4f*>(slot + 256);
+    const float sx[4] = {qx.x, qx.y, qx.z, qx.w}, sy[4] = {qy.x, qy.y, qy.z, qy.w};
+    int e[4];
+    batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
+#pragma unroll
+    for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << 2;
+  };
+
+  float ga[8], gb[8];    // tap rows: [2k], [2k+1] = the two dwords of footprint k
+  float txa[4], tya[4], txb[4], tyb[4];
+  unsigned offa[4], offb[4], ina, inb;
+  v2f acc[K][2];
+
+  // prologue: the rows of block 0 into the ring (row `wave` by this wave), barrier, the loads of
+  // block 1's row issued, row 0 resolved and its gathers in flight
+  issue_map((int)wave);
+  vm_wait<0>();
+  publish_map((int)wave);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring rows are written
+  issue_map(W + (int)wave);
+  footprint(0, txa, tya, offa, ina);
+#pragma unroll
+  for (int k = 0; k < 4; k++) pipe_gather2(ga[2 * k], ga[2 * k + 1], offa[k], rs);
+#pragma unroll
+  for (int k = 0; k < 4; k++) pipe_gather2(gb[2 * k], gb[2 * k + 1], offa[k] + pitch_b, rs);
+
+  // one iteration (row t, step ST = t mod W of its block); TOP / BOT = tap-row registers of row
+  // t; the bottom registers become the top registers of row t + 1
+  auto step = [&](auto St, int t, float (&top)[8], float (&bot)[8], const float (&tx)[4],
+                  const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
+                  float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn) {
+    constexpr int ST = decltype(St)::value;
+    if constexpr (ST == W - 1) {
+      // the block's barrier: behind it the rows of the next block are in the ring and nobody
+      // reads this block's half any more; the next row of this wave is requested at once
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue_map(t + 1 + W + (int)wave);
+    }
+    // 1. the gathers of row t (and everything older): the only younger operations are the
+    //    store of iteration t-1 and, on the last step of a block, the 8 map loads above
+    // (rows past the strip - the last block is filled up - store nothing either)
+    const bool stored = t >= K && t <= T;
+    if constexpr (ST == W - 1) {
+      if (stored) vm_wait<9>();
+      else vm_wait<8>();
+    } else {
+      if (stored) vm_wait<1>();
+      else vm_wait<0>();
+    }
+    vm_pin(top);
+    vm_pin(bot);
+    if constexpr (ST == W - 2) publish_map(t + 2 + (int)wave);  // issued W - 1 iterations ago
+    // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
+    float cur[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const float wx0 = 1.f - tx[k], wx1 = tx[k], wy0 = 1.f - ty[k], wy1 = ty[k];
+      float r0 = wx0 * top[2 * k];
+      r0 = ipa_fma(wx1, top[2 * k + 1], r0);
+      float o = wy0 * r0;
+      float r1 = wx0 * bot[2 * k];
+      r1 = ipa_fma(wx1, bot[2 * k + 1], r1);
+      cur[k] = ipa_fma(wy1, r1, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
+    if (__builtin_amdgcn_ballot_w64(interior != 0xfu)) {
+      // footprints touching the source border (rare): redo them tap by tap, straight into the
+      // LDS row - ONE copy of the border-aware sampler per step (a loop, not unrolled)
+#pragma unroll 1
+      for (int k = 0; k < 4; k++) {
+        if (!((interior >> k) & 1u)) {
+          float sx, sy;
+          src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
+          xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+        }
+      }
+    }
+    // 3. row t + 1: footprints from the ring, its top tap row into `bot` for the lanes whose
+    //    footprint did not move straight down (no instruction at all when there is none), its
+    //    bottom row into `top`
+    footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+#if IPA_PIPE_REUSE
+      const unsigned long long need = __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b);
+      if (need) pipe_gather2_masked(bot[2 * k], bot[2 * k + 1], offn[k], rs, need);
+#else
+      pipe_gather2(bot[2 * k], bot[2 * k + 1], offn[k], rs);
+#endif
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) pipe_gather2(top[2 * k], top[2 * k + 1], offn[k] + pitch_b, rs);
+    __builtin_amdgcn_wave_barrier();
+    // 4. filter + store
+    const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
+    const int o = t - (K - 1);
+    if (o >= 0 && o < nrows) {
+      if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // the loop body is one block (W steps: the tap registers swap roles every step, W is even);
+  // every wave of the workgroup runs the same T, so the barriers match
+  const int Tb = (T + W - 1) / W * W;
+  int tb = 0;
+#pragma unroll 1
+  do {
+    static_for<0, W>([&](auto St) {
+      constexpr int st = decltype(St)::value;
+      if constexpr (st % 2 == 0) step(St, tb + st, ga, gb, txa, tya, offa, ina, txb, tyb, offb, inb);
+      else step(St, tb + st, gb, ga, txb, tyb, offb, inb, txa, tya, offa, ina);
+    });
+    tb += W;
+  } while (tb < Tb);
 }
 
 }  // namespace ipa

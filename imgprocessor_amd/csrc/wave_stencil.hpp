@@ -66,6 +66,12 @@
 #ifndef IPA_PIPE_MIN_WAVES
 #define IPA_PIPE_MIN_WAVES 4
 #endif
+#ifndef IPA_WPB
+#define IPA_WPB 4   // waves per workgroup
+#endif
+#ifndef IPA_PIPE_SHARED
+#define IPA_PIPE_SHARED 1   // frames of a workgroup share their map rows through LDS
+#endif
 
 namespace ipa {
 
@@ -589,9 +595,6 @@ namespace ipa {
 #ifndef IPA_WAVE_MIN_WAVES
 #define IPA_WAVE_MIN_WAVES 1
 #endif
-#ifndef IPA_WPB
-#define IPA_WPB 4   // waves per workgroup
-#endif
 template <typename Src, int K, bool STREAM = false>
 __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
                                                   const Weights<float, K * K>& wts,
@@ -624,6 +627,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   constexpr int kLead = G::H > kRowPad ? 4 : 0;
   __shared__ __attribute__((aligned(16))) float xpose[kLead + IPA_WPB * kXp + kLead];
   float* xp = xpose + kLead + wave * kXp;
+  // map rows shared by the frames of a workgroup (wave_run_strip_shared): a ring of 2 IPA_WPB rows
+  constexpr bool kShared = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && !STREAM && pipe_capable<Src, K>::value &&
+                           Src::kHasQ5;
+  __shared__ __attribute__((aligned(16))) float mapring[kShared ? 2 * IPA_WPB * 512 : 4];
   if (sid >= p.strips) return;  // whole wave
   if (p.skip && p.skip[sid]) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
@@ -649,6 +656,14 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
+    if constexpr (kShared) {
+      // the waves of this workgroup are frames of ONE strip: every wave takes this branch
+      if (p.frames_wg) {
+        if (src.q5) wave_run_strip_shared<K, 1>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        return;
+      }
+    }
     if constexpr (IPA_PIPE && !STREAM && pipe_capable<Src, K>::value) {
       if constexpr (Src::kHasQ5) {
         if (src.q5) wave_run_strip_pipe<K, 1, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
