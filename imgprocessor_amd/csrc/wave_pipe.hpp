@@ -562,6 +562,18 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   float txa[4], tya[4], txb[4], tyb[4];
   unsigned offa[4], offb[4], ina, inb;
   v2f acc[K][2];
+#ifdef IPA_DEBUG_STAMP   // diagnostic build: cycles of the wave by phase (s_memtime), summed per launch
+  unsigned long long st_wait = 0, st_blend = 0, st_issue = 0, st_filter = 0, st_barrier = 0, st_last;
+  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
+#define IPA_STAMP(acc_)                                                  \
+  do {                                                                   \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
+    acc_ += now_ - st_last;                                              \
+    st_last = now_;                                                      \
+  } while (0)
+#else
+#define IPA_STAMP(acc_) do {} while (0)
+#endif
 
   // prologue: the rows of block 0 into the ring (row `wave` by this wave), barrier, the loads of
   // block 1's row issued, row 0 resolved and its gathers in flight
@@ -582,11 +594,15 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                   const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
                   float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn) {
     constexpr int ST = decltype(St)::value;
+#ifdef IPA_DEBUG_STAMP
+    st_last = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (ST == W - 1) {
       // the block's barrier: behind it the rows of the next block are in the ring and nobody
       // reads this block's half any more; the next row of this wave is requested at once
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       issue_map(t + 1 + W + (int)wave);
+      IPA_STAMP(st_barrier);
     }
     // 1. the gathers of row t (and everything older): the only younger operations are the
     //    store of iteration t-1 and, on the last step of a block, the 8 map loads above
@@ -601,6 +617,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     }
     vm_pin(top);
     vm_pin(bot);
+    IPA_STAMP(st_wait);
     if constexpr (ST == W - 2) publish_map(t + 2 + (int)wave);  // issued W - 1 iterations ago
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
     float cur[4];
@@ -628,6 +645,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
         }
       }
     }
+    IPA_STAMP(st_blend);
     // 3. row t + 1: footprints from the ring, its top tap row into `bot` for the lanes whose
     //    footprint did not move straight down (no instruction at all when there is none), its
     //    bottom row into `top`
@@ -644,6 +662,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #pragma unroll
     for (int k = 0; k < 4; k++) pipe_gather2(top[2 * k], top[2 * k + 1], offn[k] + pitch_b, rs);
     __builtin_amdgcn_wave_barrier();
+    IPA_STAMP(st_issue);
     // 4. filter + store
     const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
     const int o = t - (K - 1);
@@ -651,6 +670,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
+    IPA_STAMP(st_filter);
   };
 
   // the loop body is one block (W steps: the tap registers swap roles every step, W is even);
@@ -666,6 +686,15 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     });
     tb += W;
   } while (tb < Tb);
+#ifdef IPA_DEBUG_STAMP
+  if (p.dbg && lane == 0) {
+    const unsigned long long total = __builtin_amdgcn_s_memtime() - st_begin;
+    atomicAdd(p.dbg + 0, st_wait); atomicAdd(p.dbg + 1, st_blend); atomicAdd(p.dbg + 2, st_issue);
+    atomicAdd(p.dbg + 3, st_filter); atomicAdd(p.dbg + 4, st_barrier); atomicAdd(p.dbg + 5, total);
+    atomicAdd(p.dbg + 6, 1ull); atomicAdd(p.dbg + 7, (unsigned long long)Tb);
+  }
+#endif
+#undef IPA_STAMP
 }
 
 }  // namespace ipa

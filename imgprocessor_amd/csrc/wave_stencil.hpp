@@ -127,6 +127,7 @@ struct WaveParams {
   // strips another kernel computes (ring_stencil.hpp): skip[strip] != 0 -> nothing to do here
   const unsigned* skip = nullptr;
   int rim_only = 0;    // 1: the interior (FAST) strips belong to another kernel (wave_split.hpp)
+  unsigned long long* dbg = nullptr;  // -DIPA_DEBUG_STAMP builds: per-phase cycle sums
   int frames_wg = 0;   // 1: the waves of a workgroup are consecutive FRAMES of one strip - the strip's
                        // map rows then reach the CU's L1 once per workgroup instead of once per
                        // frame (64 x 4K fused 5x5: 1.361 -> 1.335 ms); set by wave_grid
