@@ -423,7 +423,6 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);   // (phases kept apart: interleaved they need more registers)
     // 3. gathers of row t + 1: its top row into `bot` under the mask of the lanes whose
     //    footprint did not move straight down, its bottom row into `top`
 #pragma unroll
@@ -438,7 +437,6 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     }
     gather_row(top, offn, pitch_b);
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);
     // 4. filter + store
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
     const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
@@ -450,7 +448,6 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_sched_barrier(0);
     // 5. map row t + 2: younger = gathers(t+1) [kTapOps] + this iteration's store
     if (t >= K - 1) vm_wait<kTapOps + 1>();
     else vm_wait<kTapOps>();
@@ -600,7 +597,9 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (ST == W - 1) {
       // the block's barrier: behind it the rows of the next block are in the ring and nobody
       // reads this block's half any more; the next row of this wave is requested at once
+#ifndef IPA_DEBUG_NO_BARRIER   // (measurement only: racy without it)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
       issue_map(t + 1 + W + (int)wave);
       IPA_STAMP(st_barrier);
     }
