@@ -648,7 +648,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     // 3. row t + 1: footprints from the ring, its top tap row into `bot` for the lanes whose
     //    footprint did not move straight down (no instruction at all when there is none), its
     //    bottom row into `top`
+#ifdef IPA_DEBUG_NO_FOOTPRINT   // measurement only (WRONG results): the footprint moves straight down
+#pragma unroll
+    for (int k = 0; k < 4; k++) { txn[k] = tx[k]; tyn[k] = ty[k]; offn[k] = off[k] + pitch_b; }
+    interiorn = 0xfu;
+#else
     footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
+#endif
 #pragma unroll
     for (int k = 0; k < 4; k++) {
 #if IPA_PIPE_REUSE
@@ -663,7 +669,11 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     __builtin_amdgcn_wave_barrier();
     IPA_STAMP(st_issue);
     // 4. filter + store
+#ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
+    const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
+#else
     const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
+#endif
     const int o = t - (K - 1);
     if (o >= 0 && o < nrows) {
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);

@@ -631,7 +631,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   // map rows shared by the frames of a workgroup (wave_run_strip_shared): a ring of 2 IPA_WPB rows
   constexpr bool kShared = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && !STREAM && pipe_capable<Src, K>::value &&
                            Src::kHasQ5;
-  __shared__ __attribute__((aligned(16))) float mapring[kShared ? 2 * IPA_WPB * 512 : 4];
+#ifndef IPA_DEBUG_LDS_PAD
+#define IPA_DEBUG_LDS_PAD 0   // measurement only: extra LDS floats per workgroup (lowers the occupancy)
+#endif
+  __shared__ __attribute__((aligned(16))) float mapring[(kShared ? 2 * IPA_WPB * 512 : 4) + IPA_DEBUG_LDS_PAD];
   if (sid >= p.strips) return;  // whole wave
   if (p.skip && p.skip[sid]) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
