@@ -727,8 +727,17 @@ wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
 // problems enough waves to fill 256 CUs
 static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_frames, int K,
-                                    bool fma_bound = false) {
+                                    bool fma_bound = false, int piped = 0) {
   if (ctx->tune.strip_h > 0) return ctx->tune.strip_h;  // tuning knob
+  // the hand-scheduled kernels of round 3 (wave_pipe.hpp) have no chunk overshoot and want more,
+  // shorter strips - the tail of the launch's last round of waves weighs more than 4 halo rows:
+  // 64 x 4K, one box: plain 5x5 (piped = 1) 72 rows 0.903, 48 0.866, 32 0.855 ms; fused
+  // undistort + 5x5 on shared map rows (piped = 2) 72 rows 1.305, 48 1.261, 36 1.251, 24 1.272
+  if (piped) {
+    long sx = (dw + 255) / 256;
+    const int want = piped == 2 ? 36 : 32;
+    if (sx * ((dh + want - 1) / want) * n_frames >= 8192) return want;
+  }
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
   long sx = (dw + ow - 1) / ow;
   // measured on 4K frames (MI355X, 4096 resident waves): with 16 frames 16-48 rows are within
