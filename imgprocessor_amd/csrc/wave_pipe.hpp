@@ -496,7 +496,7 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 // store), whatever was issued - so a top-row gather whose EXEC mask is empty is branched over
 // instead of issued (43 % of them on the 4K lens map).
 // Same footprints, same words, same blend as wave_run_strip_pipe: identical bits.
-template <int K, int QM, typename Coord>
+template <int K, int QM, bool EDGE, typename Coord>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       const SampleRowSrc<float, kLinear, Coord>& src,
                                                       const Weights<float, K * K>& wts, float* xp,
@@ -513,8 +513,15 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned voff = 16u * lane, moff = 4u * lane;
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
   const int yb = y0 - G::H;                          // first input row of the strip
-  const float* mxr = src.coord.mx + ((long)yb * src.coord.pitch + c.xs);
-  const float* myr = src.coord.my + ((long)yb * src.coord.pitch + c.xs);
+  // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
+  // filter's border mode per lane (c.uq, -1 = constant border), its rows per row on the scalar
+  // unit; interior strips address the map rows as base + 4 lane + 256 k
+  const float* mxr = src.coord.mx + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
+  const float* myr = src.coord.my + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
+  auto row_of = [&](int t) -> int {   // resolved input row of strip row t (-1 = constant border)
+    if constexpr (EDGE) return resolve_idx(yb + t, p.dh, p.cby);
+    else return yb + t;
+  };
   const SrcView& s = src.s;
   const unsigned long long fb = (unsigned long long)src.fbase;
   const v4i rs = v4i{(int)(unsigned)fb, (int)((unsigned)(fb >> 32) & 0xffffu), (int)src.src_bytes,
@@ -527,15 +534,24 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   // this wave's map row of a block (clamped to the strip) -> pm[k] = x, pm[4 + k] = y
   float pm[8];
   auto issue_map = [&](int r) {
-    const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
-    static_for<0, 4>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      pipe_load1<256 * k>(pm[k], moff, mxr + o);
-    });
-    static_for<0, 4>([&](auto Kk) {
-      constexpr int k = decltype(Kk)::value;
-      pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
-    });
+    if constexpr (EDGE) {
+      const int rr = row_of(r < T ? r : T - 1);
+      const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
+#pragma unroll
+      for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
+#pragma unroll
+      for (int k = 0; k < 4; k++) pipe_load1<0>(pm[4 + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
+    } else {
+      const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
+      static_for<0, 4>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        pipe_load1<256 * k>(pm[k], moff, mxr + o);
+      });
+      static_for<0, 4>([&](auto Kk) {
+        constexpr int k = decltype(Kk)::value;
+        pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
+      });
+    }
   };
   auto publish_map = [&](int r) {   // registers -> ring row r mod R (after a wait that covers them)
     vm_pin(pm);
@@ -630,6 +646,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       r1 = ipa_fma(wx1, bot[2 * k + 1], r1);
       cur[k] = ipa_fma(wy1, r1, o);
     }
+    int rowt = 0;   // EDGE: resolved row of this strip row
+    if constexpr (EDGE) {
+      rowt = row_of(t < T ? t : T - 1);
+      // positions the filter's constant border supplies
+#pragma unroll
+      for (int k = 0; k < 4; k++) cur[k] = (rowt < 0 || c.uq[k] < 0) ? src.ccval : cur[k];
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
     if (__builtin_amdgcn_ballot_w64(interior != 0xfu)) {
@@ -639,8 +662,16 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       for (int k = 0; k < 4; k++) {
         if (!((interior >> k) & 1u)) {
           float sx, sy;
-          src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
-          xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+          if constexpr (EDGE) {
+            // (the column is resolved again: c.uq[k] with a run-time k would live in scratch)
+            const int uqk = resolve_idx(c.xs + (int)lane + 64 * k, p.dw, p.cbx);
+            src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
+            if (!(rowt < 0 || uqk < 0))
+              xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+          } else {
+            src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
+            xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+          }
         }
       }
     }

@@ -69,6 +69,9 @@
 #ifndef IPA_WPB
 #define IPA_WPB 4   // waves per workgroup
 #endif
+#ifndef IPA_PIPE_EDGE
+#define IPA_PIPE_EDGE 1     // ... the rim strips of such a launch too (columns / rows resolved)
+#endif
 #ifndef IPA_PIPE_SHARED
 #define IPA_PIPE_SHARED 1   // frames of a workgroup share their map rows through LDS
 #endif
@@ -663,8 +666,8 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     if constexpr (kShared) {
       // the waves of this workgroup are frames of ONE strip: every wave takes this branch
       if (p.frames_wg) {
-        if (src.q5) wave_run_strip_shared<K, 1>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, false>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }
@@ -687,6 +690,15 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     for (int k = 0; k < 4; k++) {
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
+    }
+    if constexpr (kShared) {
+      // (vector alignment holds: the strip runs on the shared-map loop with its columns and
+      // rows resolved through the filter's border mode; 15 % of a 4K frame's strips)
+      if (p.frames_wg && src.vectors_ok() && p.vec_out && IPA_PIPE_EDGE) {
+        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        return;
+      }
     }
     if constexpr (HALO)
       c.uh = resolve_idx(xs - G::H + (int)halo_pos<G::H>(lane < 2 * G::H ? (unsigned)lane : 0u), p.dw, p.cbx);
