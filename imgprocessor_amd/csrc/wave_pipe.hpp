@@ -173,32 +173,49 @@ __device__ __forceinline__ v4f pipe_filter_row(const Weights<float, K * K>& wts,
 }
 
 // ------------------------------------------------------------------ plain rows --
-template <int K, bool HALO>
+// EDGE: a strip on the rim of the image - its columns are resolved through the filter's border
+// mode per lane (c.uu / c.uh, -1 = constant border) and loaded as dwords, its rows per row on
+// the scalar unit; interior strips load a row as one float4 per lane (+ the halo dword).
+template <int K, bool HALO, bool EDGE>
 __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const LoadRowSrc& src,
                                                     const Weights<float, K * K>& wts, float* xp,
                                                     const Cols& c, int y0, int nrows, bool writer,
                                                     float* dst) {
   using G = wave_geom<K, HALO>;
   constexpr int P = IPA_PIPE_ROWS;
-  constexpr int OPS = HALO ? 2 : 1;   // loads per row: the row + (HALO) its 2 H halo pixels
+  // loads per row: the row (one float4, EDGE: four dwords) + (HALO) its 2 H halo pixels
+  constexpr int OPS = (EDGE ? 4 : 1) + (HALO ? 1 : 0);
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
   unsigned lane4_opaque = 4u * lane;
   asm volatile("" : "+v"(lane4_opaque));
   const unsigned voff = 16u * lane;
-  const float* rows = src.base + ((long)(y0 - G::H) * src.pitch + c.xs);  // scalar: input row 0
-  float* outs = dst + ((long)y0 * p.dpitch + c.xs);                      // scalar: output row 0
+  const int yb = y0 - G::H;
+  const float* rows = src.base + (EDGE ? 0 : (long)yb * src.pitch + c.xs);  // scalar
+  float* outs = dst + ((long)y0 * p.dpitch + c.xs);                          // scalar: output row 0
   // HALO: lane j < 2H supplies the pixel H - j left of the strip / j - H right of it
-  const unsigned hoff = 4u * halo_pos<G::H>(lane);     // bytes from (row - H floats)
+  const unsigned hoff = EDGE ? 4u * (unsigned)(c.uh < 0 ? 0 : c.uh) : 4u * halo_pos<G::H>(lane);
   const unsigned long long hmask = (1ull << (2 * G::H)) - 1ull;
-  v4f buf[P];
+  auto row_of = [&](int t) -> int {   // resolved input row of strip row t (-1 = constant border)
+    if constexpr (EDGE) return resolve_idx(yb + t, p.dh, p.cby);
+    else return t;
+  };
+  float buf[P][4];   // EDGE: the row as four dwords
+  v4f bufv[P];       // interior: the row as one float4 (only one of the two forms is live)
   float hb[P] = {};
-  static_for<0, P>([&](auto U) {
-    constexpr int u = decltype(U)::value;
-    const float* r = rows + (long)(u < T ? u : T - 1) * src.pitch;
-    pipe_load4(buf[u], voff, r);
-    if constexpr (HALO) pipe_load1_masked<0>(hb[u], hoff, r - G::H, hmask);
-  });
+  auto issue = [&](float (&b)[4], v4f& bv, float& h, int t) {
+    const int rr = row_of(t < T ? t : T - 1);
+    const float* r = rows + (long)(rr < 0 ? 0 : rr) * src.pitch;
+    if constexpr (EDGE) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) pipe_load1<0>(b[k], 4u * (unsigned)(c.uu[k] < 0 ? 0 : c.uu[k]), r);
+      if constexpr (HALO) pipe_load1_masked<0>(h, hoff, r, hmask);
+    } else {
+      pipe_load4(bv, voff, r);
+      if constexpr (HALO) pipe_load1_masked<0>(h, hoff, r - G::H, hmask);
+    }
+  };
+  static_for<0, P>([&](auto U) { constexpr int u = decltype(U)::value; issue(buf[u], bufv[u], hb[u], u); });
   v2f acc[K][2];
   int tb = 0;
 #pragma unroll 1
@@ -211,16 +228,27 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const L
         // iterations t-P .. t-1 (iteration j stores when j >= K - 1)
         if (t >= P + K - 1) vm_wait<OPS * (P - 1) + P>();
         else vm_wait<OPS * (P - 1)>();
-        vm_pin(buf[u]);
-        *reinterpret_cast<v4f*>(xp + kRowPad + 4u * lane) = buf[u];
-        if constexpr (HALO) {
-          vm_pin(hb[u]);
-          if (lane < 2u * G::H) xp[kRowPad - G::H + halo_pos<G::H>(lane)] = hb[u];
+        float v[4];
+        if constexpr (EDGE) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) { vm_pin(buf[u][k]); v[k] = buf[u][k]; }
+        } else {
+          vm_pin(bufv[u]);
+          v[0] = bufv[u].x; v[1] = bufv[u].y; v[2] = bufv[u].z; v[3] = bufv[u].w;
         }
-        const int tn = t + P < T ? t + P : T - 1;
-        const float* r = rows + (long)tn * src.pitch;
-        pipe_load4(buf[u], voff, r);
-        if constexpr (HALO) pipe_load1_masked<0>(hb[u], hoff, r - G::H, hmask);
+        float hv = 0.f;
+        if constexpr (HALO) { vm_pin(hb[u]); hv = hb[u]; }
+        if constexpr (EDGE) {   // positions the constant border supplies
+          const int rr = row_of(t);
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = (rr < 0 || c.uu[k] < 0) ? src.cval : v[k];
+          hv = (rr < 0 || c.uh < 0) ? src.cval : hv;
+        }
+        *reinterpret_cast<v4f*>(xp + kRowPad + 4u * lane) = v4f{v[0], v[1], v[2], v[3]};
+        if constexpr (HALO) {
+          if (lane < 2u * G::H) xp[kRowPad - G::H + halo_pos<G::H>(lane)] = hv;
+        }
+        issue(buf[u], bufv[u], hb[u], t + P);
         __builtin_amdgcn_wave_barrier();
         const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
         const int o = t - (K - 1);

@@ -676,7 +676,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
         if (src.q5) wave_run_strip_pipe<K, 1, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
         else wave_run_strip_pipe<K, 0, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
       } else {
-        wave_run_strip_pipe<K, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        wave_run_strip_pipe<K, HALO, false>(p, src, wts, xp, c, y0, nrows, writer, dst);
       }
     } else if constexpr (Src::kHasQ5) {
       // wave-uniform choice hoisted out of the per-sample code
@@ -694,7 +694,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     if constexpr (kShared) {
       // (vector alignment holds: the strip runs on the shared-map loop with its columns and
       // rows resolved through the filter's border mode; 15 % of a 4K frame's strips)
-      if (p.frames_wg && src.vectors_ok() && p.vec_out && IPA_PIPE_EDGE) {
+      if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
         else wave_run_strip_shared<K, 0, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
@@ -702,6 +702,13 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     }
     if constexpr (HALO)
       c.uh = resolve_idx(xs - G::H + (int)halo_pos<G::H>(lane < 2 * G::H ? (unsigned)lane : 0u), p.dw, p.cbx);
+    if constexpr (HALO && !Src::kHasQ5 && IPA_PIPE_EDGE) {
+      // plain rows: the rim strips on the hand-scheduled loop too (resolved columns and rows)
+      if (p.vec_out && (p.dw & 3) == 0) {
+        wave_run_strip_pipe<K, HALO, true>(p, src, wts, xp, c, y0, nrows, writer, dst);
+        return;
+      }
+    }
     wave_run_strip<false, Src, K, -1, STREAM, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst, wk);
   }
 }
