@@ -19,6 +19,8 @@ struct ipa_tuning {
   int strip_h = 0;        // rows per strip of the marching kernels (0: by launch size)
   int frames_inner = 1;   // batches dispatched strip by strip (frames of a strip adjacent)
   int frames_wg = 1;      // map-based fused kernels: the waves of a workgroup are frames of ONE strip
+  int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
+                          // XCD streaming through frames of its own
   int big_wave = 1;       // 9x9 / 11x11 filter on the marching wave (0: LDS-tiled kernel)
   int big_fused = 1;      // remap -> 7x7 / 9x9 / 11x11 in one kernel
   int stream_k = 7;       // smallest K whose coefficients are streamed through SGPRs

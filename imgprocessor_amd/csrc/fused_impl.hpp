@@ -142,7 +142,7 @@ int IPA_CAT(ipa_wave_conv_launch_k, IPA_FUSED_K)(ipa_ctx* ctx, const ipa::WavePa
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false,
                                 pipe_capable<LoadRowSrc, K>::value && IPA_PIPE ? 1 : 0);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid = wave_grid(ctx, p, n_frames, IPA_WPB, true), block(64 * IPA_WPB);
+  dim3 grid = wave_grid(ctx, p, n_frames, IPA_WPB, true, false, true), block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_kernel<LoadRowSrc, K>), grid, block, 0, ctx->stream, p, src, w);
   return IPA_OK;
 }

@@ -131,6 +131,10 @@ struct WaveParams {
   const unsigned* skip = nullptr;
   int rim_only = 0;    // 1: the interior (FAST) strips belong to another kernel (wave_split.hpp)
   unsigned long long* dbg = nullptr;  // -DIPA_DEBUG_STAMP builds: per-phase cycle sums
+  unsigned frame_major = 0;  // n > 0: 1-D grid of n blocks per frame, frame after frame - with the
+                             // XCD-contiguous block order every XCD then streams through whole
+                             // frames of its own (plain filters: no rows shared between frames;
+                             // tools/pipe_micro.hip order 1: 835 -> 775 us per 64 x 4K copy)
   int frames_wg = 0;   // 1: the waves of a workgroup are consecutive FRAMES of one strip - the strip's
                        // map rows then reach the CU's L1 once per workgroup instead of once per
                        // frame (64 x 4K fused 5x5: 1.361 -> 1.335 ms); set by wave_grid
@@ -139,10 +143,18 @@ struct WaveParams {
 // grid for a launch over n_frames; fills p.frames_inner
 // share_maps: the row source reads a coordinate table the frames of a batch share (MapCoord)
 static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, int waves_per_block,
-                             bool frames_inner, bool share_maps = false) {
+                             bool frames_inner, bool share_maps = false,
+                             bool may_frame_major = false) {
   unsigned blocks = (p.strips + waves_per_block - 1) / waves_per_block;
   frames_inner = frames_inner && ctx->tune.frames_inner != 0;
   p.frames_wg = 0;
+  p.frame_major = 0;
+  if (may_frame_major && !share_maps && ctx->tune.frame_major != 0 && n_frames > 1 &&
+      (unsigned long)blocks * n_frames < (1ul << 31)) {
+    p.frames_inner = 0;
+    p.frame_major = blocks;
+    return dim3(blocks * (unsigned)n_frames, 1);
+  }
   if (frames_inner && share_maps && ctx->tune.frames_wg != 0 && n_frames % waves_per_block == 0 &&
       (unsigned long)p.strips * n_frames < (1ul << 31)) {
     p.frames_inner = n_frames;
@@ -612,7 +624,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   // neighbours in the (XCD-contiguous) order, so they run at the same time on the same XCD and
   // the read-only rows they share (the remap's map rows) are fetched into that L2 once.
   unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
-  if (p.frames_inner) {
+  if (p.frame_major) {
+    frame = b / p.frame_major;
+    b -= frame * p.frame_major;
+  } else if (p.frames_inner) {
     frame = b % (unsigned)p.frames_inner;
     b /= (unsigned)p.frames_inner;
   }
