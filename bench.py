@@ -468,9 +468,11 @@ def main():
                          'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
                          'compulsory_bytes_per_step': compulsory,
-                         'limiter': 'vector-memory path of the CU, not HBM: texture addresser busy '
-                                    '74 %, and a wave\'s map loads, gathers and stores complete '
-                                    'one after the other (DESIGN.md section 5)',
+                         'limiter': 'the streaming rate of the marching-strip launch shape (a plain '
+                                    '5x5 on the same skeleton runs at 5.8 TB/s) plus the gathers: '
+                                    'a vector-memory instruction costs the CU ~4.6 clocks whatever '
+                                    'its EXEC mask (DESIGN.md section 5); HBM is the roofline the '
+                                    'compulsory bytes are priced against, not what saturates',
                          'kernel': kname, 'launches_per_step': launches,
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
                          'literal_survey_8d': {

@@ -763,14 +763,23 @@ wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
 static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_frames, int K,
                                     bool fma_bound = false, int piped = 0) {
   if (ctx->tune.strip_h > 0) return ctx->tune.strip_h;  // tuning knob
-  // the hand-scheduled kernels of round 3 (wave_pipe.hpp) have no chunk overshoot and want more,
-  // shorter strips - the tail of the launch's last round of waves weighs more than 4 halo rows:
-  // 64 x 4K, one box: plain 5x5 (piped = 1) 72 rows 0.903, 48 0.866, 32 0.855 ms; fused
-  // undistort + 5x5 on shared map rows (piped = 2) 72 rows 1.305, 48 1.261, 36 1.251, 24 1.272
+  // the hand-scheduled kernels of round 3 (wave_pipe.hpp; their rim strips run on the fast loop
+  // too).  Plain filters (piped = 1) want many short strips - the tail of the launch's last
+  // round of waves weighs more than the K - 1 halo rows: 64 x 4K 5x5, one box: 72 rows 0.738,
+  // 48 0.740, 24 0.729 ms; 16 x 4K: 72 0.208, 36 0.199, 24 0.195.  The fused undistort + filter
+  // on shared map rows (piped = 2) wants tall ones (every strip start costs a barrier-separated
+  // prologue of dependent loads): 64 x 4K: 36 rows 1.066, 72 1.042, 108 1.031, 144 1.024 ms;
+  // 16 x 4K: 24 0.296, 48 0.286, 72 0.283
   if (piped) {
-    long sx = (dw + 255) / 256;
-    const int want = piped == 2 ? 36 : 32;
-    if (sx * ((dh + want - 1) / want) * n_frames >= 8192) return want;
+    const long sx = (dw + 255) / 256;
+    const int cand2[4] = {144, 72, 48, 32};
+    const long need2[4] = {12288, 6144, 4096, 0};
+    if (piped == 2) {
+      for (int i = 0; i < 4; i++)
+        if (sx * ((dh + cand2[i] - 1) / cand2[i]) * n_frames >= need2[i]) return cand2[i];
+    } else if (sx * ((dh + 23) / 24) * n_frames >= 8192) {
+      return 24;
+    }
   }
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
   long sx = (dw + ow - 1) / ow;
