@@ -19,6 +19,7 @@ struct ipa_tuning {
   int strip_h = 0;        // rows per strip of the marching kernels (0: by launch size)
   int frames_inner = 1;   // batches dispatched strip by strip (frames of a strip adjacent)
   int frames_wg = 1;      // map-based fused kernels: the waves of a workgroup are frames of ONE strip
+  int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
   int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
                           // XCD streaming through frames of its own
   int big_wave = 1;       // 9x9 / 11x11 filter on the marching wave (0: LDS-tiled kernel)

@@ -72,6 +72,7 @@ const TuneName kTuneNames[] = {
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
+    {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
     {"ring_big", "IPA_RING_BIG", &ipa_tuning::ring_big},
     {"pair", "IPA_PAIR", &ipa_tuning::pair},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},

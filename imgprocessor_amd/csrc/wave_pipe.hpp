@@ -108,6 +108,20 @@ __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v
                : "=v"(a), "=v"(b)
                : "v"(off), "s"(rs));
 }
+// one dword (uint16 frames: both taps of a bilinear tap row)
+__device__ __forceinline__ void pipe_gather1(float& a, unsigned off, v4i rs) {
+  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+}
+__device__ __forceinline__ void pipe_gather1_masked(float& a, unsigned off, v4i rs,
+                                                    unsigned long long m) {
+  unsigned long long sv;
+  asm volatile("s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, %4\n\t"
+               "buffer_load_dword %0, %2, %3, 0 offen\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(a), "=&s"(sv)
+               : "v"(off), "s"(rs), "s"(m));
+}
 // the same under an EXEC mask: lanes outside `m` keep a and b
 __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned off, v4i rs,
                                                     unsigned long long m) {
@@ -266,8 +280,15 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p, const L
 // float32 frames, bilinear, coordinates from a table (the maps of LensDistortion.correct)
 template <typename Src, int K> struct pipe_capable : std::false_type {};
 template <int K> struct pipe_capable<LoadRowSrc, K> : std::true_type {};
-template <typename Coord, int K> struct pipe_capable<SampleRowSrc<float, kLinear, Coord>, K> {
-  static constexpr bool value = SampleRowSrc<float, kLinear, Coord>::template depth<K>::kPiped;
+template <typename ST, typename Coord, int K> struct pipe_capable<SampleRowSrc<ST, kLinear, Coord>, K> {
+  static constexpr bool value = SampleRowSrc<ST, kLinear, Coord>::template depth<K>::kPiped;
+};
+// ... of which the FAST strips of launches that do NOT share map rows (single frames, batches
+// that are no multiple of IPA_WPB) run on wave_run_strip_pipe (float32 frames only)
+template <typename Src, int K> struct pipe_unshared : std::false_type {};
+template <int K> struct pipe_unshared<LoadRowSrc, K> : std::true_type {};
+template <typename Coord, int K> struct pipe_unshared<SampleRowSrc<float, kLinear, Coord>, K> {
+  static constexpr bool value = pipe_capable<SampleRowSrc<float, kLinear, Coord>, K>::value;
 };
 // which kernels take the 256-px aligned strip geometry with a halo pass: the plain filter
 // (one extra EXEC-masked load per row: 64 x 4K 5x5 0.97 -> 0.90 ms, 0.85 with 32-row strips).
@@ -524,13 +545,18 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 // store), whatever was issued - so a top-row gather whose EXEC mask is empty is branched over
 // instead of issued (43 % of them on the 4K lens map).
 // Same footprints, same words, same blend as wave_run_strip_pipe: identical bits.
-template <int K, int QM, bool EDGE, typename Coord>
+template <int K, int QM, bool EDGE, typename ST, typename Coord>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
-                                                      const SampleRowSrc<float, kLinear, Coord>& src,
+                                                      const SampleRowSrc<ST, kLinear, Coord>& src,
                                                       const Weights<float, K * K>& wts, float* xp,
                                                       float* ring, unsigned wave, const Cols& c,
                                                       int y0, int nrows, bool writer, float* dst) {
   using G = wave_geom<K, false>;
+  // registers per tap row of a footprint: float32 frames two dwords, uint16 frames ONE dword that
+  // holds both taps (any byte offset, as TapLoad<uint16_t, float> loads it)
+  constexpr int NR = sizeof(ST) == 4 ? 2 : 1;
+  constexpr int SH = sizeof(ST) == 4 ? 2 : 1;   // log2 of the element size
+  static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value, "float32 / uint16 frames");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
   constexpr int R = 2 * W;          // ring rows
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
@@ -554,7 +580,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned long long fb = (unsigned long long)src.fbase;
   const v4i rs = v4i{(int)(unsigned)fb, (int)((unsigned)(fb >> 32) & 0xffffu), (int)src.src_bytes,
                      0x00020000};
-  const unsigned pitch_b = (unsigned)s.pitch * 4u;
+  const unsigned pitch_b = (unsigned)s.pitch << SH;
   // ring row = {x of pixels lane + 64 k, k = 0..3} for 64 lanes, then the same for y: a lane's
   // four values are one aligned 16-byte word (conflict-free b128 accesses)
   float* rlane = ring + 4u * lane;
@@ -596,10 +622,27 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     int e[4];
     batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
 #pragma unroll
-    for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << 2;
+    for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << SH;
+  };
+  // the tap row of footprint k at byte offset o -> g[NR k .. NR k + NR - 1]
+  auto gather = [&](float (&g)[4 * NR], int k, unsigned o) {
+    if constexpr (NR == 2) pipe_gather2(g[2 * k], g[2 * k + 1], o, rs);
+    else pipe_gather1(g[k], o, rs);
+  };
+  auto gather_masked = [&](float (&g)[4 * NR], int k, unsigned o, unsigned long long m) {
+    if constexpr (NR == 2) pipe_gather2_masked(g[2 * k], g[2 * k + 1], o, rs, m);
+    else pipe_gather1_masked(g[k], o, rs, m);
+  };
+  auto pin_taps = [&](float (&g)[4 * NR]) {
+#pragma unroll
+    for (int k = 0; k < 4 * NR; k++) vm_pin(g[k]);
+  };
+  auto taps_of = [&](const float (&g)[4 * NR], int k, float& v0, float& v1) {
+    if constexpr (NR == 2) { v0 = g[2 * k]; v1 = g[2 * k + 1]; }
+    else TapLoad<uint16_t, float>::unpack(__float_as_uint(g[k]), v0, v1);
   };
 
-  float ga[8], gb[8];    // tap rows: [2k], [2k+1] = the two dwords of footprint k
+  float ga[4 * NR], gb[4 * NR];    // tap rows of the footprints (see NR)
   float txa[4], tya[4], txb[4], tyb[4];
   unsigned offa[4], offb[4], ina, inb;
   v2f acc[K][2];
@@ -625,20 +668,20 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   issue_map(W + (int)wave);
   footprint(0, txa, tya, offa, ina);
 #pragma unroll
-  for (int k = 0; k < 4; k++) pipe_gather2(ga[2 * k], ga[2 * k + 1], offa[k], rs);
+  for (int k = 0; k < 4; k++) gather(ga, k, offa[k]);
 #pragma unroll
-  for (int k = 0; k < 4; k++) pipe_gather2(gb[2 * k], gb[2 * k + 1], offa[k] + pitch_b, rs);
+  for (int k = 0; k < 4; k++) gather(gb, k, offa[k] + pitch_b);
 
   // one iteration (row t, step ST = t mod W of its block); TOP / BOT = tap-row registers of row
   // t; the bottom registers become the top registers of row t + 1
-  auto step = [&](auto St, int t, float (&top)[8], float (&bot)[8], const float (&tx)[4],
+  auto step = [&](auto St, int t, float (&top)[4 * NR], float (&bot)[4 * NR], const float (&tx)[4],
                   const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
                   float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn) {
-    constexpr int ST = decltype(St)::value;
+    constexpr int STEP = decltype(St)::value;
 #ifdef IPA_DEBUG_STAMP
     st_last = __builtin_amdgcn_s_memtime();
 #endif
-    if constexpr (ST == W - 1) {
+    if constexpr (STEP == W - 1) {
       // the block's barrier: behind it the rows of the next block are in the ring and nobody
       // reads this block's half any more; the next row of this wave is requested at once
 #ifndef IPA_DEBUG_NO_BARRIER   // (measurement only: racy without it)
@@ -651,27 +694,30 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     //    store of iteration t-1 and, on the last step of a block, the 8 map loads above
     // (rows past the strip - the last block is filled up - store nothing either)
     const bool stored = t >= K && t <= T;
-    if constexpr (ST == W - 1) {
+    if constexpr (STEP == W - 1) {
       if (stored) vm_wait<9>();
       else vm_wait<8>();
     } else {
       if (stored) vm_wait<1>();
       else vm_wait<0>();
     }
-    vm_pin(top);
-    vm_pin(bot);
+    pin_taps(top);
+    pin_taps(bot);
     IPA_STAMP(st_wait);
-    if constexpr (ST == W - 2) publish_map(t + 2 + (int)wave);  // issued W - 1 iterations ago
+    if constexpr (STEP == W - 2) publish_map(t + 2 + (int)wave);  // issued W - 1 iterations ago
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
     float cur[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const float wx0 = 1.f - tx[k], wx1 = tx[k], wy0 = 1.f - ty[k], wy1 = ty[k];
-      float r0 = wx0 * top[2 * k];
-      r0 = ipa_fma(wx1, top[2 * k + 1], r0);
+      float v00, v01, v10, v11;
+      taps_of(top, k, v00, v01);
+      taps_of(bot, k, v10, v11);
+      float r0 = wx0 * v00;
+      r0 = ipa_fma(wx1, v01, r0);
       float o = wy0 * r0;
-      float r1 = wx0 * bot[2 * k];
-      r1 = ipa_fma(wx1, bot[2 * k + 1], r1);
+      float r1 = wx0 * v10;
+      r1 = ipa_fma(wx1, v11, r1);
       cur[k] = ipa_fma(wy1, r1, o);
     }
     int rowt = 0;   // EDGE: resolved row of this strip row
@@ -695,10 +741,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             const int uqk = resolve_idx(c.xs + (int)lane + 64 * k, p.dw, p.cbx);
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
             if (!(rowt < 0 || uqk < 0))
-              xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+              xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, float>(s, sx, sy, src.cval);
           } else {
             src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
-            xp[kRowPad + 64u * k + lane] = sample<float, kLinear, float>(s, sx, sy, src.cval);
+            xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, float>(s, sx, sy, src.cval);
           }
         }
       }
@@ -718,13 +764,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     for (int k = 0; k < 4; k++) {
 #if IPA_PIPE_REUSE
       const unsigned long long need = __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b);
-      if (need) pipe_gather2_masked(bot[2 * k], bot[2 * k + 1], offn[k], rs, need);
+      if (need) gather_masked(bot, k, offn[k], need);
 #else
-      pipe_gather2(bot[2 * k], bot[2 * k + 1], offn[k], rs);
+      gather(bot, k, offn[k]);
 #endif
     }
 #pragma unroll
-    for (int k = 0; k < 4; k++) pipe_gather2(top[2 * k], top[2 * k + 1], offn[k] + pitch_b, rs);
+    for (int k = 0; k < 4; k++) gather(top, k, offn[k] + pitch_b);
     __builtin_amdgcn_wave_barrier();
     IPA_STAMP(st_issue);
     // 4. filter + store

@@ -63,6 +63,9 @@
 #ifndef IPA_PIPE
 #define IPA_PIPE 1   // FAST strips on the hand-scheduled memory pipeline of wave_pipe.hpp
 #endif
+#ifndef IPA_PIPE_MAX_K
+#define IPA_PIPE_MAX_K 7   // largest K of the hand-scheduled sampling kernels (resident coefficients)
+#endif
 #ifndef IPA_PIPE_MIN_WAVES
 #define IPA_PIPE_MIN_WAVES 4
 #endif
@@ -277,8 +280,10 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #endif
     // float32 frames sampled bilinearly from a coordinate table run their FAST strips on
     // wave_pipe.hpp for K <= 5 (K = 7 streams its coefficients: wave_stencil_big_kernel); the chunked loop is then the rim strips only: depth 1
-    static constexpr bool kPiped = IPA_PIPE && K <= 5 && INTERP == kLinear &&
-                                   std::is_same<ST, float>::value && coord_is_table<Coord>::value;
+    static constexpr bool kPiped = IPA_PIPE && K <= IPA_PIPE_MAX_K && INTERP == kLinear &&
+                                   (std::is_same<ST, float>::value ||
+                                    std::is_same<ST, uint16_t>::value) &&
+                                   coord_is_table<Coord>::value;
     static constexpr int value =
         INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kPiped ? 1 : IPA_SAMPLE_DEPTH)) : 1;
   };
@@ -686,7 +691,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
         return;
       }
     }
-    if constexpr (IPA_PIPE && !STREAM && pipe_capable<Src, K>::value) {
+    if constexpr (IPA_PIPE && !STREAM && pipe_unshared<Src, K>::value) {
       if constexpr (Src::kHasQ5) {
         if (src.q5) wave_run_strip_pipe<K, 1, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
         else wave_run_strip_pipe<K, 0, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);

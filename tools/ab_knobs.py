@@ -55,7 +55,15 @@ def main():
     one = rng.random((16, h, w), dtype=np.float32)
     src = ctx.to_device(np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch])
     dst = ctx.empty((batch, h, w), np.float32)
+    k7 = rng.random((7, 7))
+    k7 /= k7.sum()
+    u16 = None
+    if 'c4' in what:
+        u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
+                            if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
     calls = {
+        'c4': lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst),
+        'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
         'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
         'conv5': lambda: ops.conv2d(src, k5, out=dst),
         'remap': lambda: ops.remap(src, dmx, dmy, out=dst),
