@@ -74,6 +74,9 @@ def main():
         dist = np.array([rng.normal(0, 0.1), rng.normal(0, 0.02), rng.normal(0, 1e-3),
                          rng.normal(0, 1e-3), 0.0])
         finterp = interp if interp in ('linear', 'linear_cv_q5', 'cubic', 'cubic_cv_q5') else 'linear'
+        if os.environ.get('FUZZ_ONLY') and int(os.environ['FUZZ_ONLY']) != case:
+            continue
+        print('case %d: %dx%d -> %dx%d n=%d angle-ish M=%s' % (case, h, w, dh, dw, n, np.round(M, 3).tolist()), flush=True)
         calls = {
             'remap': lambda: ops.remap(d_src, dmx, dmy, interp, border, cval),
             'warp': lambda: ops.warp_perspective(d_src, M, (dh, dw), interp, border, cval),
@@ -106,6 +109,16 @@ def main():
                         got = fn().get()
                         if not same(got, ref):
                             fails += 1
+                            bad = (got.view(np.uint32) != ref.view(np.uint32)) & ~(np.isnan(got) & np.isnan(ref))
+                            idx = np.argwhere(bad.reshape((-1,) + bad.shape[-2:]))
+                            print('   %d values differ; frames %s rows %d..%d cols %d..%d; first %s got %r want %r'
+                                  % (bad.sum(), sorted(set(idx[:, 0].tolist())), idx[:, 1].min(), idx[:, 1].max(),
+                                     idx[:, 2].min(), idx[:, 2].max(), idx[0].tolist(),
+                                     got.reshape((-1,) + got.shape[-2:])[tuple(idx[0])],
+                                     ref.reshape((-1,) + ref.shape[-2:])[tuple(idx[0])]))
+                            rows = np.bincount(idx[:, 1], minlength=bad.shape[-2])
+                            print('   rows with mismatches (row: count): %s' % ', '.join(
+                                '%d: %d' % (r, c) for r, c in enumerate(rows) if c)[:600])
                             print('MISMATCH case %d %s %r rep %d: %dx%d -> %dx%d n=%d interp=%s '
                                   'border=%s K=%d cmode=%s' % (case, name, alt, rep, h, w, dh, dw,
                                                                n, interp, border, K, cmode))
