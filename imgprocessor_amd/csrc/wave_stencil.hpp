@@ -736,7 +736,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
 // waves per SIMD the register allocation must leave room for: the hand-scheduled sampling
 // kernels sit right at the 128-register step (4 waves per SIMD)
 template <typename Src, int K> struct wave_min_waves {
-  static constexpr int value = (pipe_capable<Src, K>::value && Src::kHasQ5 && IPA_PIPE) ? IPA_PIPE_MIN_WAVES : IPA_WAVE_MIN_WAVES;
+  static constexpr int value = (pipe_capable<Src, K>::value && Src::kHasQ5 && IPA_PIPE && K <= 5) ? IPA_PIPE_MIN_WAVES : IPA_WAVE_MIN_WAVES;   // (7x7: 46 filter registers more - no cap, no spills)
 };
 template <typename Src, int K>
 __global__ void __launch_bounds__(64 * IPA_WPB, (wave_min_waves<Src, K>::value))
