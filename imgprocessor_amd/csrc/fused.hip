@@ -309,13 +309,15 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
   // 493 -> 460 us (uint16 frames); 5x5 measured slower streamed (0.427 vs 0.399 ms, 16 frames).
   // stream_k = 9 is the tuning knob that puts 7x7 back on the resident form.
   const int stream_k = ctx->tune.stream_k;
-  // round 3: batches whose frames share map rows through LDS (wave_run_strip_shared: bilinear,
-  // float32 / uint16 frames, n_frames a multiple of the workgroup's waves) keep the 7x7
-  // coefficients resident as op_sel pairs on the hand-scheduled loop (knob pipe7 = 0: streamed)
+  // round 3: batches of uint16 frames whose frames share map rows through LDS
+  // (wave_run_strip_shared: bilinear, n_frames a multiple of the workgroup's waves) keep the 7x7
+  // coefficients resident as op_sel pairs on the hand-scheduled loop: C4 64 x 4K 1.475 -> 1.333 ms
+  // (knob pipe7 = 0: streamed).  float32 frames measure the same either way (1.484 / 1.484: two
+  // more tap registers per footprint, 141 VGPRs) and stay on the streamed kernel.
   const bool shared7 = kh == 7 && kw == 7 && ctx->tune.pipe7 != 0 && ctx->tune.frames_wg != 0 &&
                        ctx->tune.frames_inner != 0 && (interp & 0xff) == IPA_INTER_LINEAR &&
                        n_frames % 4 == 0 && dst_dtype == IPA_F32 &&
-                       (src_dtype == IPA_F32 || src_dtype == IPA_U16);
+                       src_dtype == IPA_U16;
   const bool streamed = kh >= stream_k && kh >= 7 && kh <= 11 && !shared7;
   {
     FusedCall f;
