@@ -341,3 +341,24 @@ def test_optimal_new_camera_matrix_independent_restatement():
                 # alpha = 0 maps the inner rectangle EXACTLY onto [0, W-1]: ceil / floor of a value
                 # that is an integer up to the convergence error of the inverse lens model
                 assert all(abs(int(a) - b) <= 1 for a, b in zip(roi, want_roi)), (name, roi)
+
+
+def test_hand_scheduled_kernels_static_check(tmp_path):
+    """the headline kernels (csrc/wave_pipe.hpp: inline-asm loads with hand-counted vmcnt waits)
+    compiled here for gfx950 and checked statically: no instruction touches a register whose
+    load is still in flight, no vector register is spilled (tools/check_pipe_asm.py)"""
+    import shutil
+    import subprocess
+    if not shutil.which('hipcc'):
+        pytest.skip('no hipcc')
+    src = os.path.join(ROOT, 'imgprocessor_amd', 'csrc')
+    cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-function',
+           '-save-temps=obj', '-c', os.path.join(src, 'fused_k5.hip'), '-I', src,
+           '-o', str(tmp_path / 'fused_k5.o')]
+    subprocess.run(cmd, check=True, cwd=str(tmp_path), capture_output=True)
+    asm = tmp_path / 'fused_k5-hip-amdgcn-amd-amdhsa-gfx950.s'
+    assert asm.exists()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_pipe_asm.py'), str(asm)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert 'SampleRowSrc' in r.stdout and 'LoadRowSrc' in r.stdout, r.stdout
