@@ -35,6 +35,8 @@ sys.path.insert(0, ROOT)
 
 H4K, W4K = 2160, 3840
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+VALU_PEAK_FLOPS = 157.3e12  # fp32 vector peak (MI355X_MICROARCH.md)
+LDS_PEAK_BPS = 150e12       # aggregate ds_read_b64/b128 rate, every CU streaming (same guide)
 
 
 def synth_frames(n, h, w, seed0=0):
@@ -158,12 +160,22 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     g /= g.sum()
     k5 = np.outer(g, g)
 
-    def entry(name, frames, h, w, ms, comp_bytes, launches, note=None):
+    def entry(name, frames, h, w, ms, comp_bytes, launches, note=None, bound='hbm', work=None):
+        """comp_bytes: the WORKLOAD's compulsory HBM bytes (inputs once, outputs once) whatever the
+        number of launches - an intermediate image through the workspace is not compulsory.
+        bound: the roofline that binds the dominant kernel; for 'valu' / 'lds' `work` is the
+        launch's flops / LDS bytes and the fraction is taken against that unit's peak."""
         e = {'workload': name, 'frames': frames, 'ms': round(ms, 4),
              'Mpix_s': round(frames * h * w / ms / 1e3, 1),
              'compulsory_bytes': int(comp_bytes),
              'frac_compulsory': round(comp_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-             'launches': launches}
+             'launches': launches, 'bound': bound}
+        if bound == 'valu' and work:
+            e['flops'] = int(work)
+            e['frac_valu'] = round(work / (ms * 1e-3) / VALU_PEAK_FLOPS, 4)
+        if bound == 'lds' and work:
+            e['lds_bytes'] = int(work)
+            e['frac_lds'] = round(work / (ms * 1e-3) / LDS_PEAK_BPS, 4)
         if note:
             e['note'] = note
         out.append(e)
@@ -192,8 +204,9 @@ def other_configs(ctx, ia, ops, budget_launches=60):
                                                                out=dst), budget_launches, 5)
         two = interp != 'linear'
         entry('C3 4K f32, PerspectiveCorrection warp (%s) + separable 9+9, %d frames/launch'
-              % (interp, B), B, h, w, ms, (16 if two else 8) * B * h * w, 2 if two else 1,
-              'two launches through the workspace' if two else None)
+              % (interp, B), B, h, w, ms, 8 * B * h * w, 2 if two else 1,
+              'two launches through the workspace (16 B/px of traffic for an 8 B/px workload)'
+              if two else None)
 
     # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
     # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
@@ -201,13 +214,17 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
                budget_launches, 5)
     entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
-          8 * B * h * w, 3, 'planning pass (first call) + ring kernel + gather kernel on the rim')
+          8 * B * h * w, 3, 'planning pass (first call) + ring kernel + gather kernel on the rim; '
+          'bound by the LDS tap reads of the ring kernel: 64 taps x 4 B per sample through ds_read_b64',
+          bound='lds', work=64 * 4 * B * h * w)
     u8 = ctx.to_device(np.round(synth_frames(B, h, w, 310) * 255).astype(np.uint8))
     d8 = ctx.empty((B, h, w), np.uint8)
     ms = timed(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
                budget_launches // 2, 3)
     entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
-          ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weight table resident in LDS (integer-exact)")
+          ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weight table resident in LDS (integer-exact); "
+          'bound by the integer VALU / texture addresser, an HBM fraction is the wrong roofline',
+          bound='valu')
     del u8, d8
 
     # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here
@@ -226,7 +243,8 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
                                                         'cubic', out=dst), budget_launches, 5)
     entry('C5-like 4K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
-          16 * B * h * w, 2, 'two launches through the workspace')
+          8 * B * h * w, 2, 'two launches through the workspace; the 11x11 filter is fma-bound',
+          bound='valu', work=(2 * 121 + 2 * 16) * B * h * w)
     del src, dst
 
     h, w, B = 4320, 7680, 4
@@ -235,7 +253,8 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
                                                         'cubic', out=dst), budget_launches // 2, 3)
     entry('C5 8K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
-          16 * B * h * w, 2, 'two launches through the workspace')
+          8 * B * h * w, 2, 'two launches through the workspace; the 11x11 filter is fma-bound',
+          bound='valu', work=(2 * 121 + 2 * 16) * B * h * w)
     del src, dst
 
     # C4: 4K uint16 -> float32 frames, undistort (maps) + dense 7x7; 64 frames per GPU

@@ -55,6 +55,23 @@ def main():
     stats = find(a.stats_dir, '*kernel_stats.csv')
     if stats:
         shutil.copy(stats[0], os.path.join(HERE, '%s_kernel_stats.csv' % a.tag))
+    # the same per LAUNCH SHAPE: one kernel name serves one-frame pipeline calls and 64-frame
+    # launches alike, and a per-name average says nothing about either
+    trace = find(a.stats_dir, '*kernel_trace.csv')
+    if trace:
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(trace[0])):
+            grid = 'x'.join(r[k] for k in ('Grid_Size_X', 'Grid_Size_Y', 'Grid_Size_Z'))
+            per[(r['Kernel_Name'], grid, r['VGPR_Count'], r['LDS_Block_Size'])].append(
+                (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+        with open(os.path.join(HERE, '%s_kernel_stats_by_grid.csv' % a.tag), 'w') as f:
+            w = csv.writer(f)
+            w.writerow(['kernel', 'grid (threads)', 'VGPRs', 'LDS bytes', 'launches', 'avg_us',
+                        'median_us', 'min_us', 'max_us'])
+            for (k, grid, vg, lds), v in sorted(per.items(), key=lambda kv: -sum(kv[1])):
+                v = sorted(v)
+                w.writerow([k, grid, vg, lds, len(v), '%.1f' % (sum(v) / len(v)),
+                            '%.1f' % v[len(v) // 2], '%.1f' % v[0], '%.1f' % v[-1]])
     fetch = mean_counter(a.fetch_dir, 'FETCH_SIZE')
     write = mean_counter(a.write_dir, 'WRITE_SIZE')
     with open(os.path.join(HERE, '%s_pmc.csv' % a.tag), 'w') as f:

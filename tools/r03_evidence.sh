@@ -10,3 +10,6 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r03_write -o r03 --ou
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/r03_cfetch -o r03 --output-format csv -- python3 $R/bench.py --no-cpu --steps 5 --warmup 2 > $R/gpurun_out/r03_cfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r03_cwrite -o r03 --output-format csv -- python3 $R/bench.py --no-cpu --steps 5 --warmup 2 > $R/gpurun_out/r03_cwrite.log 2>&1
 cat $R/gpurun_out/r03_bench.json | head -c 600
+# the N > 1 launcher path on hardware: two ranks time-sharing this box's one GPU (no scaling claim)
+cd $R && python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 $R/bench.py --gpus 2 --steps 50 --warmup 5 > $R/gpurun_out/r03_bench_2ranks_one_gpu.json 2> $R/gpurun_out/r03_bench_2ranks.err
+tail -c 400 $R/gpurun_out/r03_bench_2ranks_one_gpu.json
