@@ -195,9 +195,19 @@ class LensDistortion(object):
             return self.img
 
         def run(d):
-            return ops.remap(d, dx, dy, self.interpolation, 'constant', borderValue, map_roi=roi)
+            return ops.remap(d, dx, dy, self._interp_for(d.dtype), 'constant', borderValue,
+                             map_roi=roi)
         self.img = self._apply(image, run)
         return self.img
+
+    def _interp_for(self, dtype):
+        """integer camera frames go through cv2.remap's own integer-frame arithmetic, as in the
+        reference (:323-326): uint8 in 15-bit fixed point (any 'linear'), uint16 with float32
+        table weights at 1/32 px ('linear_cv_q5').  Float frames keep the exact-coordinate
+        bilinear of scipy / skimage unless the caller asked for the cv2 variant."""
+        if self.interpolation == 'linear' and np.dtype(dtype) == np.uint16:
+            return 'linear_cv_q5'
+        return self.interpolation
 
     def distortImage(self, image):
         """opposite of `correct` (approximate inverse map, :332-340)"""
@@ -207,7 +217,7 @@ class LensDistortion(object):
             h, w = np.shape(image)[:2]
         mx, my = self.getDistortRectifyMap(w, h)
         dmx, dmy = self.ctx.to_device(mx), self.ctx.to_device(my)
-        return self._apply(image, lambda d: ops.remap(d, dmx, dmy, self.interpolation,
+        return self._apply(image, lambda d: ops.remap(d, dmx, dmy, self._interp_for(d.dtype),
                                                       'constant', 0))
 
     def undistortPoints(self, points, keepSize=False):

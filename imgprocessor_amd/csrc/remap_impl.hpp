@@ -120,12 +120,15 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   // uint8 Lanczos4: OpenCV's short weights formed per sample from the float32 1-D table;
   // uint8 bicubic: the whole 2-D short table (32 KB) in LDS, a workgroup then works on
   // p.tile_rows groups of rows
-  constexpr bool kTabFixed = FIXED && INTERP == kLanczos4;
-  constexpr bool kTabLds = FIXED && INTERP == kCubic;
+  // uint16 -> uint16 with FIXED: OpenCV's 16U float-table arithmetic (sample_u16_cv); bicubic
+  // reads the float32 bicubic rows of the same table
+  constexpr bool kU16Cv = FIXED && std::is_same<ST, uint16_t>::value;
+  constexpr bool kTabFixed = FIXED && (INTERP == kLanczos4 || (kU16Cv && INTERP == kCubic));
+  constexpr bool kTabLds = FIXED && INTERP == kCubic && !kU16Cv;
   __shared__ __attribute__((aligned(16)))
   float lz_tab[kTabFixed ? 384 : (INTERP == kLanczos4 ? 256 : 4)];
   __shared__ __attribute__((aligned(16))) int4 tab_lds[kTabLds ? 1024 * kU8CubicRow : 1];
-  if constexpr (INTERP == kLanczos4) {
+  if constexpr (INTERP == kLanczos4 || kTabFixed) {
     const unsigned tid = threadIdx.y * 64 + threadIdx.x;
     lz_tab[tid] = p.lanczos[tid];
     if constexpr (kTabFixed)
@@ -215,6 +218,12 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
       out[k] = k < n ? store_cast<DT, double>(
                            sample_exact<ST, INTERP, typename Coord::coord_t>(s, sx[k], sy[k], p.cval))
                      : (DT)0;
+  } else if constexpr (kU16Cv) {
+    const double r16 = rint(p.cval);
+    const uint16_t cv16 = (uint16_t)(r16 > 0 ? (r16 < 65535 ? r16 : 65535) : 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      out[k] = k < n ? sample_u16_cv<INTERP>(s, lz_tab, sx[k], sy[k], cv16) : (DT)0;
   } else if constexpr (FIXED) {
     double r = rint(p.cval);
     uint8_t cv8 = (uint8_t)(r > 0 ? (r < 255 ? r : 255) : 0);
@@ -491,7 +500,13 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
     rc = ipa_u8_lanczos_tab2d(ctx, &p.tab2d);
     if (rc) return rc;
   }
-  if (base == IPA_INTER_LANCZOS4) {
+  // uint16 -> uint16 in a cv2 mode (1/32-px coordinates: linear_cv_q5, cubic_cv_q5, lanczos4):
+  // OpenCV's 16U float-table arithmetic (sampler.hpp::sample_u16_cv); the exact-coordinate modes
+  // keep the double sums of sample_exact
+  const bool u16_cv = a.src_dt == IPA_U16 && a.dst_dt == IPA_U16 &&
+                      (base == IPA_INTER_LANCZOS4 ||
+                       (p.q5 && (base == IPA_INTER_LINEAR || base == IPA_INTER_CUBIC_CV)));
+  if (base == IPA_INTER_LANCZOS4 || (u16_cv && base == IPA_INTER_CUBIC_CV)) {
     rc = ipa_lanczos_table(ctx, &p.lanczos);
     if (rc) return rc;
   }
@@ -560,7 +575,8 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   } else if (s == IPA_U16 && d == IPA_F32) {
     launch_interp<uint16_t, float, Coord, false>(ctx, p, coord, base, grid);
   } else if (s == IPA_U16 && d == IPA_U16) {
-    launch_interp<uint16_t, uint16_t, Coord, false>(ctx, p, coord, base, grid);
+    if (u16_cv) launch_interp<uint16_t, uint16_t, Coord, true>(ctx, p, coord, base, grid);
+    else launch_interp<uint16_t, uint16_t, Coord, false>(ctx, p, coord, base, grid);
   } else if (s == IPA_U8 && d == IPA_F32) {
     launch_interp<uint8_t, float, Coord, false>(ctx, p, coord, base, grid);
   } else if (s == IPA_U8 && d == IPA_U8) {

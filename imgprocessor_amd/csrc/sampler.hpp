@@ -831,6 +831,105 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
 }
 
+// OpenCV's remap arithmetic on CV_16U frames (what cv2.remap / warpPerspective do on the camera's
+// uint16 frames in LensDistortion.correct, camera/LensDistortion.py:323-326, and
+// PerspectiveCorrection.correct, camera/PerspectiveCorrection.py:401-405), restated from the
+// published algorithm (imgwarp.cpp: remapBilinear / remapBicubic / remapLanczos4 instantiated
+// with Cast<float, ushort>, weights float):
+//   * coordinates rounded to 1/32 px; the 1-D weights of the 32 fractions in float32
+//     (interpolateLinear / interpolateCubic / interpolateLanczos4), the 2-D weight of a tap the
+//     float32 PRODUCT wy[r] * wx[c] (initInterTab2D without fixed point);
+//   * float32 accumulation, every product and every sum rounded, no fused multiply-add:
+//       bilinear          v00 w00 + v01 w01 + v10 w10 + v11 w11, left to right (taps outside the
+//                         frame replaced by the border value first);
+//       bicubic, inside   the 16 products summed left to right in row-major order;
+//       Lanczos4, inside  per tap row the 8 products summed left to right, the row sums added;
+//       bicubic / Lanczos4 with taps outside the frame:  sum = cv, then for every tap that
+//                         exists (rows, columns through the border mode)  sum += (S - cv) * w;
+//   * saturate_cast<ushort>(sum) = round half to even, clamp to [0, 65535].
+// `tab`: the float32 1-D tables ([0, 256) Lanczos4 rows, [256, 384) bicubic rows) of
+// ipa_lanczos_table.  Unpinned against cv2 like the other cv2 modes: the
+// expression order is restated from memory of the OpenCV 4.x source.
+template <int INTERP, typename C>
+__device__ __forceinline__ uint16_t sample_u16_cv(const SrcView& s, const float* tab, C sx, C sy,
+                                                  uint16_t cv16) {
+#pragma clang fp contract(off)
+  constexpr int ks = ntaps<INTERP>::value;
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit &&
+        sy < (C)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cv16;
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
+  }
+  const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
+  const int ix0 = (qx >> 5) - (ks / 2 - 1), iy0 = (qy >> 5) - (ks / 2 - 1);
+  if (s.border == IPA_BORDER_CONSTANT &&
+      (ix0 >= s.w || ix0 + ks <= 0 || iy0 >= s.h || iy0 + ks <= 0))
+    return cv16;  // whole footprint outside
+  float wx[ks], wy[ks];
+  if constexpr (INTERP == kLinear) {
+    const float fx = (float)(qx & 31) * 0.03125f, fy = (float)(qy & 31) * 0.03125f;
+    wx[0] = 1.f - fx; wx[1] = fx;
+    wy[0] = 1.f - fy; wy[1] = fy;
+  } else {
+    const float* t = tab + (INTERP == kCubic ? 256 : 0);
+#pragma unroll
+    for (int k = 0; k < ks; k++) {
+      wx[k] = t[(qx & 31) * ks + k];
+      wy[k] = t[(qy & 31) * ks + k];
+    }
+  }
+  const float cv = (float)cv16;
+  const bool inside = ix0 >= 0 && iy0 >= 0 && ix0 + ks <= s.w && iy0 + ks <= s.h;
+  auto tap = [&](int yy, int xx) -> float {
+    return (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(s.rsrc, (yy * s.pitch + xx) << 1, 0, 0);
+  };
+  float sum;
+  if constexpr (INTERP == kLinear) {
+    float v[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int yy = inside ? iy0 + r : resolve_idx(iy0 + r, s.h, s.border);
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const int xx = inside ? ix0 + c : resolve_idx(ix0 + c, s.w, s.border);
+        v[r][c] = (yy < 0 || xx < 0) ? cv : tap(yy < 0 ? 0 : yy, xx < 0 ? 0 : xx);
+      }
+    }
+    sum = v[0][0] * (wy[0] * wx[0]);
+    sum = sum + v[0][1] * (wy[0] * wx[1]);
+    sum = sum + v[1][0] * (wy[1] * wx[0]);
+    sum = sum + v[1][1] * (wy[1] * wx[1]);
+  } else if (inside) {
+    sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < ks; r++) {
+      float rs = 0.f;
+#pragma unroll
+      for (int c = 0; c < ks; c++) {
+        const float pr = tap(iy0 + r, ix0 + c) * (wy[r] * wx[c]);
+        if constexpr (INTERP == kCubic) sum = (r == 0 && c == 0) ? pr : sum + pr;   // one flat sum
+        else rs = c == 0 ? pr : rs + pr;                                            // row sums
+      }
+      if constexpr (INTERP != kCubic) sum = sum + rs;
+    }
+  } else {
+    sum = cv;
+    for (int r = 0; r < ks; r++) {
+      const int yy = resolve_idx(iy0 + r, s.h, s.border);
+      if (yy < 0) continue;
+      for (int c = 0; c < ks; c++) {
+        const int xx = resolve_idx(ix0 + c, s.w, s.border);
+        if (xx >= 0) sum = sum + (tap(yy, xx) - cv) * (wy[r] * wx[c]);
+      }
+    }
+  }
+  float r = rintf(sum);
+  r = r > 0.f ? r : 0.f;  // NaN -> 0
+  r = r < 65535.f ? r : 65535.f;
+  return (uint16_t)r;
+}
+
 // ------------------------------------------------------- coordinate sources --
 // Each provides  coord_t  and  get(u, v, sx, sy)  for destination pixel (u,v).
 

@@ -412,8 +412,103 @@ static uint8_t sample_u8_tab(const sampler_t* s, double sx, double sy, uint8_t c
   return (uint8_t)(o < 0 ? 0 : (o > 255 ? 255 : o));
 }
 
-/* uint8 -> uint8: 0 = floating point path, 1 = bilinear fixed point, 2 = table fixed point */
+/* OpenCV's remap arithmetic on CV_16U (cv2.remap / warpPerspective on the camera's uint16 frames:
+ * camera/LensDistortion.py:323-326, camera/PerspectiveCorrection.py:401-405), restated from the
+ * published algorithm - imgwarp.cpp remapBilinear / remapBicubic / remapLanczos4 with
+ * Cast<float, ushort> and float weights (cv2 itself is absent here: unpinned, and the expression
+ * order below is from memory of the OpenCV 4.x source):
+ *   coordinates to 1/32 px; 1-D float32 weights of the 32 fractions; the 2-D weight of a tap the
+ *   float32 product wy[r] * wx[c]; float32 accumulation (every product and sum rounded, no fma):
+ *     bilinear         v00 w00 + v01 w01 + v10 w10 + v11 w11 left to right, taps outside the frame
+ *                      replaced by the border value;
+ *     bicubic inside   the 16 products summed left to right in row-major order;
+ *     Lanczos4 inside  per tap row the 8 products summed left to right, the row sums added;
+ *     bicubic / Lanczos4 with taps outside:  sum = cv;  sum += (S - cv) * w  for every tap that
+ *                      exists after the border mode;
+ *   saturate_cast<ushort>: round half to even, clamp. */
+static uint16_t sample_u16_cv(const sampler_t* s, double sx, double sy, uint16_t cv16) {
+  init_fixed_tabs();
+  const int ks = s->interp == ORC_LANCZOS4 ? 8 : (s->interp == ORC_LINEAR ? 2 : 4);
+  if (!(sx > -1e6 && sx < 1e6 && sy > -1e6 && sy < 1e6)) {
+    if (s->border == ORC_CONSTANT || sx != sx || sy != sy) return cv16;
+    sx = sx < -1e6 ? -1e6 : (sx > 1e6 ? 1e6 : sx);
+    sy = sy < -1e6 ? -1e6 : (sy > 1e6 ? 1e6 : sy);
+  }
+  long qx = (long)nearbyint(sx * 32.0), qy = (long)nearbyint(sy * 32.0);
+  long ix0 = (qx >> 5) - (ks / 2 - 1), iy0 = (qy >> 5) - (ks / 2 - 1);
+  if (s->border == ORC_CONSTANT &&
+      (ix0 >= s->w || ix0 + ks <= 0 || iy0 >= s->h || iy0 + ks <= 0))
+    return cv16;
+  float wx[8], wy[8];
+  if (ks == 2) {
+    float fx = (float)(qx & 31) * 0.03125f, fy = (float)(qy & 31) * 0.03125f;
+    wx[0] = 1.f - fx; wx[1] = fx; wy[0] = 1.f - fy; wy[1] = fy;
+  } else {
+    const float* tx = ks == 4 ? g_tab_cubic[qx & 31] : g_tab_lanczos[qx & 31];
+    const float* ty = ks == 4 ? g_tab_cubic[qy & 31] : g_tab_lanczos[qy & 31];
+    for (int k = 0; k < ks; k++) { wx[k] = tx[k]; wy[k] = ty[k]; }
+  }
+  const uint16_t* src = (const uint16_t*)s->src;
+  const float cv = (float)cv16;
+  const int inside = ix0 >= 0 && iy0 >= 0 && ix0 + ks <= s->w && iy0 + ks <= s->h;
+  float sum;
+  if (ks == 2) {
+    float v[2][2];
+    for (int r = 0; r < 2; r++) {
+      long yy = resolve_idx(iy0 + r, s->h, s->border);
+      for (int c = 0; c < 2; c++) {
+        long xx = resolve_idx(ix0 + c, s->w, s->border);
+        v[r][c] = (yy < 0 || xx < 0) ? cv : (float)src[yy * s->pitch + xx];
+      }
+    }
+    sum = v[0][0] * (wy[0] * wx[0]);
+    sum = sum + v[0][1] * (wy[0] * wx[1]);
+    sum = sum + v[1][0] * (wy[1] * wx[0]);
+    sum = sum + v[1][1] * (wy[1] * wx[1]);
+  } else if (inside) {
+    sum = 0.f;
+    for (int r = 0; r < ks; r++) {
+      float rs = 0.f;
+      for (int c = 0; c < ks; c++) {
+        float pr = (float)src[(iy0 + r) * s->pitch + ix0 + c] * (wy[r] * wx[c]);
+        if (ks == 4) sum = (r == 0 && c == 0) ? pr : sum + pr;
+        else rs = c == 0 ? pr : rs + pr;
+      }
+      if (ks != 4) sum = sum + rs;
+    }
+  } else {
+    sum = cv;
+    for (int r = 0; r < ks; r++) {
+      long yy = resolve_idx(iy0 + r, s->h, s->border);
+      if (yy < 0) continue;
+      for (int c = 0; c < ks; c++) {
+        long xx = resolve_idx(ix0 + c, s->w, s->border);
+        if (xx >= 0) sum = sum + ((float)src[yy * s->pitch + xx] - cv) * (wy[r] * wx[c]);
+      }
+    }
+  }
+  double r = nearbyint((double)sum);
+  if (!(r > 0)) r = 0;
+  if (r > 65535) r = 65535;
+  return (uint16_t)r;
+}
+
+static inline uint16_t sat_u16cv(double v) {
+  double r = nearbyint(v);
+  if (!(r > 0)) r = 0;
+  if (r > 65535) r = 65535;
+  return (uint16_t)r;
+}
+
+/* integer frames in cv2's own arithmetic: 0 = floating point path, 1 = uint8 bilinear fixed point,
+ * 2 = uint8 table fixed point, 3 = uint16 float tables (the cv2 modes: 1/32-px coordinates) */
 static int fixed_kind(const sampler_t* s, int src_dt, int dst_dt) {
+  if (src_dt == ORC_U16 && dst_dt == ORC_U16) {
+    if (s->interp == ORC_LANCZOS4 ||
+        (s->q5 && (s->interp == ORC_LINEAR || s->interp == ORC_CUBIC_CV)))
+      return 3;
+    return 0;
+  }
   if (src_dt != ORC_U8 || dst_dt != ORC_U8) return 0;
   if (s->interp == ORC_LINEAR) return 1;
   if (s->interp == ORC_CUBIC_CV || s->interp == ORC_LANCZOS4) {
@@ -447,11 +542,14 @@ int orc_remap(const void* src, int src_dt, long sh, long sw, long src_pitch, con
   init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
   int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
+  uint16_t cv16 = sat_u16cv(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++) {
     for (long u = 0; u < dw; u++) {
       double sx = mapx[v * map_pitch + u], sy = mapy[v * map_pitch + u];
-      if (fixed)
+      if (fixed == 3)
+        ((uint16_t*)dst)[v * dst_pitch + u] = sample_u16_cv(&s, sx, sy, cv16);
+      else if (fixed)
         ((uint8_t*)dst)[v * dst_pitch + u] =
             fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else
@@ -516,6 +614,7 @@ int orc_undistort(const void* src, int src_dt, long sh, long sw, long src_pitch,
   if (inv3(newK, ir)) return -1;
   int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
+  uint16_t cv16 = sat_u16cv(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++)
     for (long u = 0; u < dw; u++) {
@@ -523,7 +622,9 @@ int orc_undistort(const void* src, int src_dt, long sh, long sw, long src_pitch,
       undistort_coord(K, dist5, ir, u, v, &sx, &sy);
       sx = (double)(float)sx; /* CV_32FC1 map storage */
       sy = (double)(float)sy;
-      if (fixed)
+      if (fixed == 3)
+        ((uint16_t*)dst)[v * dst_pitch + u] = sample_u16_cv(&s, sx, sy, cv16);
+      else if (fixed)
         ((uint8_t*)dst)[v * dst_pitch + u] =
             fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else
@@ -543,6 +644,7 @@ int orc_warp_perspective(const void* src, int src_dt, long sh, long sw, long src
   init_sampler(&s, src, src_dt, sh, sw, src_pitch, interp, border, cval);
   int fixed = fixed_kind(&s, src_dt, dst_dt);
   uint8_t cv8 = sat_u8(cval);
+  uint16_t cv16 = sat_u16cv(cval);
 #pragma omp parallel for num_threads(g_threads) schedule(static)
   for (long v = 0; v < dh; v++)
     for (long u = 0; u < dw; u++) {
@@ -552,7 +654,9 @@ int orc_warp_perspective(const void* src, int src_dt, long sh, long sw, long src
       double sx, sy;
       if (W != 0) { double iw = 1.0 / W; sx = X * iw; sy = Y * iw; }
       else { sx = 0; sy = 0; } /* cv2: W ? 1/W : 0 */
-      if (fixed)
+      if (fixed == 3)
+        ((uint16_t*)dst)[v * dst_pitch + u] = sample_u16_cv(&s, sx, sy, cv16);
+      else if (fixed)
         ((uint8_t*)dst)[v * dst_pitch + u] =
             fixed == 1 ? sample_u8_fixed(&s, sx, sy, cv8) : sample_u8_tab(&s, sx, sy, cv8);
       else

@@ -552,6 +552,73 @@ def remap_u8_tab_np(img8, mx, my, kind, cval8=0):
     return out.astype(np.uint8)
 
 
+def remap_u16_cv_np(img16, mx, my, kind, cval16=0):
+    """cv2.remap on CV_16U with BORDER_CONSTANT, written from the published scheme in float32
+    numpy arithmetic (every product and every sum an IEEE single, no fused multiply-add):
+    coordinates to 1/32 px, 1-D float32 weights (linear: 1 - x, x; cubic / Lanczos4: the tables
+    of cv_fixed_tables_np), 2-D weight = the float32 product wy * wx;
+      linear             v00 w00 + v01 w01 + v10 w10 + v11 w11 left to right (border value
+                         substituted for taps outside);
+      cubic, inside      the 16 products summed left to right, row-major;
+      Lanczos4, inside   row sums (8 products left to right), added row by row;
+      taps outside       sum = cv, then sum += (S - cv) * w for the taps inside the frame;
+    cvRound + saturation to uint16."""
+    f = np.float32
+    ks = {'linear': 2, 'cubic': 4, 'lanczos4': 8}[kind]
+    qx = np.rint(mx.astype(np.float64) * 32).astype(np.int64)
+    qy = np.rint(my.astype(np.float64) * 32).astype(np.int64)
+    ix0, iy0, fx, fy = (qx >> 5) - (ks // 2 - 1), (qy >> 5) - (ks // 2 - 1), qx & 31, qy & 31
+    if kind == 'linear':
+        x = np.arange(32, dtype=f) * f(1.0 / 32)
+        tab = np.stack([f(1) - x, x], axis=1).astype(f)
+    else:
+        tab = cv_fixed_tables_np(kind)[0]
+    wx, wy = tab[fx], tab[fy]                       # (H, W, ks) float32
+    src = img16.astype(f)
+    h, w = src.shape
+    cv = f(cval16)
+    S = np.empty((ks, ks) + mx.shape, f)
+    ok = np.empty((ks, ks) + mx.shape, bool)
+    for r in range(ks):
+        for c in range(ks):
+            yy, xx = iy0 + r, ix0 + c
+            o = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+            v = np.full(mx.shape, cv, f)
+            v[o] = src[yy[o], xx[o]]
+            S[r, c], ok[r, c] = v, o
+    W2 = [[(wy[..., r] * wx[..., c]).astype(f) for c in range(ks)] for r in range(ks)]
+    inside = ok.all(axis=(0, 1))
+    if kind == 'linear':
+        out = (S[0, 0] * W2[0][0]).astype(f)
+        for (r, c) in ((0, 1), (1, 0), (1, 1)):
+            out = (out + (S[r, c] * W2[r][c]).astype(f)).astype(f)
+    else:
+        if kind == 'cubic':
+            ins = None
+            for r in range(ks):
+                for c in range(ks):
+                    pr = (S[r, c] * W2[r][c]).astype(f)
+                    ins = pr if ins is None else (ins + pr).astype(f)
+        else:
+            ins = np.zeros(mx.shape, f)
+            for r in range(ks):
+                rs = None
+                for c in range(ks):
+                    pr = (S[r, c] * W2[r][c]).astype(f)
+                    rs = pr if rs is None else (rs + pr).astype(f)
+                ins = (ins + rs).astype(f)
+        brd = np.full(mx.shape, cv, f)
+        for r in range(ks):
+            for c in range(ks):
+                term = ((S[r, c] - cv).astype(f) * W2[r][c]).astype(f)
+                brd = np.where(ok[r, c], (brd + term).astype(f), brd)
+        out = np.where(inside, ins, brd)
+    res = np.clip(np.rint(out.astype(np.float64)), 0, 65535)
+    outside = (ix0 >= w) | (ix0 + ks <= 0) | (iy0 >= h) | (iy0 + ks <= 0)
+    res[outside] = int(cval16)
+    return res.astype(np.uint16)
+
+
 def optimal_new_camera_matrix_np(K, d, size, alpha):
     """cv2.getOptimalNewCameraMatrix(K, d, (w, h), alpha, (w, h)), OpenCV 4.x definition:
     a 9 x 9 grid of image points is undistorted to ideal coordinates; `outer` bounds all of
@@ -606,6 +673,8 @@ def gen_cv_modes():
     img8 = np.round(synth((H, W), 5, np.float64) * 255).astype(np.uint8)
     out['img'] = img
     out['img8'] = img8
+    img16 = np.round(synth((H, W), 6, np.float64) * 65535).astype(np.uint16)
+    out['img16'] = img16
     for name in ('radial', 'strong'):
         fx, fy, cx, cy, d = REMAP_CASES[name]
         K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1.]])
@@ -637,6 +706,10 @@ def gen_cv_modes():
         for kind in ('cubic', 'lanczos4'):
             out['u8tab_%s_%s' % (kind, name)] = remap_u8_tab_np(img8, mx, my, kind, 0)
             out['u8tab17_%s_%s' % (kind, name)] = remap_u8_tab_np(img8, mx, my, kind, 17)
+        # OpenCV's 16U arithmetic (float32 table weights, float32 accumulation)
+        for kind in ('linear', 'cubic', 'lanczos4'):
+            out['u16cv_%s_%s' % (kind, name)] = remap_u16_cv_np(img16, mx, my, kind, 0)
+            out['u16cv1000_%s_%s' % (kind, name)] = remap_u16_cv_np(img16, mx, my, kind, 1000)
     # the Lanczos4 table itself: rows k / 32, taps -3..4, normalised
     t = np.arange(32) / 32.0
     tab = np.stack([lanczos4_kernel(t - o) for o in range(-3, 5)], axis=1)

@@ -691,6 +691,12 @@ def test_lens_distortion_class(ia, oracle):
     assert o.shape == rgb.shape and o.dtype == np.uint8
     for c in range(3):
         assert np.array_equal(o[..., c], oracle.remap(np.ascontiguousarray(rgb[..., c]), omx, omy))
+    # the camera's uint16 frames: cv2.remap's 16U arithmetic (float32 table weights at 1/32 px),
+    # as the reference's correct() gets from cv2 (camera/LensDistortion.py:323-326)
+    f16 = np.round(synth((H, W), 8, np.float64) * 4095).astype(np.uint16)
+    o16 = ld.correct(f16, keepSize=True)
+    assert o16.dtype == np.uint16
+    assert np.array_equal(o16, oracle.remap(f16, omx, omy, oracle.LINEAR | oracle.Q5))
     # distortImage: first-order inverse map as written in the reference
     posy, posx = np.mgrid[0:H, 0:W].astype(np.float32)
     close32(ld.distortImage(img), oracle.remap(img, posx + (posx - omx), posy + (posy - omy)),
@@ -773,6 +779,51 @@ def test_errors(ia):
                      np.zeros((4, 4), np.float32), out_dtype=np.float32)
     with pytest.raises(ValueError):
         ia.ops.undistort(img, np.eye(3), np.zeros(5), np.zeros((3, 3)))  # singular newK
+
+
+def test_cv_u16_arithmetic(ia, oracle):
+    """uint16 -> uint16 in the cv2 modes (linear_cv_q5, cubic_cv_q5, lanczos4) = OpenCV's 16U
+    arithmetic (float32 table weights, float32 accumulation, cvRound): bit for bit the oracle for
+    every border mode and border value, and the independent numpy restatement (Lanczos4: up to
+    the last-bit differences of the 1-D tables).  This is what LensDistortion.correct /
+    PerspectiveCorrection.correct do on the camera's uint16 frames (camera/LensDistortion.py:
+    323-326, camera/PerspectiveCorrection.py:401-405)."""
+    g = load_golden('cv_modes.npz')
+    img16 = g['img16']
+    big = np.round(synth((300, 700), 77, np.float64) * 65535).astype(np.uint16)
+    yy, xx = np.mgrid[0:300, 0:700].astype(np.float32)
+    bmx = (xx * 1.03 - 14.3 + 2.0 * np.sin(yy / 23)).astype(np.float32)
+    bmy = (yy * 0.97 + 6.1 + 1.5 * np.cos(xx / 31)).astype(np.float32)
+    modes = (('linear', 'linear_cv_q5', oracle.LINEAR | oracle.Q5),
+             ('cubic', 'cubic_cv_q5', oracle.CUBIC_CV | oracle.Q5),
+             ('lanczos4', 'lanczos4', oracle.LANCZOS4))
+    for name in ('radial', 'strong'):
+        mx, my = g['mapx_' + name], g['mapy_' + name]
+        for kind, iname, iid in modes:
+            for key, cv in (('u16cv', 0), ('u16cv1000', 1000)):
+                got = ia.ops.remap(img16, mx, my, iname, 'constant', cv)
+                assert got.dtype == np.uint16
+                assert np.array_equal(got, oracle.remap(img16, mx, my, iid, oracle.CONSTANT, cv)), (kind, name, key)
+                want = g['%s_%s_%s' % (key, kind, name)]
+                if kind == 'lanczos4':
+                    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+                    assert d.max() <= 1 and (d != 0).mean() < 0.01
+                else:
+                    assert np.array_equal(got, want), (kind, name, key)
+            for bname, bid in (('replicate', oracle.REPLICATE), ('reflect', oracle.REFLECT),
+                               ('reflect101', oracle.REFLECT101), ('wrap', oracle.WRAP)):
+                assert np.array_equal(ia.ops.remap(img16, mx, my, iname, bname),
+                                      oracle.remap(img16, mx, my, iid, bid)), (kind, name, bname)
+    for kind, iname, iid in modes:   # a frame with several tiles per axis, batch of 3
+        batch = np.stack([np.roll(big, 13 * i, axis=1) for i in range(3)])
+        got = ia.ops.remap(batch, bmx, bmy, iname, 'constant', 70)
+        for i in range(3):
+            assert np.array_equal(got[i], oracle.remap(batch[i], bmx, bmy, iid, oracle.CONSTANT, 70)), (kind, i)
+    # the analytic sources take the same arithmetic
+    M = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
+    for kind, iname, iid in modes:
+        assert np.array_equal(ia.ops.warp_perspective(big, M, (300, 700), iname),
+                              oracle.warp_perspective(big, M, (300, 700), iid)), kind
 
 
 def test_cv_modes_vs_independent_restatements(ia, oracle):

@@ -400,3 +400,31 @@ def test_cv_u8_fixed_point_tables(oracle):
             # the 1/32-px flag changes nothing: 8U coordinates are always rounded
             assert np.array_equal(oracle.remap(img8, mx, my, iid | oracle.Q5),
                                   oracle.remap(img8, mx, my, iid))
+
+
+def test_cv_u16_arithmetic_independent_restatement(oracle):
+    """OpenCV's remap arithmetic on CV_16U (float32 table weights at 1/32 px, float32
+    accumulation, cvRound) - what cv2.remap does on the camera's uint16 frames in
+    LensDistortion.correct (camera/LensDistortion.py:323-326): the oracle's restatement against
+    the second, independently written float32-numpy one (gen_golden.py::remap_u16_cv_np).
+    Bilinear and bicubic bit for bit; Lanczos4 up to the last-bit differences of the two 1-D
+    weight tables (off by one on a few pixels).  cv2 itself is absent: unpinned."""
+    g = load_golden('cv_modes.npz')
+    img16 = g['img16']
+    for name in ('radial', 'strong'):
+        mx, my = g['mapx_' + name], g['mapy_' + name]
+        for kind, iid in (('linear', oracle.LINEAR | oracle.Q5), ('cubic', oracle.CUBIC_CV | oracle.Q5),
+                          ('lanczos4', oracle.LANCZOS4)):
+            for key, cv in (('u16cv', 0), ('u16cv1000', 1000)):
+                got = oracle.remap(img16, mx, my, iid, oracle.CONSTANT, cv)
+                want = g['%s_%s_%s' % (key, kind, name)]
+                assert got.dtype == np.uint16
+                if kind == 'lanczos4':
+                    d = np.abs(got.astype(np.int64) - want.astype(np.int64))
+                    assert d.max() <= 1 and (d != 0).mean() < 0.01, (kind, name, d.max(), (d != 0).mean())
+                else:
+                    assert np.array_equal(got, want), (kind, name, key)
+    # the exact-coordinate modes keep the double sums (not the cv2 arithmetic)
+    a = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR)
+    b = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR | oracle.Q5)
+    assert not np.array_equal(a, b)
