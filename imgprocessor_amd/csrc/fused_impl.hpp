@@ -53,32 +53,15 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false,
-                                pipe_capable<Src, K>::value && IPA_PIPE ? 2 : 0);
+                                shared_capable<Src, K>::value && IPA_PIPE ? 2 : 0);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   // frames of one strip block run together: map-based remaps share their map rows between
   // frames (L2 fetch traffic -62 % on 16 x 4K), and even without shared rows the order measured
   // ~5 % faster than frame-after-frame
-  dim3 grid = wave_grid(ctx, p, f.n_frames, IPA_WPB, true, coord_is_table<Coord>::value);
+  dim3 grid = wave_grid(ctx, p, f.n_frames, IPA_WPB, true,
+                        coord_is_table<Coord>::value || shared_capable<Src, K>::value);
   dim3 block(64 * IPA_WPB);
-#ifdef IPA_DEBUG_STAMP
-  static unsigned long long* d_dbg = nullptr;
-  if (!d_dbg) (void)hipMalloc(&d_dbg, 64);
-  (void)hipMemsetAsync(d_dbg, 0, 64, ctx->stream);
-  p.dbg = d_dbg;
-#endif
   hipLaunchKernelGGL((wave_stencil_kernel<Src, K>), grid, block, 0, ctx->stream, p, s, w);
-#ifdef IPA_DEBUG_STAMP
-  {
-    unsigned long long h[8];
-    (void)hipMemcpyAsync(h, d_dbg, 64, hipMemcpyDeviceToHost, ctx->stream);
-    (void)hipStreamSynchronize(ctx->stream);
-    if (h[6])
-      fprintf(stderr, "STAMP waves %llu rows/wave %.1f  cycles per wave-row: wait %.0f blend %.0f "
-                      "issue %.0f filter %.0f barrier(+map issue)/row %.0f  total/row %.0f\n",
-              h[6], (double)h[7] / h[6], (double)h[0] / h[7], (double)h[1] / h[7],
-              (double)h[2] / h[7], (double)h[3] / h[7], (double)h[4] / h[7], (double)h[5] / h[7]);
-  }
-#endif
 }
 
 template <typename ST, typename Coord, int K>

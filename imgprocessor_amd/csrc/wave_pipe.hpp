@@ -283,6 +283,12 @@ template <int K> struct pipe_capable<LoadRowSrc, K> : std::true_type {};
 template <typename ST, typename Coord, int K> struct pipe_capable<SampleRowSrc<ST, kLinear, Coord>, K> {
   static constexpr bool value = SampleRowSrc<ST, kLinear, Coord>::template depth<K>::kPiped;
 };
+// kernels whose batches share footprint records through LDS (wave_run_strip_shared): bilinear
+// sampling of float32 / uint16 frames from ANY coordinate source
+template <typename Src, int K> struct shared_capable : std::false_type {};
+template <typename ST, typename Coord, int K> struct shared_capable<SampleRowSrc<ST, kLinear, Coord>, K> {
+  static constexpr bool value = SampleRowSrc<ST, kLinear, Coord>::template depth<K>::kShared;
+};
 // ... of which the FAST strips of launches that do NOT share map rows (single frames, batches
 // that are no multiple of IPA_WPB) run on wave_run_strip_pipe (float32 frames only)
 template <typename Src, int K> struct pipe_unshared : std::false_type {};
@@ -525,33 +531,56 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 #undef hoff
 }
 
-// ------------------------------------------------------------------ sampling source, map rows
+// ------------------------------------------------------------------ sampling source, footprints
 // shared by the frames of a workgroup --
 // WaveParams::frames_wg: the IPA_WPB waves of a workgroup work on IPA_WPB frames of ONE strip, so
-// they need the SAME map rows.  A vector-memory instruction costs the CU's vector-memory path
-// ~4.6 clocks whatever it fetches (tools/pipe_micro.hip), and the 8 map dwords per row and wave
-// were a third of the kernel's vector-memory instructions (and 13 % of its time: build with
-// -DIPA_DEBUG_NO_MAP).  Here each map row is loaded ONCE per workgroup - row r by wave r mod
-// IPA_WPB - and handed to the others through a ring of 2 IPA_WPB rows in LDS:
+// their samples have the SAME footprints.  A vector-memory instruction costs the CU's
+// vector-memory path ~4.6 clocks whatever it fetches (tools/pipe_micro.hip), and the 8 map
+// dwords per row and wave were a third of the kernel's vector-memory instructions (13 % of its
+// time: -DIPA_DEBUG_NO_MAP); the homography's double coordinates a third of the C3 chain.  Here
+// the footprints of a row - byte offset of the top-left tap, the two fractions, the "inside the
+// source" bits - are worked out ONCE per workgroup, row r by wave r mod IPA_WPB (from 8 map
+// dwords, or from the lens model / homography in double), and handed to the other waves as a
+// RECORD row in a ring of 2 IPA_WPB rows in LDS:
 //
 //   rows are grouped in blocks of W = IPA_WPB; between the barriers of block b-1 and block b
 //   (one s_barrier per W rows, at the top of the block's last step) every wave READS the rows
 //   of block b and the producers WRITE the rows of block b + 1 into the other half of the ring;
-//   a producer issues its row's 8 loads right behind the barrier and writes them to LDS W - 1
-//   iterations later.
+//   a producer of a table source issues its row's 8 loads right behind the barrier and turns
+//   them into the record W - 1 iterations later.
 //
 // With the map loads issued BEFORE the row's gathers, the only operation younger than the
 // gathers a wave waits for is its latest store: every wait is vmcnt(1) (0 before the first
 // store), whatever was issued - so a top-row gather whose EXEC mask is empty is branched over
 // instead of issued (43 % of them on the 4K lens map).
-// Same footprints, same words, same blend as wave_run_strip_pipe: identical bits.
-template <int K, int QM, bool EDGE, typename ST, typename Coord>
+// The filter is a policy: dense K x K (DenseFilter) or separable K + K (SepFilter, wave_sep.hpp).
+// Same footprints, same words, same blend as wave_run_strip_pipe / the chunked loop: identical bits.
+constexpr int kRingRow = 3 * 256 + 64;   // floats per record row: offsets, tx, ty, inside bits
+
+template <int K> struct DenseFilter {
+  static constexpr int kTaps = K;
+  const Weights<float, K * K>& wts;
+  unsigned lane4_opaque;
+  v2f acc[K][2];
+  __device__ __forceinline__ DenseFilter(const Weights<float, K * K>& w) : wts(w) {
+    lane4_opaque = 4u * (threadIdx.x & 63u);
+    asm volatile("" : "+v"(lane4_opaque));
+  }
+  // sample row (LDS, natural pixel order) -> the output row that completes with it
+  template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols&) {
+    return pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
+  }
+};
+
+template <int K, int QM, bool EDGE, typename Filter, typename ST, typename Coord>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       const SampleRowSrc<ST, kLinear, Coord>& src,
-                                                      const Weights<float, K * K>& wts, float* xp,
-                                                      float* ring, unsigned wave, const Cols& c,
-                                                      int y0, int nrows, bool writer, float* dst) {
+                                                      Filter& filt, float* xp, float* ring,
+                                                      unsigned wave, const Cols& c, int y0,
+                                                      int nrows, bool writer, float* dst) {
   using G = wave_geom<K, false>;
+  using C = typename Coord::coord_t;
+  constexpr bool kTable = coord_is_table<Coord>::value;   // coordinates from a float32 table
   // registers per tap row of a footprint: float32 frames two dwords, uint16 frames ONE dword that
   // holds both taps (any byte offset, as TapLoad<uint16_t, float> loads it)
   constexpr int NR = sizeof(ST) == 4 ? 2 : 1;
@@ -559,19 +588,22 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value, "float32 / uint16 frames");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
   constexpr int R = 2 * W;          // ring rows
+  constexpr int kMapOps = kTable ? 8 : 0;
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
-  unsigned lane4_opaque = 4u * lane;
-  asm volatile("" : "+v"(lane4_opaque));
   const unsigned voff = 16u * lane, moff = 4u * lane;
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
   const int yb = y0 - G::H;                          // first input row of the strip
   // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
   // filter's border mode per lane (c.uq, -1 = constant border), its rows per row on the scalar
   // unit; interior strips address the map rows as base + 4 lane + 256 k
-  const float* mxr = src.coord.mx + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
-  const float* myr = src.coord.my + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
+  const float* mxr = nullptr;
+  const float* myr = nullptr;
+  if constexpr (kTable) {
+    mxr = src.coord.mx + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
+    myr = src.coord.my + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
+  }
   auto row_of = [&](int t) -> int {   // resolved input row of strip row t (-1 = constant border)
     if constexpr (EDGE) return resolve_idx(yb + t, p.dh, p.cby);
     else return yb + t;
@@ -581,48 +613,69 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const v4i rs = v4i{(int)(unsigned)fb, (int)((unsigned)(fb >> 32) & 0xffffu), (int)src.src_bytes,
                      0x00020000};
   const unsigned pitch_b = (unsigned)s.pitch << SH;
-  // ring row = {x of pixels lane + 64 k, k = 0..3} for 64 lanes, then the same for y: a lane's
-  // four values are one aligned 16-byte word (conflict-free b128 accesses)
+  // a lane's four values of a record array are one aligned 16-byte word (conflict-free b128)
   float* rlane = ring + 4u * lane;
 
-  // this wave's map row of a block (clamped to the strip) -> pm[k] = x, pm[4 + k] = y
+  // ---- producer: this wave's row of a block.  Table sources: the 8 map dwords (clamped to the
+  // strip) into pm; the record is formed when they have arrived.
   float pm[8];
-  auto issue_map = [&](int r) {
-    if constexpr (EDGE) {
-      const int rr = row_of(r < T ? r : T - 1);
-      const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
+  auto issue_coords = [&](int r) {
+    if constexpr (kTable) {
+      if constexpr (EDGE) {
+        const int rr = row_of(r < T ? r : T - 1);
+        const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
 #pragma unroll
-      for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
 #pragma unroll
-      for (int k = 0; k < 4; k++) pipe_load1<0>(pm[4 + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
-    } else {
-      const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
-      static_for<0, 4>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        pipe_load1<256 * k>(pm[k], moff, mxr + o);
-      });
-      static_for<0, 4>([&](auto Kk) {
-        constexpr int k = decltype(Kk)::value;
-        pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
-      });
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[4 + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
+      } else {
+        const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
+        static_for<0, 4>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          pipe_load1<256 * k>(pm[k], moff, mxr + o);
+        });
+        static_for<0, 4>([&](auto Kk) {
+          constexpr int k = decltype(Kk)::value;
+          pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
+        });
+      }
     }
   };
-  auto publish_map = [&](int r) {   // registers -> ring row r mod R (after a wait that covers them)
-    vm_pin(pm);
-    float* slot = rlane + (unsigned)(r % R) * 512u;
-    *reinterpret_cast<v4f*>(slot) = v4f{pm[0], pm[1], pm[2], pm[3]};
-    *reinterpret_cast<v4f*>(slot + 256) = v4f{pm[4], pm[5], pm[6], pm[7]};
+  auto publish = [&](int r) {   // (table sources: after a wait that covers pm)
+    C sx[4], sy[4];
+    if constexpr (kTable) {
+      vm_pin(pm);
+#pragma unroll
+      for (int k = 0; k < 4; k++) { sx[k] = pm[k]; sy[k] = pm[4 + k]; }
+    } else {
+      const int rc = r < T ? r : T - 1;
+      const int rr = row_of(rc);
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if constexpr (EDGE) src.coord.get(c.uq[k] < 0 ? 0 : c.uq[k], rr < 0 ? 0 : rr, sx[k], sy[k]);
+        else src.coord.get(c.xs + (int)lane + 64 * k, rr, sx[k], sy[k]);
+      }
+    }
+    float tx[4], ty[4];
+    int e[4];
+    unsigned interior;
+    batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
+    float* slot = rlane + (unsigned)(r % R) * kRingRow;
+    *reinterpret_cast<v4i*>(slot) = v4i{e[0] << SH, e[1] << SH, e[2] << SH, e[3] << SH};
+    *reinterpret_cast<v4f*>(slot + 256) = v4f{tx[0], tx[1], tx[2], tx[3]};
+    *reinterpret_cast<v4f*>(slot + 512) = v4f{ty[0], ty[1], ty[2], ty[3]};
+    reinterpret_cast<unsigned*>(ring + (unsigned)(r % R) * kRingRow + 768)[lane] = interior;
   };
-  // footprints of ring row r: fractions, byte offsets of the top-left taps, interior bits
+  // ---- consumer: the footprints of ring row r
   auto footprint = [&](int r, float (&tx)[4], float (&ty)[4], unsigned (&off)[4],
                        unsigned& interior) {
-    const float* slot = rlane + (unsigned)(r % R) * 512u;
-    const v4f qx = *reinterpret_cast<const v4f*>(slot), qy = *reinterpret_cast<const v4f*>(slot + 256);
-    const float sx[4] = {qx.x, qx.y, qx.z, qx.w}, sy[4] = {qy.x, qy.y, qy.z, qy.w};
-    int e[4];
-    batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
-#pragma unroll
-    for (int k = 0; k < 4; k++) off[k] = (unsigned)e[k] << SH;
+    const float* slot = rlane + (unsigned)(r % R) * kRingRow;
+    const v4i qo = *reinterpret_cast<const v4i*>(slot);
+    const v4f qx = *reinterpret_cast<const v4f*>(slot + 256), qy = *reinterpret_cast<const v4f*>(slot + 512);
+    interior = reinterpret_cast<const unsigned*>(ring + (unsigned)(r % R) * kRingRow + 768)[lane];
+    off[0] = (unsigned)qo.x; off[1] = (unsigned)qo.y; off[2] = (unsigned)qo.z; off[3] = (unsigned)qo.w;
+    tx[0] = qx.x; tx[1] = qx.y; tx[2] = qx.z; tx[3] = qx.w;
+    ty[0] = qy.x; ty[1] = qy.y; ty[2] = qy.z; ty[3] = qy.w;
   };
   // the tap row of footprint k at byte offset o -> g[NR k .. NR k + NR - 1]
   auto gather = [&](float (&g)[4 * NR], int k, unsigned o) {
@@ -645,66 +698,48 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   float ga[4 * NR], gb[4 * NR];    // tap rows of the footprints (see NR)
   float txa[4], tya[4], txb[4], tyb[4];
   unsigned offa[4], offb[4], ina, inb;
-  v2f acc[K][2];
-#ifdef IPA_DEBUG_STAMP   // diagnostic build: cycles of the wave by phase (s_memtime), summed per launch
-  unsigned long long st_wait = 0, st_blend = 0, st_issue = 0, st_filter = 0, st_barrier = 0, st_last;
-  const unsigned long long st_begin = __builtin_amdgcn_s_memtime();
-#define IPA_STAMP(acc_)                                                  \
-  do {                                                                   \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();       \
-    acc_ += now_ - st_last;                                              \
-    st_last = now_;                                                      \
-  } while (0)
-#else
-#define IPA_STAMP(acc_) do {} while (0)
-#endif
 
-  // prologue: the rows of block 0 into the ring (row `wave` by this wave), barrier, the loads of
-  // block 1's row issued, row 0 resolved and its gathers in flight
-  issue_map((int)wave);
+  // prologue: the records of block 0 into the ring (row `wave` by this wave), barrier, the
+  // loads of block 1's row issued, row 0's gathers in flight
+  issue_coords((int)wave);
   vm_wait<0>();
-  publish_map((int)wave);
+  publish((int)wave);
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring rows are written
-  issue_map(W + (int)wave);
+  issue_coords(W + (int)wave);
   footprint(0, txa, tya, offa, ina);
 #pragma unroll
   for (int k = 0; k < 4; k++) gather(ga, k, offa[k]);
 #pragma unroll
   for (int k = 0; k < 4; k++) gather(gb, k, offa[k] + pitch_b);
 
-  // one iteration (row t, step ST = t mod W of its block); TOP / BOT = tap-row registers of row
-  // t; the bottom registers become the top registers of row t + 1
+  // one iteration (row t, step STEP = t mod W of its block); TOP / BOT = tap-row registers of
+  // row t; the bottom registers become the top registers of row t + 1
   auto step = [&](auto St, int t, float (&top)[4 * NR], float (&bot)[4 * NR], const float (&tx)[4],
                   const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
                   float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn) {
     constexpr int STEP = decltype(St)::value;
-#ifdef IPA_DEBUG_STAMP
-    st_last = __builtin_amdgcn_s_memtime();
-#endif
     if constexpr (STEP == W - 1) {
-      // the block's barrier: behind it the rows of the next block are in the ring and nobody
+      // the block's barrier: behind it the records of the next block are in the ring and nobody
       // reads this block's half any more; the next row of this wave is requested at once
 #ifndef IPA_DEBUG_NO_BARRIER   // (measurement only: racy without it)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
-      issue_map(t + 1 + W + (int)wave);
-      IPA_STAMP(st_barrier);
+      issue_coords(t + 1 + W + (int)wave);
     }
     // 1. the gathers of row t (and everything older): the only younger operations are the
-    //    store of iteration t-1 and, on the last step of a block, the 8 map loads above
+    //    store of iteration t-1 and, on the last step of a block, the map loads above
     // (rows past the strip - the last block is filled up - store nothing either)
     const bool stored = t >= K && t <= T;
     if constexpr (STEP == W - 1) {
-      if (stored) vm_wait<9>();
-      else vm_wait<8>();
+      if (stored) vm_wait<kMapOps + 1>();
+      else vm_wait<kMapOps>();
     } else {
       if (stored) vm_wait<1>();
       else vm_wait<0>();
     }
     pin_taps(top);
     pin_taps(bot);
-    IPA_STAMP(st_wait);
-    if constexpr (STEP == W - 2) publish_map(t + 2 + (int)wave);  // issued W - 1 iterations ago
+    if constexpr (STEP == W - 2) publish(t + 2 + (int)wave);  // (its loads: W - 1 iterations ago)
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
     float cur[4];
 #pragma unroll
@@ -735,21 +770,20 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #pragma unroll 1
       for (int k = 0; k < 4; k++) {
         if (!((interior >> k) & 1u)) {
-          float sx, sy;
+          C sx, sy;
           if constexpr (EDGE) {
             // (the column is resolved again: c.uq[k] with a run-time k would live in scratch)
             const int uqk = resolve_idx(c.xs + (int)lane + 64 * k, p.dw, p.cbx);
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
             if (!(rowt < 0 || uqk < 0))
-              xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, float>(s, sx, sy, src.cval);
+              xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           } else {
             src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
-            xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, float>(s, sx, sy, src.cval);
+            xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           }
         }
       }
     }
-    IPA_STAMP(st_blend);
     // 3. row t + 1: footprints from the ring, its top tap row into `bot` for the lanes whose
     //    footprint did not move straight down (no instruction at all when there is none), its
     //    bottom row into `top`
@@ -772,19 +806,17 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #pragma unroll
     for (int k = 0; k < 4; k++) gather(top, k, offn[k] + pitch_b);
     __builtin_amdgcn_wave_barrier();
-    IPA_STAMP(st_issue);
     // 4. filter + store
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
     const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
 #else
-    const v4f q = pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
+    const v4f q = filt.template row<EDGE>(xp, lane, c);
 #endif
     const int o = t - (K - 1);
     if (o >= 0 && o < nrows) {
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
-    IPA_STAMP(st_filter);
   };
 
   // the loop body is one block (W steps: the tap registers swap roles every step, W is even);
@@ -800,15 +832,6 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     });
     tb += W;
   } while (tb < Tb);
-#ifdef IPA_DEBUG_STAMP
-  if (p.dbg && lane == 0) {
-    const unsigned long long total = __builtin_amdgcn_s_memtime() - st_begin;
-    atomicAdd(p.dbg + 0, st_wait); atomicAdd(p.dbg + 1, st_blend); atomicAdd(p.dbg + 2, st_issue);
-    atomicAdd(p.dbg + 3, st_filter); atomicAdd(p.dbg + 4, st_barrier); atomicAdd(p.dbg + 5, total);
-    atomicAdd(p.dbg + 6, 1ull); atomicAdd(p.dbg + 7, (unsigned long long)Tb);
-  }
-#endif
-#undef IPA_STAMP
 }
 
 }  // namespace ipa

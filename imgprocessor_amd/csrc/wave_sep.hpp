@@ -131,9 +131,70 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& s
   }
 }
 
+// the separable filter as a policy of wave_run_strip_shared (wave_pipe.hpp): the sample row
+// arrives in the wave's LDS row; y pass into the K running intermediate rows, x pass on the
+// completed one through DPP wave shifts - the arithmetic and order of wave_sep_strip
+template <int K> struct SepFilter {
+  const SepTaps<K>& w;
+  float xcval;
+  float acc[K][4];
+  __device__ __forceinline__ SepFilter(const SepTaps<K>& taps, float xc) : w(taps), xcval(xc) {}
+  template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols& c) {
+    constexpr int H = K / 2;
+    const float4 q = *reinterpret_cast<const float4*>(xp + kRowPad + 4u * lane);
+    const float cur[4] = {q.x, q.y, q.z, q.w};
+    static_for<0, K>([&](auto Ii) {
+      constexpr int i = K - 1 - decltype(Ii)::value;
+#pragma unroll
+      for (int ox = 0; ox < 4; ox++) {
+        if constexpr (i == 0) acc[0][ox] = w.ky[0] * cur[ox];
+        else acc[i][ox] = fmaf(w.ky[i], cur[ox], acc[i - 1][ox]);
+      }
+    });
+    float mid[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) mid[k] = acc[K - 1][k];
+    if constexpr (EDGE) {
+      // constant x border: scipy pads the INTERMEDIATE with cval
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if (c.uu[k] < 0) mid[k] = xcval;
+    }
+    float win[4 + 2 * H];
+#pragma unroll
+    for (int k = 0; k < 4; k++) win[H + k] = mid[k];
+#pragma unroll
+    for (int m = 0; m < H; m++) {
+      win[H - 1 - m] = from_lane_below(mid[3 - m]);
+      win[H + 4 + m] = from_lane_above(mid[m]);
+    }
+    float out[4];
+#pragma unroll
+    for (int ox = 0; ox < 4; ox++) {
+      float a = w.kx[0] * win[ox];
+#pragma unroll
+      for (int j = 1; j < K; j++) a = fmaf(w.kx[j], win[ox + j], a);
+      out[ox] = a;
+    }
+    return v4f{out[0], out[1], out[2], out[3]};
+  }
+};
+
+// batches of bilinear-sampled frames share their footprint records through LDS (any coordinate
+// source, K = 3..9: the C3 chain - homography + separable 9+9 - evaluates its double
+// coordinates once per four frames)
+template <typename Src, int K> struct sep_shared : std::false_type {};
+template <typename ST, typename Coord, int K> struct sep_shared<SampleRowSrc<ST, kLinear, Coord>, K> {
+  static constexpr bool value = IPA_PIPE != 0 && IPA_PIPE_SHARED != 0 &&
+                                (std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value);
+};
+
 template <typename Src> struct sep_shares_maps : std::false_type {};
 template <typename ST, int I, typename Coord>
-struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> : coord_is_table<Coord> {};
+struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> {
+  static constexpr bool value = coord_is_table<Coord>::value ||
+                                (I == kLinear && IPA_PIPE != 0 && IPA_PIPE_SHARED != 0);
+};
 
 template <typename Src, int K>
 __global__ void __launch_bounds__(256)
@@ -157,6 +218,9 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     sid = b / groups;
   }
   float* xp = xpose + (kRegs ? 0 : wave * kRowStride * D);
+  constexpr bool kShared = sep_shared<Src, K>::value;
+  __shared__ __attribute__((aligned(16))) float mapring[kShared ? 2 * 4 * kRingRow : 4];
+  static_assert(!kShared || IPA_WPB == 4, "the separable kernel runs 4 waves per workgroup");
   if (sid >= p.strips) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
   src.set_frame(frame);
@@ -174,6 +238,14 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
+    if constexpr (kShared) {
+      if (p.frames_wg) {   // every wave of the workgroup: the same strip of another frame
+        SepFilter<K> filt(w, xcval);
+        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        return;
+      }
+    }
     if constexpr (!kRegs) {
       if (src.q5) wave_sep_strip<true, Src, K, 1>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
       else wave_sep_strip<true, Src, K, 0>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
@@ -185,6 +257,14 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     for (int k = 0; k < 4; k++) {
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
+    }
+    if constexpr (kShared) {
+      if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
+        SepFilter<K> filt(w, xcval);
+        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        return;
+      }
     }
     wave_sep_strip<false, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
   }
@@ -199,7 +279,8 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
     w.kx[i] = (float)kx[i];
   }
   p.strips_x = (p.dw + 247) / 248;
-  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K);
+  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false,
+                                sep_shared<Src, K>::value ? 2 : 0);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);

@@ -133,7 +133,6 @@ struct WaveParams {
   // strips another kernel computes (ring_stencil.hpp): skip[strip] != 0 -> nothing to do here
   const unsigned* skip = nullptr;
   int rim_only = 0;    // 1: the interior (FAST) strips belong to another kernel (wave_split.hpp)
-  unsigned long long* dbg = nullptr;  // -DIPA_DEBUG_STAMP builds: per-phase cycle sums
   unsigned frame_major = 0;  // n > 0: 1-D grid of n blocks per frame, frame after frame - with the
                              // XCD-contiguous block order every XCD then streams through whole
                              // frames of its own (plain filters: no rows shared between frames;
@@ -280,12 +279,14 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #endif
     // float32 frames sampled bilinearly from a coordinate table run their FAST strips on
     // wave_pipe.hpp for K <= 5 (K = 7 streams its coefficients: wave_stencil_big_kernel); the chunked loop is then the rim strips only: depth 1
-    static constexpr bool kPiped = IPA_PIPE && K <= IPA_PIPE_MAX_K && INTERP == kLinear &&
-                                   (std::is_same<ST, float>::value ||
-                                    std::is_same<ST, uint16_t>::value) &&
-                                   coord_is_table<Coord>::value;
+    // kShared: batches share footprint records through LDS (any coordinate source);
+    // kPiped: table sources, whose single frames run the hand-scheduled loop too
+    static constexpr bool kShared = IPA_PIPE && K <= IPA_PIPE_MAX_K && INTERP == kLinear &&
+                                    (std::is_same<ST, float>::value ||
+                                     std::is_same<ST, uint16_t>::value);
+    static constexpr bool kPiped = kShared && coord_is_table<Coord>::value;
     static constexpr int value =
-        INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kPiped ? 1 : IPA_SAMPLE_DEPTH)) : 1;
+        INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kShared ? 1 : IPA_SAMPLE_DEPTH)) : 1;
   };
   template <int D> struct Chunk {
     BatchTaps<ST, INTERP, 4> t[D];
@@ -652,12 +653,12 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   __shared__ __attribute__((aligned(16))) float xpose[kLead + IPA_WPB * kXp + kLead];
   float* xp = xpose + kLead + wave * kXp;
   // map rows shared by the frames of a workgroup (wave_run_strip_shared): a ring of 2 IPA_WPB rows
-  constexpr bool kShared = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && !STREAM && pipe_capable<Src, K>::value &&
-                           Src::kHasQ5;
+  constexpr bool kShared = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && !STREAM &&
+                           shared_capable<Src, K>::value;
 #ifndef IPA_DEBUG_LDS_PAD
 #define IPA_DEBUG_LDS_PAD 0   // measurement only: extra LDS floats per workgroup (lowers the occupancy)
 #endif
-  __shared__ __attribute__((aligned(16))) float mapring[(kShared ? 2 * IPA_WPB * 512 : 4) + IPA_DEBUG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float mapring[(kShared ? 2 * IPA_WPB * kRingRow : 4) + IPA_DEBUG_LDS_PAD];
   if (sid >= p.strips) return;  // whole wave
   if (p.skip && p.skip[sid]) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
@@ -686,8 +687,9 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     if constexpr (kShared) {
       // the waves of this workgroup are frames of ONE strip: every wave takes this branch
       if (p.frames_wg) {
-        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, false>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        DenseFilter<K> filt(wts);
+        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }
@@ -715,8 +717,9 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
       // (vector alignment holds: the strip runs on the shared-map loop with its columns and
       // rows resolved through the filter's border mode; 15 % of a 4K frame's strips)
       if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
-        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, true>(p, src, wts, xp, mapring, wave, c, y0, nrows, writer, dst);
+        DenseFilter<K> filt(wts);
+        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }

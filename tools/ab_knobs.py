@@ -61,7 +61,17 @@ def main():
     if 'c4' in what:
         u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
                             if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
+    Hm = None
+    if 'c3' in what or 'warp5' in what:
+        from imgprocessor_amd.utils import getPerspectiveTransform
+        quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+        rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+        Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))
+    g9 = ops.gaussian_kernel1d(1.0)
     calls = {
+        'c3': lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, 'linear', out=dst),
+        'warp5': lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k5, 'linear', out=dst),
+        'sep9map': lambda: ops.remap_sepconv2d(src, dmx, dmy, g9, g9, out=dst),
         'c4': lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst),
         'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
         'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
