@@ -51,7 +51,11 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------------ asm primitives --
 template <int N> __device__ __forceinline__ void vm_wait() {
+#ifdef IPA_DEBUG_WAIT0   // debugging: every counted wait drains the queue
+  asm volatile("s_waitcnt vmcnt(0)" ::"n"(N));
+#else
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N));
+#endif
 }
 // releases registers after a wait: no instruction, only the dependence
 // (the comment names the registers for tools/check_pipe_asm.py)
