@@ -50,6 +50,16 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #endif
 
 // ------------------------------------------------------------------ asm primitives --
+// A gfx9-family hazard the compiler cannot guard for us: a vector-memory instruction that reads
+// an SGPR (row base, buffer descriptor) a VALU instruction has written within the last 5 wait
+// states sees the OLD value.  hipcc inserts the no-ops for the vector-memory instructions it
+// emits itself; inline asm is opaque to its hazard recognizer - and under SGPR pressure it
+// restores exactly these scalars with v_readlane_b32 (VALU writes SGPR) right in front of our
+// statements.  Symptom (round 3): wrong first rows of strips in the 7x7 kernels (800 spilled
+// SGPRs), non-deterministic, while kernels with fewer spills ran clean.  Every statement that
+// carries a vector-memory instruction therefore opens with the five wait states.
+#define IPA_SGPR_HAZARD "s_nop 4\n\t"
+
 template <int N> __device__ __forceinline__ void vm_wait() {
 #ifdef IPA_DEBUG_WAIT0   // debugging: every counted wait drains the queue
   asm volatile("s_waitcnt vmcnt(0)" ::"n"(N));
@@ -67,18 +77,18 @@ __device__ __forceinline__ void vm_pin(float (&a)[8]) {
 __device__ __forceinline__ void vm_pin(v4f& a) { asm volatile("; pin %0" : "+v"(a)); }
 
 __device__ __forceinline__ void pipe_load4(v4f& x, unsigned voff, const float* sbase) {
-  asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(voff), "s"(sbase));
+  asm volatile(IPA_SGPR_HAZARD "global_load_dwordx4 %0, %1, %2" : "=v"(x) : "v"(voff), "s"(sbase));
 }
 template <int OFF> __device__ __forceinline__ void pipe_load1(float& x, unsigned voff,
                                                               const float* sbase) {
-  asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=v"(x) : "v"(voff), "s"(sbase), "n"(OFF));
+  asm volatile(IPA_SGPR_HAZARD "global_load_dword %0, %1, %2 offset:%3" : "=v"(x) : "v"(voff), "s"(sbase), "n"(OFF));
 }
 // one dword of the lanes in `m` (the halo lanes); the others keep x
 template <int OFF> __device__ __forceinline__ void pipe_load1_masked(float& x, unsigned voff,
                                                                      const float* sbase,
                                                                      unsigned long long m) {
   unsigned long long sv;
-  asm volatile("s_mov_b64 %1, exec\n\t"
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %1, exec\n\t"
                "s_mov_b64 exec, %4\n\t"
                "global_load_dword %0, %2, %3 offset:%5\n\t"
                "s_mov_b64 exec, %1"
@@ -91,9 +101,9 @@ template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, uns
   // (the s_nop: a VALU write of the data registers directly behind a 128-bit store needs one
   // wait state the compiler's hazard pass cannot see through the asm)
   if constexpr (NT)
-    asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
+    asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
   else
-    asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
+    asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
 }
 // the two dwords of a bilinear tap row at byte offset `off` of the frame (range-checked)
 __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v4i rs) {
@@ -103,23 +113,23 @@ __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v
   return;
 #endif
 #ifdef IPA_DEBUG_ONE_DWORD   // measurement only (WRONG results): one dword per tap row
-  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+  asm volatile(IPA_SGPR_HAZARD "buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
   b = a;
   return;
 #endif
-  asm volatile("buffer_load_dword %0, %2, %3, 0 offen\n\t"
+  asm volatile(IPA_SGPR_HAZARD "buffer_load_dword %0, %2, %3, 0 offen\n\t"
                "buffer_load_dword %1, %2, %3, 0 offen offset:4"
                : "=v"(a), "=v"(b)
                : "v"(off), "s"(rs));
 }
 // one dword (uint16 frames: both taps of a bilinear tap row)
 __device__ __forceinline__ void pipe_gather1(float& a, unsigned off, v4i rs) {
-  asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+  asm volatile(IPA_SGPR_HAZARD "buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
 }
 __device__ __forceinline__ void pipe_gather1_masked(float& a, unsigned off, v4i rs,
                                                     unsigned long long m) {
   unsigned long long sv;
-  asm volatile("s_mov_b64 %1, exec\n\t"
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %1, exec\n\t"
                "s_mov_b64 exec, %4\n\t"
                "buffer_load_dword %0, %2, %3, 0 offen\n\t"
                "s_mov_b64 exec, %1"
@@ -136,7 +146,7 @@ __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned
   return;
 #endif
 #ifdef IPA_DEBUG_ONE_DWORD
-  asm volatile("s_mov_b64 %1, exec\n\t"
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %1, exec\n\t"
                "s_mov_b64 exec, %4\n\t"
                "buffer_load_dword %0, %2, %3, 0 offen\n\t"
                "s_mov_b64 exec, %1"
@@ -145,7 +155,7 @@ __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned
   b = a;
   return;
 #endif
-  asm volatile("s_mov_b64 %2, exec\n\t"
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %2, exec\n\t"
                "s_mov_b64 exec, %5\n\t"
                "buffer_load_dword %0, %3, %4, 0 offen\n\t"
                "buffer_load_dword %1, %3, %4, 0 offen offset:4\n\t"

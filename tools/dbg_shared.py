@@ -17,7 +17,7 @@ u16 = np.round(f32 * 4095).astype(np.uint16)
 M = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
 for name, src in (('f32', f32), ('u16', u16)):
     d = ctx.to_device(src)
-    for ksz in (7,):
+    for ksz in (5, 7):
         k = rng.random((ksz, ksz)); k /= k.sum()
         for what, fn in (('maps', lambda: ops.remap_conv2d(d, dmx, dmy, k)),
                          ('homography', lambda: ops.warp_perspective_conv2d(d, M, (h, w), k))):
