@@ -32,8 +32,19 @@ def check(name, lines):
     ins, in_asm = [], False
     cur_loop, parent, pending_label = None, {}, None   # innermost loop header of the current block
     loop_of = []
+    asm_first = None   # first instruction of the current asm block
+    unguarded = []
     for ln, l in lines:
         t = l.strip()
+        # every asm block that carries a vector-memory instruction opens with `s_nop 4`: the
+        # VALU-writes-SGPR -> VMEM-reads-SGPR hazard (5 wait states) is invisible to the compiler
+        if t.startswith(';;#ASMSTART'):
+            asm_first = None
+        elif in_asm and t and not t.startswith(';'):
+            if asm_first is None:
+                asm_first = t
+            if t.split()[0].startswith(('buffer_', 'global_')) and asm_first.split(';')[0].strip() != 's_nop 4':
+                unguarded.append((ln, t))
         # LLVM's block comments: "in Loop: Header=BB0_729 Depth=1", "=>This Loop Header: Depth=1",
         # "Parent Loop BB0_729 Depth=1" + "=> This Inner Loop Header: Depth=2"
         if re.match(r'^(\.LBB\d+_\d+):|^; %bb\.\d+:', t):
@@ -174,6 +185,8 @@ def check(name, lines):
         transfer(bi, inn[bi], bad)
     nload = sum(1 for x in ins if x[1] == 'load')
     npin = sum(1 for x in ins if x[1] == 'pin')
+    for ln, t in unguarded:
+        bad.append((ln, 'vector-memory asm statement without the s_nop 4 hazard guard: ' + t, -1, ln))
     return bad, nload, npin
 
 
