@@ -77,10 +77,15 @@ int ipa_device_count(int* count);
 int ipa_ctx_create(int device_id, ipa_ctx** ctx);
 int ipa_ctx_destroy(ipa_ctx* ctx);
 int ipa_ctx_synchronize(ipa_ctx* ctx);
-/* Launch-shape knobs of a context ("strip_h", "frames_inner", "big_wave", "big_fused",
- * "stream_k", "ring", "ring_min", "group", "group_min", "group_ring").  ipa_ctx_create reads
- * their IPA_* environment defaults once; no launch path consults the environment.  The
- * reference has no counterpart (its numba / cv2 calls take no launch parameters). */
+/* Launch-shape knobs of a context (csrc/runtime.hip::kTuneNames is the list):
+ *   "strip_h" (0 = by launch size), "frames_inner", "frames_wg", "frame_major", "big_wave",
+ *   "big_fused", "stream_k", "pipe7", "ring_remap", "ring_min", "lens_cache", "u8_lz_lds";
+ *   only in `make EXPERIMENTAL=1` builds (rejected with IPA_ERR_UNSUPPORTED otherwise):
+ *   "group", "group_min", "group_ring", "ring", "pair", "ring_big", "ring_ablate";
+ *   read-only: "experimental" (1 in such a build).
+ * Values are range-checked (IPA_ERR_BAD_ARG).  ipa_ctx_create reads the IPA_* environment
+ * defaults once; no launch path consults the environment.  The reference has no counterpart
+ * (its numba / cv2 calls take no launch parameters). */
 int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value);
 int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value);
 /* name (e.g. "gfx950...") and compute-unit count of the context's device */
