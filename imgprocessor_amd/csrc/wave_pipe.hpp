@@ -48,6 +48,9 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef IPA_PIPE_REUSE
 #define IPA_PIPE_REUSE 1  // vertical tap reuse of the sampling source
 #endif
+#ifndef IPA_PIPE_STAY
+#define IPA_PIPE_STAY 1   // ... the footprint-did-not-move case from registers too
+#endif
 
 // ------------------------------------------------------------------ asm primitives --
 // A gfx9-family hazard the compiler cannot guard for us: a vector-memory instruction that reads
@@ -811,7 +814,17 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #pragma unroll
     for (int k = 0; k < 4; k++) {
 #if IPA_PIPE_REUSE
-      const unsigned long long need = __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b);
+      // three cases per lane: the footprint moved straight down (its top row = this row's
+      // bottom row, already in `bot`); it did NOT move (vertical scale < 1: both its tap rows
+      // are this row's - the top one is copied over from `top` before the gathers below
+      // overwrite it); anything else: gathered under the lanes' EXEC mask
+      const bool stay = IPA_PIPE_STAY && offn[k] == off[k];
+      if (__builtin_amdgcn_ballot_w64(stay)) {
+#pragma unroll
+        for (int j = 0; j < NR; j++) bot[NR * k + j] = stay ? top[NR * k + j] : bot[NR * k + j];
+      }
+      const unsigned long long need =
+          __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b && !stay);
       if (need) gather_masked(bot, k, offn[k], need);
 #else
       gather(bot, k, offn[k]);
