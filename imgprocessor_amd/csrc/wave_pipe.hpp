@@ -49,7 +49,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define IPA_PIPE_REUSE 1  // vertical tap reuse of the sampling source
 #endif
 #ifndef IPA_PIPE_STAY
-#define IPA_PIPE_STAY 1   // ... the footprint-did-not-move case from registers too
+#define IPA_PIPE_STAY 0   // ... the footprint-did-not-move case from registers too (measured: no gain, 1.035 vs 1.034 ms)
 #endif
 
 // ------------------------------------------------------------------ asm primitives --
@@ -317,8 +317,9 @@ template <typename Coord, int K> struct pipe_unshared<SampleRowSrc<float, kLinea
 // (one extra EXEC-masked load per row: 64 x 4K 5x5 0.97 -> 0.90 ms, 0.85 with 32-row strips).
 // NOT the sampling source: there the halo costs a fifth sample per lane and row - six more
 // vector-memory instructions, and an instruction costs the CU's vector-memory path ~4.6 clocks
-// WHATEVER its EXEC mask is, EXEC = 0 included (tools/pipe_micro.hip) - 1.30 -> 1.42 ms
-// (IPA_HALO_SAMPLE=1 builds it)
+// WHATEVER its EXEC mask is, EXEC = 0 included (tools/pipe_micro.hip) - 1.30 -> 1.42 ms on the
+// unshared loop, 0.969 -> 1.015 ms on the shared-record loop (same bits; IPA_HALO_SAMPLE=1
+// builds both)
 #ifndef IPA_HALO_SAMPLE
 #define IPA_HALO_SAMPLE 0
 #endif
@@ -572,7 +573,9 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 // instead of issued (43 % of them on the 4K lens map).
 // The filter is a policy: dense K x K (DenseFilter) or separable K + K (SepFilter, wave_sep.hpp).
 // Same footprints, same words, same blend as wave_run_strip_pipe / the chunked loop: identical bits.
-constexpr int kRingRow = 3 * 256 + 64;   // floats per record row: offsets, tx, ty, inside bits
+// floats per record row: offsets, tx, ty (256 each), inside bits (64); HALO geometry: + the halo
+// sample's offset, tx, ty per lane (3 x 64)
+template <bool HALO> struct ring_row { static constexpr int value = HALO ? 1024 : 832; };
 
 template <int K> struct DenseFilter {
   static constexpr int kTaps = K;
@@ -589,14 +592,19 @@ template <int K> struct DenseFilter {
   }
 };
 
-template <int K, int QM, bool EDGE, typename Filter, typename ST, typename Coord>
+template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       const SampleRowSrc<ST, kLinear, Coord>& src,
                                                       Filter& filt, float* xp, float* ring,
                                                       unsigned wave, const Cols& c, int y0,
                                                       int nrows, bool writer, float* dst) {
-  using G = wave_geom<K, false>;
+  using G = wave_geom<K, HALO>;
   using C = typename Coord::coord_t;
+  // samples per lane and row: pixels lane + 64 k (k = 0..3) and, in the HALO geometry (256-px
+  // aligned strips, all lanes store), the halo pixel of lanes 0 .. 2H-1 as a fifth sample under
+  // an EXEC mask
+  constexpr int NS = HALO ? 5 : 4;
+  constexpr int RR = ring_row<HALO>::value;   // floats per record row
   constexpr bool kTable = coord_is_table<Coord>::value;   // coordinates from a float32 table
   // registers per tap row of a footprint: float32 frames two dwords, uint16 frames ONE dword that
   // holds both taps (any byte offset, as TapLoad<uint16_t, float> loads it)
@@ -605,7 +613,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value, "float32 / uint16 frames");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
   constexpr int R = 2 * W;          // ring rows
-  constexpr int kMapOps = kTable ? 8 : 0;
+  constexpr int kMapOps = kTable ? 2 * NS : 0;
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
@@ -632,10 +640,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned pitch_b = (unsigned)s.pitch << SH;
   // a lane's four values of a record array are one aligned 16-byte word (conflict-free b128)
   float* rlane = ring + 4u * lane;
+  // HALO: the halo pixel of lane j < 2H is column xs - H + halo_pos(j); the lanes' mask
+  const unsigned hcol = halo_pos<G::H>(lane);
+  const unsigned long long hmask = (1ull << (2 * G::H)) - 1ull;
 
   // ---- producer: this wave's row of a block.  Table sources: the 8 map dwords (clamped to the
   // strip) into pm; the record is formed when they have arrived.
-  float pm[8];
+  float pm[2 * NS] = {};
   auto issue_coords = [&](int r) {
     if constexpr (kTable) {
       if constexpr (EDGE) {
@@ -643,27 +654,32 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
         const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
 #pragma unroll
         for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], 4u * (unsigned)(c.uh < 0 ? 0 : c.uh), mxr + o, hmask);
 #pragma unroll
-        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[4 + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[NS + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], 4u * (unsigned)(c.uh < 0 ? 0 : c.uh), myr + o, hmask);
       } else {
         const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
           pipe_load1<256 * k>(pm[k], moff, mxr + o);
         });
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], 4u * hcol, mxr + o - G::H, hmask);
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          pipe_load1<256 * k>(pm[4 + k], moff, myr + o);
+          pipe_load1<256 * k>(pm[NS + k], moff, myr + o);
         });
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], 4u * hcol, myr + o - G::H, hmask);
       }
     }
   };
   auto publish = [&](int r) {   // (table sources: after a wait that covers pm)
-    C sx[4], sy[4];
+    C sx[NS], sy[NS];
     if constexpr (kTable) {
-      vm_pin(pm);
 #pragma unroll
-      for (int k = 0; k < 4; k++) { sx[k] = pm[k]; sy[k] = pm[4 + k]; }
+      for (int k = 0; k < 2 * NS; k++) vm_pin(pm[k]);
+#pragma unroll
+      for (int k = 0; k < NS; k++) { sx[k] = pm[k]; sy[k] = pm[NS + k]; }
     } else {
       const int rc = r < T ? r : T - 1;
       const int rr = row_of(rc);
@@ -672,49 +688,72 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
         if constexpr (EDGE) src.coord.get(c.uq[k] < 0 ? 0 : c.uq[k], rr < 0 ? 0 : rr, sx[k], sy[k]);
         else src.coord.get(c.xs + (int)lane + 64 * k, rr, sx[k], sy[k]);
       }
+      if constexpr (HALO) {
+        if constexpr (EDGE) src.coord.get(c.uh < 0 ? 0 : c.uh, rr < 0 ? 0 : rr, sx[4], sy[4]);
+        else src.coord.get(c.xs - G::H + (int)(lane < 2u * G::H ? hcol : (unsigned)G::H), rr, sx[4], sy[4]);
+      }
     }
-    float tx[4], ty[4];
-    int e[4];
+    float tx[NS], ty[NS];
+    int e[NS];
     unsigned interior;
-    batch_footprint_linear<4, QM>(s, sx, sy, tx, ty, e, interior);
-    float* slot = rlane + (unsigned)(r % R) * kRingRow;
+    batch_footprint_linear<NS, QM>(s, sx, sy, tx, ty, e, interior);
+    if constexpr (HALO) interior |= lane < 2u * G::H ? 0u : 0x10u;   // lanes without a halo pixel
+    float* slot = rlane + (unsigned)(r % R) * RR;
     *reinterpret_cast<v4i*>(slot) = v4i{e[0] << SH, e[1] << SH, e[2] << SH, e[3] << SH};
     *reinterpret_cast<v4f*>(slot + 256) = v4f{tx[0], tx[1], tx[2], tx[3]};
     *reinterpret_cast<v4f*>(slot + 512) = v4f{ty[0], ty[1], ty[2], ty[3]};
-    reinterpret_cast<unsigned*>(ring + (unsigned)(r % R) * kRingRow + 768)[lane] = interior;
+    float* rowp = ring + (unsigned)(r % R) * RR;
+    reinterpret_cast<unsigned*>(rowp + 768)[lane] = interior;
+    if constexpr (HALO) {
+      reinterpret_cast<int*>(rowp + 832)[lane] = e[4] << SH;
+      rowp[896 + lane] = tx[4];
+      rowp[960 + lane] = ty[4];
+    }
   };
   // ---- consumer: the footprints of ring row r
-  auto footprint = [&](int r, float (&tx)[4], float (&ty)[4], unsigned (&off)[4],
+  auto footprint = [&](int r, float (&tx)[NS], float (&ty)[NS], unsigned (&off)[NS],
                        unsigned& interior) {
-    const float* slot = rlane + (unsigned)(r % R) * kRingRow;
+    const float* slot = rlane + (unsigned)(r % R) * RR;
+    const float* rowp = ring + (unsigned)(r % R) * RR;
     const v4i qo = *reinterpret_cast<const v4i*>(slot);
     const v4f qx = *reinterpret_cast<const v4f*>(slot + 256), qy = *reinterpret_cast<const v4f*>(slot + 512);
-    interior = reinterpret_cast<const unsigned*>(ring + (unsigned)(r % R) * kRingRow + 768)[lane];
+    interior = reinterpret_cast<const unsigned*>(rowp + 768)[lane];
     off[0] = (unsigned)qo.x; off[1] = (unsigned)qo.y; off[2] = (unsigned)qo.z; off[3] = (unsigned)qo.w;
     tx[0] = qx.x; tx[1] = qx.y; tx[2] = qx.z; tx[3] = qx.w;
     ty[0] = qy.x; ty[1] = qy.y; ty[2] = qy.z; ty[3] = qy.w;
+    if constexpr (HALO) {
+      off[4] = reinterpret_cast<const unsigned*>(rowp + 832)[lane];
+      tx[4] = rowp[896 + lane];
+      ty[4] = rowp[960 + lane];
+    }
   };
   // the tap row of footprint k at byte offset o -> g[NR k .. NR k + NR - 1]
-  auto gather = [&](float (&g)[4 * NR], int k, unsigned o) {
+  auto gather = [&](float (&g)[NS * NR], int k, unsigned o) {
     if constexpr (NR == 2) pipe_gather2(g[2 * k], g[2 * k + 1], o, rs);
     else pipe_gather1(g[k], o, rs);
   };
-  auto gather_masked = [&](float (&g)[4 * NR], int k, unsigned o, unsigned long long m) {
+  auto gather_masked = [&](float (&g)[NS * NR], int k, unsigned o, unsigned long long m) {
     if constexpr (NR == 2) pipe_gather2_masked(g[2 * k], g[2 * k + 1], o, rs, m);
     else pipe_gather1_masked(g[k], o, rs, m);
   };
-  auto pin_taps = [&](float (&g)[4 * NR]) {
+  auto pin_taps = [&](float (&g)[NS * NR]) {
 #pragma unroll
-    for (int k = 0; k < 4 * NR; k++) vm_pin(g[k]);
+    for (int k = 0; k < NS * NR; k++) vm_pin(g[k]);
   };
-  auto taps_of = [&](const float (&g)[4 * NR], int k, float& v0, float& v1) {
+  // a full tap row: the strip's pixels by the whole wave, the halo sample by its lanes
+  auto gather_row = [&](float (&g)[NS * NR], const unsigned (&off)[NS], unsigned add) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) gather(g, k, off[k] + add);
+    if constexpr (HALO) gather_masked(g, 4, off[4] + add, hmask);
+  };
+  auto taps_of = [&](const float (&g)[NS * NR], int k, float& v0, float& v1) {
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = g[2 * k + 1]; }
     else TapLoad<uint16_t, float>::unpack(__float_as_uint(g[k]), v0, v1);
   };
 
-  float ga[4 * NR], gb[4 * NR];    // tap rows of the footprints (see NR)
-  float txa[4], tya[4], txb[4], tyb[4];
-  unsigned offa[4], offb[4], ina, inb;
+  float ga[NS * NR] = {}, gb[NS * NR] = {};    // tap rows of the footprints (see NR)
+  float txa[NS], tya[NS], txb[NS], tyb[NS];
+  unsigned offa[NS], offb[NS], ina, inb;
 
   // prologue: the records of block 0 into the ring (row `wave` by this wave), barrier, the
   // loads of block 1's row issued, row 0's gathers in flight
@@ -724,16 +763,14 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // the ring rows are written
   issue_coords(W + (int)wave);
   footprint(0, txa, tya, offa, ina);
-#pragma unroll
-  for (int k = 0; k < 4; k++) gather(ga, k, offa[k]);
-#pragma unroll
-  for (int k = 0; k < 4; k++) gather(gb, k, offa[k] + pitch_b);
+  gather_row(ga, offa, 0u);
+  gather_row(gb, offa, pitch_b);
 
   // one iteration (row t, step STEP = t mod W of its block); TOP / BOT = tap-row registers of
   // row t; the bottom registers become the top registers of row t + 1
-  auto step = [&](auto St, int t, float (&top)[4 * NR], float (&bot)[4 * NR], const float (&tx)[4],
-                  const float (&ty)[4], const unsigned (&off)[4], unsigned interior,
-                  float (&txn)[4], float (&tyn)[4], unsigned (&offn)[4], unsigned& interiorn) {
+  auto step = [&](auto St, int t, float (&top)[NS * NR], float (&bot)[NS * NR], const float (&tx)[NS],
+                  const float (&ty)[NS], const unsigned (&off)[NS], unsigned interior,
+                  float (&txn)[NS], float (&tyn)[NS], unsigned (&offn)[NS], unsigned& interiorn) {
     constexpr int STEP = decltype(St)::value;
     if constexpr (STEP == W - 1) {
       // the block's barrier: behind it the records of the next block are in the ring and nobody
@@ -758,9 +795,9 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     pin_taps(bot);
     if constexpr (STEP == W - 2) publish(t + 2 + (int)wave);  // (its loads: W - 1 iterations ago)
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
-    float cur[4];
+    float cur[NS];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NS; k++) {
       const float wx0 = 1.f - tx[k], wx1 = tx[k], wy0 = 1.f - ty[k], wy1 = ty[k];
       float v00, v01, v10, v11;
       taps_of(top, k, v00, v01);
@@ -778,25 +815,31 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       // positions the filter's constant border supplies
 #pragma unroll
       for (int k = 0; k < 4; k++) cur[k] = (rowt < 0 || c.uq[k] < 0) ? src.ccval : cur[k];
+      if constexpr (HALO) cur[4] = (rowt < 0 || c.uh < 0) ? src.ccval : cur[4];
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
-    if (__builtin_amdgcn_ballot_w64(interior != 0xfu)) {
+    if constexpr (HALO) {
+      if (lane < 2u * G::H) xp[kRowPad - G::H + hcol] = cur[4];
+    }
+    if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
       // footprints touching the source border (rare): redo them tap by tap, straight into the
       // LDS row - ONE copy of the border-aware sampler per step (a loop, not unrolled)
 #pragma unroll 1
-      for (int k = 0; k < 4; k++) {
+      for (int k = 0; k < NS; k++) {
         if (!((interior >> k) & 1u)) {
           C sx, sy;
+          // pixel column of sample k and its place in the LDS row
+          const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
+          const unsigned pos = k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol;
           if constexpr (EDGE) {
             // (the column is resolved again: c.uq[k] with a run-time k would live in scratch)
-            const int uqk = resolve_idx(c.xs + (int)lane + 64 * k, p.dw, p.cbx);
+            const int uqk = resolve_idx(col, p.dw, p.cbx);
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
-            if (!(rowt < 0 || uqk < 0))
-              xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+            if (!(rowt < 0 || uqk < 0)) xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           } else {
-            src.coord.get(c.xs + (int)lane + 64 * k, yb + t, sx, sy);
-            xp[kRowPad + 64u * k + lane] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+            src.coord.get(col, yb + t, sx, sy);
+            xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           }
         }
       }
@@ -806,13 +849,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     //    bottom row into `top`
 #ifdef IPA_DEBUG_NO_FOOTPRINT   // measurement only (WRONG results): the footprint moves straight down
 #pragma unroll
-    for (int k = 0; k < 4; k++) { txn[k] = tx[k]; tyn[k] = ty[k]; offn[k] = off[k] + pitch_b; }
-    interiorn = 0xfu;
+    for (int k = 0; k < NS; k++) { txn[k] = tx[k]; tyn[k] = ty[k]; offn[k] = off[k] + pitch_b; }
+    interiorn = (1u << NS) - 1u;
 #else
     footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NS; k++) {
 #if IPA_PIPE_REUSE
       // three cases per lane: the footprint moved straight down (its top row = this row's
       // bottom row, already in `bot`); it did NOT move (vertical scale < 1: both its tap rows
@@ -823,15 +866,16 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #pragma unroll
         for (int j = 0; j < NR; j++) bot[NR * k + j] = stay ? top[NR * k + j] : bot[NR * k + j];
       }
-      const unsigned long long need =
+      unsigned long long need =
           __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b && !stay);
+      if (k == 4) need &= hmask;
       if (need) gather_masked(bot, k, offn[k], need);
 #else
-      gather(bot, k, offn[k]);
+      if (k < 4) gather(bot, k, offn[k]);
+      else gather_masked(bot, k, offn[k], hmask);
 #endif
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) gather(top, k, offn[k] + pitch_b);
+    gather_row(top, offn, pitch_b);
     __builtin_amdgcn_wave_barrier();
     // 4. filter + store
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out

@@ -219,7 +219,7 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   }
   float* xp = xpose + (kRegs ? 0 : wave * kRowStride * D);
   constexpr bool kShared = sep_shared<Src, K>::value;
-  __shared__ __attribute__((aligned(16))) float mapring[kShared ? 2 * 4 * kRingRow : 4];
+  __shared__ __attribute__((aligned(16))) float mapring[kShared ? 2 * 4 * ring_row<false>::value : 4];
   static_assert(!kShared || IPA_WPB == 4, "the separable kernel runs 4 waves per workgroup");
   if (sid >= p.strips) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
@@ -241,8 +241,8 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     if constexpr (kShared) {
       if (p.frames_wg) {   // every wave of the workgroup: the same strip of another frame
         SepFilter<K> filt(w, xcval);
-        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_shared<K, 1, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }
@@ -261,8 +261,8 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     if constexpr (kShared) {
       if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         SepFilter<K> filt(w, xcval);
-        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_shared<K, 1, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }

@@ -658,7 +658,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
 #ifndef IPA_DEBUG_LDS_PAD
 #define IPA_DEBUG_LDS_PAD 0   // measurement only: extra LDS floats per workgroup (lowers the occupancy)
 #endif
-  __shared__ __attribute__((aligned(16))) float mapring[(kShared ? 2 * IPA_WPB * kRingRow : 4) + IPA_DEBUG_LDS_PAD];
+  __shared__ __attribute__((aligned(16))) float mapring[(kShared ? 2 * IPA_WPB * ring_row<HALO>::value : 4) + IPA_DEBUG_LDS_PAD];
   if (sid >= p.strips) return;  // whole wave
   if (p.skip && p.skip[sid]) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
@@ -688,8 +688,8 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
       // the waves of this workgroup are frames of ONE strip: every wave takes this branch
       if (p.frames_wg) {
         DenseFilter<K> filt(wts);
-        if (src.q5) wave_run_strip_shared<K, 1, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_shared<K, 1, false, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, false, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }
@@ -713,18 +713,18 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
       c.uu[k] = resolve_idx(c.xo + k, p.dw, p.cbx);
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
     }
+    if constexpr (HALO)
+      c.uh = resolve_idx(xs - G::H + (int)halo_pos<G::H>(lane < 2 * G::H ? (unsigned)lane : 0u), p.dw, p.cbx);
     if constexpr (kShared) {
       // (vector alignment holds: the strip runs on the shared-map loop with its columns and
       // rows resolved through the filter's border mode; 15 % of a 4K frame's strips)
       if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         DenseFilter<K> filt(wts);
-        if (src.q5) wave_run_strip_shared<K, 1, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, true>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if (src.q5) wave_run_strip_shared<K, 1, true, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        else wave_run_strip_shared<K, 0, true, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         return;
       }
     }
-    if constexpr (HALO)
-      c.uh = resolve_idx(xs - G::H + (int)halo_pos<G::H>(lane < 2 * G::H ? (unsigned)lane : 0u), p.dw, p.cbx);
     if constexpr (HALO && !Src::kHasQ5 && IPA_PIPE_EDGE) {
       // plain rows: the rim strips on the hand-scheduled loop too (resolved columns and rows)
       if (p.vec_out && (p.dw & 3) == 0) {

@@ -62,6 +62,8 @@ def main():
     g = np.exp(-0.5 * np.arange(-2, 3) ** 2)
     g /= g.sum()
     k5 = np.outer(g, g)
+    g7 = np.exp(-0.5 * (np.arange(-3, 4) / 1.5) ** 2)
+    k7 = np.outer(g7, g7) / g7.sum() ** 2
     rng = np.random.default_rng(0)
     one = rng.random((16, h, w), dtype=np.float32)
     host = np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch]
@@ -98,6 +100,7 @@ def main():
                 mod.dmx, mod.dmy = view(first.dmx), view(first.dmy)
         calls = {
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
+            'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
             'remap': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, out=m.dst),
             'copy': lambda m=mod: m.dst.copy_from(m.src),
