@@ -88,6 +88,12 @@ PROTOTYPES = {
     'ipa_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _dp],
     'ipa_fast_idw_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _vp, _dp, _i, _i],
     'ipa_fast_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _vp, _dp, _i, _i],
+    'ipa_unstructured_idw_dev': [_vp, _vp, _i, _i, _i, _l, _dp, _dp, _dp, _i, _d],
+    'ipa_unstructured_idw': [_vp, _vp, _i, _i, _i, _dp, _dp, _dp, _i, _d],
+    'ipa_circular_idw_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _d, _d, _d, _d, _d],
+    'ipa_circular_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d, _d, _d, _d, _d],
+    'ipa_cross_avg_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _d],
+    'ipa_cross_avg_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d],
 }
 _CHARP = {'ipa_status_string': [_i], 'ipa_last_error': [_vp]}
 

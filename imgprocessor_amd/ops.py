@@ -711,3 +711,74 @@ def fast_idw_fill(grid, mask, offsets, weights, minnvals, ctx=None):
     ctx._check(ctx._lib.ipa_fast_idw_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h,
                                           wd, _p(offs), wp, n, int(minnvals)), 'fast_idw_fill')
     return grid
+
+
+def _fill_grid(grid):
+    if not (isinstance(grid, np.ndarray) and grid.flags.c_contiguous and grid.ndim == 2):
+        raise ValueError('grid must be a C-contiguous 2-D ndarray (it is modified in place)')
+    if grid.dtype not in (np.float32, np.float64):
+        raise TypeError('grid must be float32 or float64')
+    return grid.shape
+
+
+def unstructured_idw(x, y, v, grid, power=2, ctx=None):
+    """every pixel of `grid` from n scattered points (interpolate2dUnstructuredIDW), in place"""
+    xs, ys, vs = (np.ascontiguousarray(np.ravel(a), dtype=np.float64) for a in (x, y, v))
+    if not (xs.size == ys.size == vs.size and vs.size >= 1):
+        raise ValueError('x, y, v must be 1-D, of equal length >= 1')
+    dp = C.POINTER(C.c_double)
+    px, py, pv = (a.ctypes.data_as(dp) for a in (xs, ys, vs))
+    ctx = _ctx_of(grid, ctx=ctx)
+    if _is_dev(grid):
+        h, w = grid.shape
+        ctx._check(ctx._lib.ipa_unstructured_idw_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype), h,
+                                                     w, w, px, py, pv, int(vs.size), float(power)),
+                   'unstructured_idw')
+        return grid
+    h, w = _fill_grid(grid)
+    ctx._check(ctx._lib.ipa_unstructured_idw(ctx.handle, _p(grid), dtype_id(grid.dtype), h, w, px,
+                                             py, pv, int(vs.size), float(power)),
+               'unstructured_idw')
+    return grid
+
+
+def circular_idw_fill(grid, mask, ksize, power=2, fr=1, fphi=1, cx=0, cy=0, ctx=None):
+    """in-place IDW hole filling with polar distances (interpolateCircular2dStructuredIDW)"""
+    ctx = _ctx_of(grid, mask, ctx=ctx)
+    args = (int(ksize), float(power), float(fr), float(fphi), float(cx), float(cy))
+    if _is_dev(grid):
+        if not _is_dev(mask):
+            raise TypeError('device grid needs a device mask')
+        h, w = grid.shape
+        ctx._check(ctx._lib.ipa_circular_idw_fill_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype),
+                                                      mask.ptr, h, w, w, *args),
+                   'circular_idw_fill')
+        return grid
+    h, w = _fill_grid(grid)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    if m.shape != grid.shape:
+        raise ValueError('mask and grid differ in shape')
+    ctx._check(ctx._lib.ipa_circular_idw_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h,
+                                              w, *args), 'circular_idw_fill')
+    return grid
+
+
+def cross_avg_fill(grid, mask, ksize, power=2, ctx=None):
+    """in-place fill of large holes from the four axis directions
+    (interpolate2dStructuredCrossAvg)"""
+    ctx = _ctx_of(grid, mask, ctx=ctx)
+    if _is_dev(grid):
+        if not _is_dev(mask):
+            raise TypeError('device grid needs a device mask')
+        h, w = grid.shape
+        ctx._check(ctx._lib.ipa_cross_avg_fill_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype),
+                                                   mask.ptr, h, w, w, int(ksize), float(power)),
+                   'cross_avg_fill')
+        return grid
+    h, w = _fill_grid(grid)
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    if m.shape != grid.shape:
+        raise ValueError('mask and grid differ in shape')
+    ctx._check(ctx._lib.ipa_cross_avg_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h, w,
+                                           int(ksize), float(power)), 'cross_avg_fill')
+    return grid

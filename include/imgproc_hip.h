@@ -356,6 +356,39 @@ int ipa_fast_idw_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* 
 int ipa_fast_idw_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
                       const int32_t* offsets, const double* weights, int n, int minnvals);
 
+/* replaces interpolate/interpolate2dUnstructuredIDW.py:7-38: every pixel of the grid
+ * becomes sum(w v) / sum(w) over the n scattered points (x = ROW coordinate, y = column - the
+ * reference indexes grid[i, j] with i against x), w = 1 / ((x-i)^2 + (y-j)^2)^(power/2), summed
+ * in point order in float64; a pixel that is a point takes the first such point's value.
+ * x, y, v: HOST doubles.  Writes every pixel of d_grid (F32 or F64). */
+int ipa_unstructured_idw_dev(ipa_ctx* ctx, void* d_grid, int dtype, int h, int w, long pitch,
+                             const double* x, const double* y, const double* v, int n,
+                             double power);
+int ipa_unstructured_idw(ipa_ctx* ctx, void* grid, int dtype, int h, int w, const double* x,
+                         const double* y, const double* v, int n, double power);
+
+/* replaces interpolate/interpolateCircular2dStructuredIDW.py:7-69 as written: IDW over the
+ * window [i-k, min(i+k, h)) x [j-k, min(j+k, h)) (upper ends exclusive) with the distance
+ * measured in polar coordinates about (cx, cy): ((fr dr)^2 + (fphi dphi midR)^2)^2; rows AND
+ * columns run to shape[0] (:16-17), so w >= h is required and columns >= h stay untouched.
+ * In place on d_grid (F32 or F64). */
+int ipa_circular_idw_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* d_mask, int h,
+                              int w, long pitch, int ksize, double power, double fr, double fphi,
+                              double cx, double cy);
+int ipa_circular_idw_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
+                          int ksize, double power, double fr, double fphi, double cx, double cy);
+
+/* replaces interpolate/interpolate2dStructuredCrossAvg.py:7-115 as written: every masked
+ * pixel blends the local averages (unmasked pixels within +-ksize) at the nearest unmasked
+ * pixel towards row 0, towards column 0 and towards the last column with weights
+ * 1 / distance^(power/2) (float32, normalised); the source's slot quirks (the search towards
+ * the last row only validates the column-0 slot, which then keeps the previous pixel's value)
+ * are reproduced.  In place on d_grid (F32 or F64). */
+int ipa_cross_avg_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t* d_mask, int h,
+                           int w, long pitch, int ksize, double power);
+int ipa_cross_avg_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
+                       int ksize, double power);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1135,6 +1135,176 @@ int orc_pos_to_intensity_unc(const void* image, int dt, long s0, long s1, const 
   return 0;
 }
 
+/* interpolate/interpolate2dUnstructuredIDW.py:7-38.  n scattered points (x = ROW coordinate,
+ * y = column, as the reference indexes grid[i, j] with i against x), every grid pixel gets
+ * sum(w v) / sum(w), w = 1 / (dx^2 + dy^2)^(power/2), summed in point order in float64; a pixel
+ * that IS a point takes the value of the first such point. */
+int orc_unstructured_idw(void* grid, int dt, long gx, long gy, const double* x, const double* y,
+                         const double* v, long n, double power) {
+  if (n < 1) return -1;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      int over = 0;
+      double sumWi = 0.0, value = 0.0;
+      for (long k = 0; k < n; k++) {
+        if (x[k] == (double)i && y[k] == (double)j) {
+          store_px(grid, dt, i * gy + j, v[k]);
+          over = 1;
+          break;
+        }
+        double dx = x[k] - (double)i, dy = y[k] - (double)j;
+        double wi = 1.0 / pow(dx * dx + dy * dy, 0.5 * power);
+        sumWi += wi;
+        value += wi * v[k];
+      }
+      if (!over) store_px(grid, dt, i * gy + j, value / sumWi);
+    }
+  return 0;
+}
+
+/* interpolate/interpolateCircular2dStructuredIDW.py:7-69, as written: the column count is
+ * taken from shape[0] too (gy = grid.shape[0], :16-17), so columns >= shape[0] are neither
+ * filled nor read (s1 < s0 indexes out of bounds in the reference: -2 here); the window is
+ * [i-k, min(i+k, gx)) x [j-k, min(j+k, gx)) - the upper end EXCLUSIVE, unlike the plain IDW;
+ * dist is the SQUARE of the squared polar distance (:56).  dist == 0 (two pixels at one polar
+ * position under the weights given) divides by zero in the reference and is not covered. */
+int orc_circular_idw(void* grid, int dt, const uint8_t* mask, long s0, long s1, long kernel,
+                     double power, double fr, double fphi, double cx, double cy) {
+  if (s1 < s0) return -2;
+  const long gx = s0, gy = s0;
+  size_t es = dtype_size(dt);
+  void* in = malloc((size_t)s0 * s1 * es);
+  if (!in) return -1;
+  memcpy(in, grid, (size_t)s0 * s1 * es); /* masked px are never read: copy == in-place */
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 4)
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      if (!mask[i * s1 + j]) continue;
+      long xmn = i - kernel < 0 ? 0 : i - kernel, xmx = i + kernel > gx ? gx : i + kernel;
+      long ymn = j - kernel < 0 ? 0 : j - kernel, ymx = j + kernel > gx ? gy : j + kernel;
+      double sumWi = 0.0, value = 0.0;
+      double di = (double)i - cx, dj = (double)j - cy;
+      double R = pow(di * di + dj * dj, 0.5), PHI = atan2(dj, di);
+      for (long xi = xmn; xi < xmx; xi++)
+        for (long yi = ymn; yi < ymx; yi++)
+          if ((xi != i || yi != j) && !mask[xi * s1 + yi]) {
+            double ni = (double)xi - cx, nj = (double)yi - cy;
+            double nR = pow(ni * ni + nj * nj, 0.5);
+            double dr = R - nR, midR = 0.5 * (R + nR);
+            double nphi = atan2(nj, ni);
+            double a = fabs(PHI - nphi), b = 2 * M_PI - a;
+            double dphi = (b < a ? b : a) * midR;
+            double q = (fr * dr) * (fr * dr) + (fphi * dphi) * (fphi * dphi);
+            double dist = q * q;
+            double wi = 1.0 / pow(dist, 0.5 * power);
+            sumWi += wi;
+            value += wi * load_px(in, dt, xi * s1 + yi);
+          }
+      if (sumWi != 0) store_px(grid, dt, i * s1 + j, value / sumWi);
+    }
+  free(in);
+  return 0;
+}
+
+/* interpolate/interpolate2dStructuredCrossAvg.py:7-115, as written.  Every masked pixel looks
+ * down / up / left / right along its column and row for the nearest unmasked pixel and takes
+ * the local average (_localAvg :21-44: unmasked pixels within +-kernel) there; the values are
+ * blended with weights 1 / distance^(power/2), normalised.  Quirks kept:
+ *  - "look up" (:73-83) stores vals[1] / dist[1] but raises valid[2], so the upward value is
+ *    never used, and slot 2 (the leftward value) counts as valid whenever EITHER the upward or
+ *    the leftward search succeeded; when only the upward one did, slot 2 still holds what the
+ *    LAST earlier pixel (raster order) with a leftward hit left there.  Before any such pixel
+ *    the slot is np.empty garbage in the reference: dropped here.
+ *  - "look right" runs only if i < gy - 1 (the ROW index against the column count, :96).
+ *  - dist is uint16, weights float32 (normalised in float32), vals has the grid's dtype.
+ *  - _localAvg clamps its window to gx / gy, not gx-1 / gy-1, and reads that index: out of
+ *    bounds (UB under numba); clamped to the array here like orc_idw.
+ * Sequential (the stale slot makes the raster order part of the result). */
+static double cross_local_avg(const void* in, int dt, const uint8_t* mask, long i, long j, long gx,
+                              long gy, long kernel) {
+  long xmn = i - kernel < 0 ? 0 : i - kernel, xmx = i + kernel > gx - 1 ? gx - 1 : i + kernel;
+  long ymn = j - kernel < 0 ? 0 : j - kernel, ymx = j + kernel > gy - 1 ? gy - 1 : j + kernel;
+  double val = 0;
+  long n = 0;
+  for (long xi = xmn; xi <= xmx; xi++)
+    for (long yi = ymn; yi <= ymx; yi++)
+      if (!mask[xi * gy + yi]) {
+        val += load_px(in, dt, xi * gy + yi);
+        n++;
+      }
+  return val / (double)n;
+}
+
+int orc_cross_avg(void* grid, int dt, const uint8_t* mask, long gx, long gy, long kernel,
+                  double power) {
+  size_t es = dtype_size(dt);
+  void* in = malloc((size_t)gx * gy * es);
+  if (!in) return -1;
+  memcpy(in, grid, (size_t)gx * gy * es); /* only unmasked px are read: copy == in-place */
+  double vals[4] = {0, 0, 0, 0};
+  uint16_t dist[4] = {0, 0, 0, 0};
+  int slot2_set = 0;
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      if (!mask[i * gy + j]) continue;
+      int valid[4] = {0, 0, 0, 0};
+      for (long i0 = i - 1; i0 >= 0; i0--) /* look down (:60-71) */
+        if (!mask[i0 * gy + j]) {
+          vals[0] = cross_local_avg(in, dt, mask, i0, j, gx, gy, kernel);
+          dist[0] = (uint16_t)(i - i0);
+          valid[0] = 1;
+          break;
+        }
+      for (long i0 = i + 1; i0 < gx; i0++) /* look up (:72-83): sets valid[2] */
+        if (!mask[i0 * gy + j]) {
+          vals[1] = cross_local_avg(in, dt, mask, i0, j, gx, gy, kernel);
+          dist[1] = (uint16_t)(i0 - i);
+          valid[2] = 1;
+          break;
+        }
+      for (long j0 = j - 1; j0 >= 0; j0--) /* look left (:84-95) */
+        if (!mask[i * gy + j0]) {
+          vals[2] = cross_local_avg(in, dt, mask, i, j0, gx, gy, kernel);
+          dist[2] = (uint16_t)(j - j0);
+          valid[2] = 1;
+          slot2_set = 1;
+          break;
+        }
+      if (i < gy - 1) /* look right (:96-107) */
+        for (long j0 = j + 1; j0 < gy; j0++)
+          if (!mask[i * gy + j0]) {
+            vals[3] = cross_local_avg(in, dt, mask, i, j0, gx, gy, kernel);
+            dist[3] = (uint16_t)(j0 - j);
+            valid[3] = 1;
+            break;
+          }
+      if (valid[2] && !slot2_set) valid[2] = 0;
+      /* vals has the grid's dtype */
+      if (dt == ORC_F32)
+        for (int s = 0; s < 4; s++) vals[s] = (double)(float)vals[s];
+      float w[4], wsum = 0.f;
+      for (int s = 0; s < 4; s++)
+        if (valid[s]) {
+          w[s] = (float)(1.0 / pow((double)dist[s], 0.5 * power));
+          wsum += w[s];
+        }
+      if (dt == ORC_F32) {
+        float acc = 0.f;
+        for (int s = 0; s < 4; s++)
+          if (valid[s]) acc += (float)vals[s] * (w[s] / wsum);
+        store_px(grid, dt, i * gy + j, acc);
+      } else {
+        double acc = 0.0;
+        for (int s = 0; s < 4; s++)
+          if (valid[s]) acc += vals[s] * (double)(w[s] / wsum);
+        store_px(grid, dt, i * gy + j, acc);
+      }
+    }
+  free(in);
+  return 0;
+}
+
 /* headline chain for the CPU baseline: map-based undistort then K x K filter */
 int orc_remap_conv2d(const void* src, int src_dt, long h, long w, const float* mapx,
                      const float* mapy, const double* kern, long kh, long kw, void* tmp, void* dst,

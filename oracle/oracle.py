@@ -399,6 +399,37 @@ def interpolate2dStructuredFastIDW(grid, mask, kernel=15, power=2, minnvals=5):
 
 
 # -------------------------------------------------------- headline chain ----
+def interpolate2dUnstructuredIDW(x, y, v, grid, power=2):
+    """interpolate/interpolate2dUnstructuredIDW.py:7-38 (in place, returns grid)"""
+    assert grid.flags.c_contiguous
+    x, y, v = (np.ascontiguousarray(a, dtype=np.float64) for a in (x, y, v))
+    _chk(lib().orc_unstructured_idw(_p(grid), _dt(grid), C.c_long(grid.shape[0]),
+                                    C.c_long(grid.shape[1]), _p(x), _p(y), _p(v),
+                                    C.c_long(len(v)), C.c_double(power)), 'unstructured_idw')
+    return grid
+
+
+def interpolateCircular2dStructuredIDW(grid, mask, kernel=15, power=2, fr=1, fphi=1, cx=0, cy=0):
+    """interpolate/interpolateCircular2dStructuredIDW.py:7-69 (in place, returns grid)"""
+    assert grid.flags.c_contiguous
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    _chk(lib().orc_circular_idw(_p(grid), _dt(grid), _p(m), C.c_long(grid.shape[0]),
+                                C.c_long(grid.shape[1]), C.c_long(kernel), C.c_double(power),
+                                C.c_double(fr), C.c_double(fphi), C.c_double(cx),
+                                C.c_double(cy)), 'circular_idw')
+    return grid
+
+
+def interpolate2dStructuredCrossAvg(grid, mask, kernel=15, power=2):
+    """interpolate/interpolate2dStructuredCrossAvg.py:7-115 (in place, returns grid)"""
+    assert grid.flags.c_contiguous
+    m = np.ascontiguousarray(mask, dtype=np.uint8)
+    _chk(lib().orc_cross_avg(_p(grid), _dt(grid), _p(m), C.c_long(grid.shape[0]),
+                             C.c_long(grid.shape[1]), C.c_long(kernel), C.c_double(power)),
+         'cross_avg')
+    return grid
+
+
 def remap_conv2d(src, mapx, mapy, kernel, interp=LINEAR, border=CONSTANT, cval=0.0,
                  cmode='reflect', out_dtype=np.float32):
     """undistort (map-based) then K x K centred correlation: the benchmark chain"""

@@ -788,9 +788,76 @@ def gen_warp_skimage():
     np.savez_compressed(os.path.join(HERE, 'warp_skimage.npz'), **d)
 
 
+def gen_interp_more():
+    """interp_more.npz: the three interpolate/ functions SURVEY §2 lists next to the IDW pair,
+    run from the reference's own source through the numba identity shim"""
+    from imgProcessor.interpolate.interpolate2dStructuredCrossAvg import \
+        interpolate2dStructuredCrossAvg
+    from imgProcessor.interpolate.interpolate2dUnstructuredIDW import interpolate2dUnstructuredIDW
+    from imgProcessor.interpolate.interpolateCircular2dStructuredIDW import \
+        interpolateCircular2dStructuredIDW
+    out = {}
+    rng = np.random.default_rng(21)
+    # unstructured IDW: x is the ROW coordinate (grid[i, j], i against x) -------------------
+    gx, gy, n = 40, 56, 12
+    xi, yi = rng.integers(0, gx, n), rng.integers(0, gy, n)   # on pixels: exact hits exist
+    vi = rng.integers(0, 10, n)
+    xf, yf = rng.random(n) * gx, rng.random(n) * gy
+    vf = rng.standard_normal(n)
+    out.update(u_xi=xi, u_yi=yi, u_vi=vi, u_xf=xf, u_yf=yf, u_vf=vf, u_shape=np.array([gx, gy]))
+    for power in (1, 2, 3):
+        out['u_int_p%d' % power] = interpolate2dUnstructuredIDW(
+            xi, yi, vi, np.zeros((gx, gy)), power)
+        out['u_flt_p%d' % power] = interpolate2dUnstructuredIDW(
+            xf, yf, vf, np.zeros((gx, gy)), power)
+    out['u_int32_p2'] = interpolate2dUnstructuredIDW(xi, yi, vi, np.zeros((gx, gy), np.float32), 2)
+    # circular IDW: square grid and one with more columns than rows (columns >= shape[0] are
+    # left alone, gy = shape[0] in the source) ---------------------------------------------
+    for name, shape in (('sq', (48, 48)), ('wide', (40, 56))):
+        g = synth(shape, 8, np.float64)
+        m = rng.random(shape) < 0.2
+        m[10:18, 12:22] = True
+        out['c_grid_' + name] = g
+        out['c_mask_' + name] = m
+        cx, cy = shape[0] // 2 + 1, shape[1] // 2 + 1
+        out['c_centre_' + name] = np.array([cx, cy])
+        for kern, power, fr, fphi in ((5, 2, 1, 0.2), (15, 2, 1, 1), (7, 1, 2, 0.5)):
+            key = 'c_%s_k%d_p%d_fr%g_fphi%g' % (name, kern, power, fr, fphi)
+            out[key] = interpolateCircular2dStructuredIDW(g.copy(), m, kern, power, fr, fphi,
+                                                          cx, cy)
+    g = out['c_grid_sq'].astype(np.float32)
+    out['c32_sq_k5'] = interpolateCircular2dStructuredIDW(g.copy(), out['c_mask_sq'], 5, 2, 1, 0.2,
+                                                          25, 25)
+    # cross average: masks kept where the source is well defined - every unmasked pixel a
+    # search can find lies more than `kernel` px from the bottom / right edge (window clamped to
+    # gx, not gx-1), and the first masked pixel in raster order has an unmasked left neighbour
+    # (slot 2 is np.empty garbage before that).  Row prefixes masked later exercise the stale
+    # slot, rows >= gy - 1 of the tall grid the skipped look-right. ----------------------------
+    for name, shape, kern in (('sq', (64, 64), 5), ('tall', (64, 40), 4), ('wide', (40, 64), 6)):
+        g = synth(shape, 9, np.float64) + np.linspace(5, 10, shape[1])[None, :]
+        m = np.zeros(shape, bool)
+        lim0, lim1 = shape[0] - kern - 2, shape[1] - kern - 2
+        m[:lim0, :lim1] = rng.random((lim0, lim1)) < 0.25
+        m[12:26, 10:24] = True            # the "large empty area" of the docstring
+        m[0:3, :] = False
+        m[:, 0] = False
+        m[30, 0:5] = True                 # no unmasked pixel to the left: stale slot 2
+        m[31, 0:2] = True
+        out['x_grid_' + name] = g
+        out['x_mask_' + name] = m
+        for power in (2, 1):
+            out['x_%s_k%d_p%d' % (name, kern, power)] = interpolate2dStructuredCrossAvg(
+                g.copy(), m, kern, power)
+    np.savez_compressed(os.path.join(HERE, 'interp_more.npz'), **out)
+
+
 if __name__ == '__main__':
     install_shim()
+    if sys.argv[1:] == ['interp_more']:
+        gen_interp_more()
+        sys.exit(0)
     gen_stencils()
+    gen_interp_more()
     gen_remap_scipy()
     gen_cv_modes()
     gen_warp_skimage()

@@ -428,3 +428,60 @@ def test_cv_u16_arithmetic_independent_restatement(oracle):
     a = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR)
     b = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR | oracle.Q5)
     assert not np.array_equal(a, b)
+
+
+def interp_more_cases(g):
+    """(key, callable(api) -> result) for every fixture of interp_more.npz; `api` is the oracle
+    module here and the product's interpolate package in the GPU tests"""
+    shape = tuple(int(v) for v in g['u_shape'])
+    cases = []
+    for power in (1, 2, 3):
+        cases.append(('u_int_p%d' % power, lambda a, p=power: a.interpolate2dUnstructuredIDW(
+            g['u_xi'], g['u_yi'], g['u_vi'], np.zeros(shape), p)))
+        cases.append(('u_flt_p%d' % power, lambda a, p=power: a.interpolate2dUnstructuredIDW(
+            g['u_xf'], g['u_yf'], g['u_vf'], np.zeros(shape), p)))
+    cases.append(('u_int32_p2', lambda a: a.interpolate2dUnstructuredIDW(
+        g['u_xi'], g['u_yi'], g['u_vi'], np.zeros(shape, np.float32), 2)))
+    for name in ('sq', 'wide'):
+        cx, cy = (int(v) for v in g['c_centre_' + name])
+        for kern, power, fr, fphi in ((5, 2, 1, 0.2), (15, 2, 1, 1), (7, 1, 2, 0.5)):
+            key = 'c_%s_k%d_p%d_fr%g_fphi%g' % (name, kern, power, fr, fphi)
+            cases.append((key, lambda a, n=name, k=kern, p=power, r=fr, f=fphi, x=cx, y=cy:
+                          a.interpolateCircular2dStructuredIDW(g['c_grid_' + n].copy(),
+                                                               g['c_mask_' + n], k, p, r, f, x, y)))
+    cases.append(('c32_sq_k5', lambda a: a.interpolateCircular2dStructuredIDW(
+        g['c_grid_sq'].astype(np.float32), g['c_mask_sq'], 5, 2, 1, 0.2, 25, 25)))
+    for name, kern in (('sq', 5), ('tall', 4), ('wide', 6)):
+        for power in (2, 1):
+            cases.append(('x_%s_k%d_p%d' % (name, kern, power), lambda a, n=name, k=kern, p=power:
+                          a.interpolate2dStructuredCrossAvg(g['x_grid_' + n].copy(),
+                                                            g['x_mask_' + n], k, p)))
+    return cases
+
+
+def test_interp_more(oracle):
+    """interpolate2dUnstructuredIDW / interpolateCircular2dStructuredIDW /
+    interpolate2dStructuredCrossAvg against the reference's own output"""
+    g = load_golden('interp_more.npz')
+    cases = interp_more_cases(g)
+    assert len(cases) == 20
+    for key, run in cases:
+        want = g[key]
+        got = run(oracle)
+        assert got.dtype == want.dtype and got.shape == want.shape, key
+        tol = F32 if want.dtype == np.float32 else 1e-12
+        if key == 'c32_sq_k5':
+            # the interpreted source sums `python float * np.float32` in float32 (NEP 50 weak
+            # scalars); numba types the accumulators float64, which the oracle follows
+            tol = 2e-6
+        assert_close(got, want, tol, 1e-15 if tol < 1e-9 else 0, what=key)
+    # float32 grids: _localAvg accumulates in float64 under numba (int 0 + float32 unifies to
+    # float64) - the interpreted shim would accumulate in float32, so this case is compared
+    # with the float64 fixture at float32 resolution
+    got = oracle.interpolate2dStructuredCrossAvg(g['x_grid_sq'].astype(np.float32),
+                                                 g['x_mask_sq'], 5, 2)
+    assert got.dtype == np.float32
+    assert_close(got, g['x_sq_k5_p2'], 1e-6, 0, what='x32')
+    # a grid with fewer columns than rows indexes out of bounds in the circular source
+    with pytest.raises(RuntimeError):
+        oracle.interpolateCircular2dStructuredIDW(np.zeros((8, 6)), np.zeros((8, 6), bool))
