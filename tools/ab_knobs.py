@@ -62,12 +62,17 @@ def main():
         u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
                             if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
     Hm = None
-    if 'c3' in what or 'warp5' in what:
+    if {'c3', 'warp5', 'lz4', 'cubic'} & set(what):
         from imgprocessor_amd.utils import getPerspectiveTransform
         quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
         rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
         Hm = np.linalg.inv(getPerspectiveTransform(quad, rect))
     g9 = ops.gaussian_kernel1d(1.0)
+    k11 = np.random.default_rng(321).random((11, 11))
+    k11 /= k11.sum()
+    ang = np.deg2rad(7.0)   # C5's warp: rotation + mild perspective
+    R7 = np.array([[np.cos(ang), -np.sin(ang), 150.0], [np.sin(ang), np.cos(ang), -100.0],
+                   [4e-6, -2e-6, 1.0]])
     calls = {
         'c3': lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, 'linear', out=dst),
         'warp5': lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k5, 'linear', out=dst),
@@ -76,6 +81,12 @@ def main():
         'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
         'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
         'conv5': lambda: ops.conv2d(src, k5, out=dst),
+        'conv11': lambda: ops.conv2d(src, k11, out=dst),
+        'lz4': lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
+        'cubic': lambda: ops.warp_perspective(src, Hm, (h, w), 'cubic', out=dst),
+        'rot7cubic': lambda: ops.warp_perspective(src, R7, (h, w), 'cubic', out=dst),
+        'rot7lz4': lambda: ops.warp_perspective(src, R7, (h, w), 'lanczos4', out=dst),
+        'c5': lambda: ops.warp_perspective_conv2d(src, R7, (h, w), k11, 'cubic', out=dst),
         'remap': lambda: ops.remap(src, dmx, dmy, out=dst),
         'copy': lambda: dst.copy_from(src),
     }

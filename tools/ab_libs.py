@@ -64,6 +64,10 @@ def main():
     k5 = np.outer(g, g)
     g7 = np.exp(-0.5 * (np.arange(-3, 4) / 1.5) ** 2)
     k7 = np.outer(g7, g7) / g7.sum() ** 2
+    k9 = np.random.default_rng(99).random((9, 9))
+    k9 /= k9.sum()
+    k11 = np.random.default_rng(321).random((11, 11))
+    k11 /= k11.sum()
     rng = np.random.default_rng(0)
     one = rng.random((16, h, w), dtype=np.float32)
     host = np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch]
@@ -102,6 +106,10 @@ def main():
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
             'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
+            'conv9': lambda o=ops, m=mod: o.conv2d(m.src, k9, out=m.dst),
+            'conv11': lambda o=ops, m=mod: o.conv2d(m.src, k11, out=m.dst),
+            'fused9': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k9, out=m.dst),
+            'fused11': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k11, out=m.dst),
             'remap': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, out=m.dst),
             'copy': lambda m=mod: m.dst.copy_from(m.src),
         }
@@ -123,14 +131,14 @@ def main():
             print('%-8s %-24s %s   min %.4f' % (c, spec, '  '.join('%.4f' % x for x in v), min(v)))
     for spec, mod, ctx, knobs, calls in builds:
         old = ctx.set_tuning(**knobs) if knobs else {}
-        calls['fused5']()
+        calls[what[0]]()
         got = mod.dst.frame(batch - 1).get()
         if old:
             ctx.set_tuning(**old)
         if ref is None:
             ref = got
         same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
-        print('%-24s fused5 result %s' % (spec, 'identical bits' if same else
+        print('%-24s %s result %s' % (spec, what[0], 'identical bits' if same else
                                           'DIFFERS from %s (max |d| %.3g)' % (names[0], np.abs(got - ref).max())))
 
 
