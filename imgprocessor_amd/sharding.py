@@ -13,6 +13,7 @@ Two ways to use it:
   * one process, several GPUs: ``ShardedRunner`` drives one context per device
     from one host thread each (ctypes releases the GIL during library calls).
 """
+import os
 import threading
 
 from .device import Context, device_count
@@ -82,10 +83,14 @@ class FramePipeline(object):
     the driver's staging copies.
     """
 
-    def __init__(self, device=0, depth=3):
+    def __init__(self, device=0, depth=3, cpus=None):
+        """cpus: optional set of host CPUs the worker threads pin themselves to (e.g. the
+        CPUs of the GPU's NUMA node, `numa_cpus_of_device`): the page-locked staging
+        buffers are then touched and the copies driven from the socket the GPU hangs on"""
         if depth < 1:
             raise ValueError('depth must be >= 1')
         self.contexts = [Context(device) for _ in range(depth)]
+        self.cpus = set(int(c) for c in cpus) if cpus else None
 
     def pinned_empty(self, shape, dtype):
         return self.contexts[0].pinned_empty(shape, dtype)
@@ -102,6 +107,8 @@ class FramePipeline(object):
             ctx = self.contexts[t]
             d_in = d_out = None
             try:
+                if self.cpus:
+                    os.sched_setaffinity(0, self.cpus)   # the calling thread only (Linux)
                 for i in range(t, n, len(self.contexts)):
                     f, o = frames[i], out[i]
                     if d_in is None or d_in.shape != f.shape or d_in.dtype != f.dtype:
@@ -122,6 +129,25 @@ class FramePipeline(object):
             if e is not None:
                 raise e
         return out
+
+
+def numa_cpus_of_device(device=0):
+    """host CPUs of the NUMA node GPU `device` is attached to, from sysfs (the render nodes'
+    PCI devices in bus order); None when the platform does not say"""
+    try:
+        base = '/sys/class/drm'
+        cards = sorted(d for d in os.listdir(base) if d.startswith('renderD'))
+        node = int(open(os.path.join(base, cards[device], 'device', 'numa_node')).read())
+        if node < 0:
+            return None
+        spec = open('/sys/devices/system/node/node%d/cpulist' % node).read().strip()
+        cpus = set()
+        for part in spec.split(','):
+            a, _, b = part.partition('-')
+            cpus.update(range(int(a), int(b or a) + 1))
+        return cpus
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 # ----------------------------------------------------------------- one huge frame --
