@@ -94,6 +94,10 @@ PROTOTYPES = {
     'ipa_circular_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d, _d, _d, _d, _d],
     'ipa_cross_avg_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _d],
     'ipa_cross_avg_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d],
+    'ipa_resize_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _l, _i],
+    'ipa_resize': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i],
+    'ipa_fast_filter_stat_dev': [_vp, _vp, _i, _i, _i, _l, _i, _i, _i, _vp],
+    'ipa_fast_filter_stat': [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
 }
 _CHARP = {'ipa_status_string': [_i], 'ipa_last_error': [_vp]}
 

@@ -7,3 +7,5 @@ from .standardDeviation import standardDeviation2d  # noqa: F401
 from .maskedFilter import maskedFilter  # noqa: F401
 from .nan_maximum_filter import nan_maximum_filter  # noqa: F401
 from .medianThreshold import medianThreshold  # noqa: F401
+from .fastFilter import fastFilter  # noqa: F401
+from .fastMean import fastMean  # noqa: F401

@@ -1,0 +1,25 @@
+"""``fastMean`` — reference: imgProcessor/filters/fastMean.py:5-19.
+
+"For bigger ksizes it is often faster to resize an image rather than blur it": the image is
+shrunk to ``round(shape / f)`` with ``cv2.resize(..., INTER_AREA)`` and enlarged back with
+``INTER_LINEAR``.  Both resizes are OpenCV's published algorithm on the GPU (`ops.resize`,
+cv2-unpinned) for float32 / float64 images; integer images take the reference's
+``toFloatArray`` rule (uint8 / uint16 -> float32) first - cv2's 8-bit fixed-point resize differs
+between OpenCV versions and is not restated.  ``inplace=True`` writes the result into ``img``.
+"""
+import numpy as np
+
+from .. import ops
+
+
+def fastMean(img, f=10, inplace=False, ctx=None):
+    src = np.asarray(img)
+    s0, s1 = src.shape[:2]
+    ss0 = int(round(s0 / f))
+    ss1 = int(round(s1 / f))
+    small = ops.resize(src, (ss0, ss1), 'area', ctx=ctx)
+    big = ops.resize(small, (s0, s1), 'linear', ctx=ctx)
+    if inplace:
+        img[...] = big
+        return img
+    return big

@@ -782,3 +782,57 @@ def cross_avg_fill(grid, mask, ksize, power=2, ctx=None):
     ctx._check(ctx._lib.ipa_cross_avg_fill(ctx.handle, _p(grid), dtype_id(grid.dtype), _p(m), h, w,
                                            int(ksize), float(power)), 'cross_avg_fill')
     return grid
+
+
+# ------------------------------------------------------- fastFilter / fastMean --
+RESIZE_INTERP = {'linear': 1, 'cubic': 2, 'area': 3, 'lanczos4': 4, 1: 1, 2: 2, 3: 3, 4: 4}
+FAST_FILTER_FN = {'median': 0, 'nanmedian': 1, 'mean': 2, 'nanmean': 3}
+
+
+def resize(img, dsize_hw, interpolation='linear', out=None, ctx=None):
+    """cv2.resize(img, (w, h), interpolation=...) for 2-D float32 / float64 images;
+    dsize_hw = (rows, columns) of the result"""
+    interp = RESIZE_INTERP[interpolation]
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    if _is_dev(img):
+        ctx = _ctx_of(img, ctx=ctx)
+        if img.ndim != 2:
+            raise ValueError('resize takes one 2-D image')
+        sh, sw = img.shape
+        dst = _dev_out(ctx, out, (dh, dw), img.dtype)
+        ctx._check(ctx._lib.ipa_resize_dev(ctx.handle, img.ptr, dtype_id(img.dtype), sh, sw, sw,
+                                           dst.ptr, dh, dw, dw, interp), 'resize')
+        return dst
+    ctx = ctx or default_context()
+    img = _float_img(img)
+    if img.ndim != 2:
+        raise ValueError('resize takes one 2-D image')
+    sh, sw = img.shape
+    dst = np.empty((dh, dw), img.dtype)
+    ctx._check(ctx._lib.ipa_resize(ctx.handle, _p(img), dtype_id(img.dtype), sh, sw, _p(dst), dh,
+                                   dw, interp), 'resize')
+    return dst
+
+
+def fast_filter_stat(arr, ksize, every, fn='median', ctx=None):
+    """the strided window statistics of fastFilter (filters/fastFilter.py:52-122): float64 array of
+    ceil(h / every) x ceil(w / every) cells"""
+    f = FAST_FILTER_FN[fn]
+    every, ksize = int(every), int(ksize)
+    if _is_dev(arr):
+        ctx = _ctx_of(arr, ctx=ctx)
+        h, w = arr.shape
+        out = ctx.empty((-(-h // every), -(-w // every)), np.float64)
+        ctx._check(ctx._lib.ipa_fast_filter_stat_dev(ctx.handle, arr.ptr, dtype_id(arr.dtype), h, w,
+                                                     w, ksize, every, f, out.ptr),
+                   'fast_filter_stat')
+        return out
+    ctx = ctx or default_context()
+    arr = _float_img(arr)
+    if arr.ndim != 2:
+        raise ValueError('fast_filter_stat takes one 2-D array')
+    h, w = arr.shape
+    out = np.empty((-(-h // every), -(-w // every)), np.float64)
+    ctx._check(ctx._lib.ipa_fast_filter_stat(ctx.handle, _p(arr), dtype_id(arr.dtype), h, w, ksize,
+                                             every, f, _p(out)), 'fast_filter_stat')
+    return out

@@ -389,6 +389,30 @@ int ipa_cross_avg_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t*
 int ipa_cross_avg_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
                        int ksize, double power);
 
+/* ---------------------------------------------------------------- filters: fast* */
+/* replaces cv2.resize(img, (dw, dh), interpolation=...) at filters/fastFilter.py:47-48
+ * (INTER_LANCZOS4 on the float64 grid of statistics) and filters/fastMean.py:14-19 (INTER_AREA
+ * down, INTER_LINEAR up), single-channel IPA_F32 / IPA_F64.  OpenCV's published algorithm
+ * (coordinates (d + 0.5) scale - 0.5 in float32, float32 coefficients, horizontal pass first in
+ * the image's type; INTER_AREA by block sums / decimation tables, downscaling only). */
+typedef enum {
+  IPA_RESIZE_LINEAR = 1, IPA_RESIZE_CUBIC = 2, IPA_RESIZE_AREA = 3, IPA_RESIZE_LANCZOS4 = 4
+} ipa_resize_interp;   /* cv2's INTER_* numbers */
+int ipa_resize_dev(ipa_ctx* ctx, const void* d_src, int dtype, int sh, int sw, long src_pitch,
+                   void* d_dst, int dh, int dw, long dst_pitch, int interp);
+int ipa_resize(ipa_ctx* ctx, const void* src, int dtype, int sh, int sw, void* dst, int dh, int dw,
+               int interp);
+
+/* replaces filters/fastFilter.py:52-122 (_iter + _calcMedian / _calcNanMedian / _calcMean /
+ * _calcNanMean): out[ii, jj] = statistic of arr[max(i-k,0) : min(i+k,h) : every,
+ * max(j-k,0) : min(j+k,w) : every] at i = ii every, j = jj every; out is ceil(h / every) x
+ * ceil(w / every) doubles (the caller applies the reference's crop of the last row and column).
+ * fn: 0 median (NaN when the window holds one), 1 nanmedian, 2 mean, 3 nanmean. */
+int ipa_fast_filter_stat_dev(ipa_ctx* ctx, const void* d_arr, int dtype, int h, int w, long pitch,
+                             int ksize, int every, int fn, double* d_out);
+int ipa_fast_filter_stat(ipa_ctx* ctx, const void* arr, int dtype, int h, int w, int ksize,
+                         int every, int fn, double* out);
+
 #ifdef __cplusplus
 }
 #endif

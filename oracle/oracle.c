@@ -1305,6 +1305,254 @@ int orc_cross_avg(void* grid, int dt, const uint8_t* mask, long gx, long gy, lon
   return 0;
 }
 
+/* ------------------------------------------------------------------ */
+/* filters/fastFilter.py, filters/fastMean.py                          */
+/* ------------------------------------------------------------------ */
+
+/* filters/fastFilter.py:52-122 (_iter + _calcMedian / _calcNanMedian / _calcMean / _calcNanMean):
+ * for i in range(0, gx, every), j in range(0, gy, every) the statistic of
+ * arr[max(i-k,0) : min(i+k,gx) : every, max(j-k,0) : min(j+k,gy) : every] goes to out[ii, jj].
+ * fn: 0 median (NaN if the window holds a NaN, like np.median), 1 nanmedian, 2 mean,
+ * 3 nanmean (NaN for an all-NaN window).  out: n0 x n1 doubles, n0 = ceil(gx / every),
+ * n1 = ceil(gy / every); the wrapper applies the reference's crop to [:n0-1, :n1-1] (:36-37:
+ * the loops return their LAST indices, which are then used as sizes). */
+int orc_fast_filter_stat(const void* arr, int dt, long gx, long gy, long ksize, long every, int fn,
+                         double* out) {
+  if (every < 1 || ksize < 1) return -1;
+  long n0 = (gx + every - 1) / every, n1 = (gy + every - 1) / every;
+  long cap = (2 * ksize / every + 2) * (2 * ksize / every + 2);
+#pragma omp parallel num_threads(g_threads)
+  {
+    double* buf = (double*)malloc((size_t)cap * sizeof(double));
+#pragma omp for schedule(dynamic, 4)
+    for (long ii = 0; ii < n0; ii++)
+      for (long jj = 0; jj < n1; jj++) {
+        long i = ii * every, j = jj * every;
+        long xmn = i - ksize < 0 ? 0 : i - ksize, xmx = i + ksize > gx ? gx : i + ksize;
+        long ymn = j - ksize < 0 ? 0 : j - ksize, ymx = j + ksize > gy ? gy : j + ksize;
+        long n = 0, nn = 0;
+        double sum = 0;
+        for (long x = xmn; x < xmx; x += every)
+          for (long y = ymn; y < ymx; y += every) {
+            double v = load_px(arr, dt, x * gy + y);
+            if (v != v) {
+              nn++;
+              continue;
+            }
+            buf[n++] = v;
+            sum += v;
+          }
+        double r;
+        if ((fn == 0 || fn == 2) && nn) r = NAN;
+        else if (n == 0) r = NAN;
+        else if (fn >= 2) r = sum / (double)n;
+        else {
+          qsort(buf, (size_t)n, sizeof(double), cmp_double);
+          r = (n & 1) ? buf[n / 2] : (buf[n / 2 - 1] + buf[n / 2]) / 2.0;
+        }
+        out[ii * n1 + jj] = r;
+      }
+    free(buf);
+  }
+  return 0;
+}
+
+/* cv::resize for single-channel float32 / float64 images (OpenCV imgproc/src/resize.cpp, restated
+ * from the published algorithm - cv2 is not available here: UNPINNED like the other cv2 modes).
+ * interp: 1 INTER_LINEAR, 2 INTER_CUBIC (a = -0.75), 3 INTER_AREA, 4 INTER_LANCZOS4.
+ *  - scale = 1 / ((double)dsize / ssize); source position of destination index d:
+ *    f = (float)((d + 0.5) * scale - 0.5), s = floor(f), f -= s  (float)
+ *  - linear: along x a position left of the first / right of the last pixel is clamped to it with
+ *    fraction 0; along y the two ROWS are clipped instead;  cubic / Lanczos4: tap indices clipped
+ *  - coefficients are float32 (interpolateCubic / interpolateLanczos4); the work type is float32 for
+ *    float32 images and float64 for float64 ones; horizontal pass first (its rows rounded to the
+ *    work type), products summed left to right
+ *  - area, integer scale: the block's pixels summed in groups of four ((a+b+c+d) added to the
+ *    running sum - CV_ENABLE_UNROLLED), times (float)(1/area); otherwise the decimation tables of
+ *    computeResizeAreaTab with float32 weights, row sums first.  Upscaling with INTER_AREA (OpenCV
+ *    switches to a bilinear variant there) is not covered: -2. */
+static void cv_cubic_coeffs(float x, float* c) {
+  const float A = -0.75f;
+  c[0] = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A;
+  c[1] = ((A + 2) * x - (A + 3)) * x * x + 1;
+  c[2] = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1;
+  c[3] = 1.f - c[0] - c[1] - c[2];
+}
+
+typedef struct { int si, di; float alpha; } area_tab_t;
+
+static int area_tab(int ssize, int dsize, double scale, area_tab_t* tab) {
+  int k = 0;
+  for (int dx = 0; dx < dsize; dx++) {
+    double fsx1 = dx * scale, fsx2 = fsx1 + scale;
+    double cell = scale < ssize - fsx1 ? scale : ssize - fsx1;
+    int sx1 = (int)ceil(fsx1), sx2 = (int)floor(fsx2);
+    sx2 = sx2 < ssize - 1 ? sx2 : ssize - 1;
+    sx1 = sx1 < sx2 ? sx1 : sx2;
+    if (sx1 - fsx1 > 1e-3) {
+      tab[k].di = dx; tab[k].si = sx1 - 1; tab[k++].alpha = (float)((sx1 - fsx1) / cell);
+    }
+    for (int sx = sx1; sx < sx2; sx++) {
+      tab[k].di = dx; tab[k].si = sx; tab[k++].alpha = (float)(1.0 / cell);
+    }
+    if (fsx2 - sx2 > 1e-3) {
+      double a = fsx2 - sx2 < 1.0 ? fsx2 - sx2 : 1.0;
+      a = a < cell ? a : cell;
+      tab[k].di = dx; tab[k].si = sx2; tab[k++].alpha = (float)(a / cell);
+    }
+  }
+  return k;
+}
+
+#define ORC_RESIZE_BODY(T, WT)                                                                      \
+  const T* S = (const T*)src;                                                                       \
+  T* D = (T*)dst;                                                                                   \
+  if (interp == 3) {                                                                                \
+    if (area_fast) {                                                                                \
+      const float fscale = 1.f / (float)(isx * isy);                                               \
+      const long w1 = sw / isx;                                                                     \
+      for (long dy = 0; dy < dh; dy++) {                                                            \
+        long sy0 = dy * isy, w = sy0 + isy <= sh ? w1 : 0;                                          \
+        if (w > dw) w = dw;                                                                         \
+        for (long dx = 0; dx < dw; dx++) {                                                          \
+          long sx0 = dx * isx;                                                                      \
+          if (sy0 >= sh) { D[dy * dw + dx] = 0; continue; }                                         \
+          if (dx < w) {                                                                             \
+            WT sum = 0;                                                                             \
+            long k = 0, area = (long)isx * isy;                                                     \
+            for (; k <= area - 4; k += 4) {                                                         \
+              WT a = S[(sy0 + k / isx) * sw + sx0 + k % isx];                                       \
+              WT b = S[(sy0 + (k + 1) / isx) * sw + sx0 + (k + 1) % isx];                           \
+              WT c = S[(sy0 + (k + 2) / isx) * sw + sx0 + (k + 2) % isx];                           \
+              WT d = S[(sy0 + (k + 3) / isx) * sw + sx0 + (k + 3) % isx];                           \
+              sum += a + b + c + d;                                                                 \
+            }                                                                                       \
+            for (; k < area; k++) sum += S[(sy0 + k / isx) * sw + sx0 + k % isx];                   \
+            D[dy * dw + dx] = (T)(sum * fscale);                                                    \
+          } else {                                                                                  \
+            WT sum = 0;                                                                             \
+            long count = 0;                                                                         \
+            if (sx0 >= sw) { D[dy * dw + dx] = 0; continue; }                                       \
+            for (long sy = 0; sy < isy && sy0 + sy < sh; sy++)                                      \
+              for (long sx = 0; sx < isx && sx0 + sx < sw; sx++) {                                  \
+                sum += S[(sy0 + sy) * sw + sx0 + sx];                                               \
+                count++;                                                                            \
+              }                                                                                     \
+            D[dy * dw + dx] = (T)((float)sum / count);                                              \
+          }                                                                                         \
+        }                                                                                           \
+      }                                                                                             \
+    } else {                                                                                        \
+      area_tab_t* xt = (area_tab_t*)malloc(sizeof(area_tab_t) * (size_t)(sw * 2 + 2 * dw + 4));    \
+      area_tab_t* yt = (area_tab_t*)malloc(sizeof(area_tab_t) * (size_t)(sh * 2 + 2 * dh + 4));    \
+      int nx = area_tab((int)sw, (int)dw, scale_x, xt), ny = area_tab((int)sh, (int)dh, scale_y, yt); \
+      WT* buf = (WT*)malloc(sizeof(WT) * (size_t)dw);                                               \
+      WT* sum = (WT*)calloc((size_t)dw, sizeof(WT));                                                \
+      int prev_dy = yt[0].di;                                                                       \
+      for (int j = 0; j < ny; j++) {                                                                \
+        WT beta = yt[j].alpha;                                                                      \
+        int dy = yt[j].di, sy = yt[j].si;                                                           \
+        for (long dx = 0; dx < dw; dx++) buf[dx] = 0;                                               \
+        for (int k = 0; k < nx; k++) buf[xt[k].di] += S[(long)sy * sw + xt[k].si] * (WT)xt[k].alpha; \
+        if (dy != prev_dy) {                                                                        \
+          for (long dx = 0; dx < dw; dx++) {                                                        \
+            D[(long)prev_dy * dw + dx] = (T)sum[dx];                                                \
+            sum[dx] = beta * buf[dx];                                                               \
+          }                                                                                         \
+          prev_dy = dy;                                                                             \
+        } else {                                                                                    \
+          for (long dx = 0; dx < dw; dx++) sum[dx] += beta * buf[dx];                               \
+        }                                                                                           \
+      }                                                                                             \
+      for (long dx = 0; dx < dw; dx++) D[(long)prev_dy * dw + dx] = (T)sum[dx];                     \
+      free(xt); free(yt); free(buf); free(sum);                                                     \
+    }                                                                                               \
+  } else {                                                                                          \
+    WT* tmp = (WT*)malloc(sizeof(WT) * (size_t)sh * dw);                                            \
+    for (long y = 0; y < sh; y++)                                                                   \
+      for (long dx = 0; dx < dw; dx++) {                                                            \
+        const float* a = alpha + dx * ks;                                                           \
+        long sx = xofs[dx];                                                                         \
+        WT v;                                                                                       \
+        if (ks == 2) {                                                                              \
+          if (dx >= xmax) v = (WT)S[y * sw + sx] * (WT)1;                                           \
+          else v = S[y * sw + sx] * (WT)a[0] + S[y * sw + sx + 1] * (WT)a[1];                       \
+        } else {                                                                                    \
+          v = 0;                                                                                    \
+          for (int j = 0; j < ks; j++) {                                                            \
+            long sxj = sx - (ks / 2 - 1) + j;                                                       \
+            sxj = sxj < 0 ? 0 : (sxj >= sw ? sw - 1 : sxj);                                         \
+            v += S[y * sw + sxj] * (WT)a[j];                                                        \
+          }                                                                                         \
+        }                                                                                           \
+        tmp[y * dw + dx] = v;                                                                       \
+      }                                                                                             \
+    for (long dy = 0; dy < dh; dy++)                                                                \
+      for (long dx = 0; dx < dw; dx++) {                                                            \
+        const float* b = beta + dy * ks;                                                            \
+        WT v = 0;                                                                                   \
+        for (int k = 0; k < ks; k++) {                                                              \
+          long sy = yofs[dy] - (ks / 2) + 1 + k;                                                    \
+          sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;                                               \
+          WT t = tmp[sy * dw + dx] * (WT)b[k];                                                      \
+          v = k == 0 ? t : v + t;                                                                   \
+        }                                                                                           \
+        D[dy * dw + dx] = (T)v;                                                                     \
+      }                                                                                             \
+    free(tmp);                                                                                      \
+  }
+
+int orc_resize(const void* src, int dt, long sh, long sw, void* dst, long dh, long dw, int interp) {
+  if (dt != ORC_F32 && dt != ORC_F64) return -1;
+  if (sh < 1 || sw < 1 || dh < 1 || dw < 1) return -1;
+  const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
+  int ks = interp == 1 ? 2 : (interp == 2 ? 4 : 8);
+  int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
+  int area_fast = 0;
+  long* xofs = NULL; long* yofs = NULL;
+  float* alpha = NULL; float* beta = NULL;
+  long xmax = dw;
+  if (interp == 3) {
+    if (!(scale_x >= 1 && scale_y >= 1)) return -2;
+    area_fast = fabs(scale_x - isx) < DBL_EPSILON && fabs(scale_y - isy) < DBL_EPSILON;
+  } else if (interp == 1 || interp == 2 || interp == 4) {
+    xofs = (long*)malloc(sizeof(long) * (size_t)dw);
+    yofs = (long*)malloc(sizeof(long) * (size_t)dh);
+    alpha = (float*)malloc(sizeof(float) * (size_t)dw * ks);
+    beta = (float*)malloc(sizeof(float) * (size_t)dh * ks);
+    for (long dx = 0; dx < dw; dx++) {
+      float fx = (float)((dx + 0.5) * scale_x - 0.5);
+      long sx = (long)floorf(fx);
+      fx -= sx;
+      if (sx < ks / 2 - 1 && sx < 0 && interp == 1) { fx = 0; sx = 0; }
+      if (sx + ks / 2 >= sw) {
+        xmax = xmax < dx ? xmax : dx;
+        if (sx >= sw - 1 && interp == 1) { fx = 0; sx = sw - 1; }
+      }
+      xofs[dx] = sx;
+      float* c = alpha + dx * ks;
+      if (interp == 2) cv_cubic_coeffs(fx, c);
+      else if (interp == 4) orc_lanczos4_weights(fx, c);
+      else { c[0] = 1.f - fx; c[1] = fx; }
+    }
+    for (long dy = 0; dy < dh; dy++) {
+      float fy = (float)((dy + 0.5) * scale_y - 0.5);
+      long sy = (long)floorf(fy);
+      fy -= sy;
+      yofs[dy] = sy;
+      float* c = beta + dy * ks;
+      if (interp == 2) cv_cubic_coeffs(fy, c);
+      else if (interp == 4) orc_lanczos4_weights(fy, c);
+      else { c[0] = 1.f - fy; c[1] = fy; }
+    }
+  } else {
+    return -1;
+  }
+  if (dt == ORC_F32) { ORC_RESIZE_BODY(float, float) } else { ORC_RESIZE_BODY(double, double) }
+  free(xofs); free(yofs); free(alpha); free(beta);
+  return 0;
+}
+
 /* headline chain for the CPU baseline: map-based undistort then K x K filter */
 int orc_remap_conv2d(const void* src, int src_dt, long h, long w, const float* mapx,
                      const float* mapy, const double* kern, long kh, long kw, void* tmp, void* dst,

@@ -430,6 +430,52 @@ def interpolate2dStructuredCrossAvg(grid, mask, kernel=15, power=2):
     return grid
 
 
+RESIZE_LINEAR, RESIZE_CUBIC, RESIZE_AREA, RESIZE_LANCZOS4 = 1, 2, 3, 4
+_FF_FN = {'median': 0, 'nanmedian': 1, 'mean': 2, 'nanmean': 3}
+
+
+def resize(img, dsize_hw, interpolation=RESIZE_LINEAR):
+    """cv2.resize(img, (w, h), interpolation=...) for 2-D float32 / float64 images - restated
+    from OpenCV's published algorithm, cv2-unpinned (oracle.c: orc_resize)"""
+    img = np.ascontiguousarray(img)
+    dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
+    out = np.empty((dh, dw), img.dtype)
+    _chk(lib().orc_resize(_p(img), _dt(img), C.c_long(img.shape[0]), C.c_long(img.shape[1]),
+                          _p(out), C.c_long(dh), C.c_long(dw), C.c_int(interpolation)), 'resize')
+    return out
+
+
+def fastFilter(arr, ksize=30, every=None, resize_=True, fn='median',
+               interpolation=RESIZE_LANCZOS4, smoothksize=0):
+    """filters/fastFilter.py:9-48 (borderMode is accepted and unused there)"""
+    if every is None:
+        every = max(ksize // 3, 1)
+    else:
+        assert ksize >= 3 * every
+    arr = np.ascontiguousarray(arr)
+    s0, s1 = arr.shape[:2]
+    ss0 = s0 // every
+    every = s0 // ss0
+    n0, n1 = -(-s0 // every), -(-s1 // every)
+    out = np.empty((n0, n1))
+    _chk(lib().orc_fast_filter_stat(_p(arr), _dt(arr), C.c_long(s0), C.c_long(s1),
+                                    C.c_long(ksize), C.c_long(every), C.c_int(_FF_FN[fn]),
+                                    _p(out)), 'fast_filter_stat')
+    out = np.ascontiguousarray(out[:n0 - 1, :n1 - 1])   # the loops' LAST indices used as sizes
+    if smoothksize:
+        out = gaussian_filter(out, smoothksize)
+    if not resize_:
+        return out
+    return resize(out, (s0, s1), interpolation)
+
+
+def fastMean(img, f=10):
+    """filters/fastMean.py:5-19: INTER_AREA down to round(shape / f), INTER_LINEAR back up"""
+    s0, s1 = img.shape[:2]
+    small = resize(img, (int(round(s0 / f)), int(round(s1 / f))), RESIZE_AREA)
+    return resize(small, (s0, s1), RESIZE_LINEAR)
+
+
 def remap_conv2d(src, mapx, mapy, kernel, interp=LINEAR, border=CONSTANT, cval=0.0,
                  cmode='reflect', out_dtype=np.float32):
     """undistort (map-based) then K x K centred correlation: the benchmark chain"""

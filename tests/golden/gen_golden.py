@@ -788,6 +788,39 @@ def gen_warp_skimage():
     np.savez_compressed(os.path.join(HERE, 'warp_skimage.npz'), **d)
 
 
+def gen_fast_filter():
+    """fast_filter.npz: the strided window statistics of filters/fastFilter.py run from the
+    reference's own source (resize=False: the cv2.resize that follows cannot run here).  The
+    module imports cv2 for the DEFAULT VALUES of two keyword arguments; a throw-away stand-in
+    that only holds those constants lets the import succeed - no cv2 function is called."""
+    d = tempfile.mkdtemp(prefix='cv2_consts_')
+    with open(os.path.join(d, 'cv2.py'), 'w') as f:
+        f.write("INTER_LANCZOS4 = 4\nBORDER_REFLECT = 2\n"
+                "def resize(*a, **k):\n    raise RuntimeError('no cv2 here')\n")
+    sys.path.insert(0, d)
+    try:
+        from imgProcessor.filters.fastFilter import fastFilter
+    finally:
+        sys.path.remove(d)
+        sys.modules.pop('cv2', None)
+    out = {}
+    img = synth((120, 171), 4, np.float64) * 100
+    nan = img.copy()
+    nan[30:34] = np.nan          # the reference's demo adds NaN stripes (:129-130)
+    nan[:, 110:113] = np.nan
+    nan[0:40, 0:45] = np.nan     # and a window that is all NaN
+    out['img'] = img
+    out['img_nan'] = nan
+    for ksize, every in ((30, None), (12, 4), (40, 2), (9, 3), (5, 1)):
+        for fn in ('median', 'nanmedian', 'mean', 'nanmean'):
+            src = nan if fn.startswith('nan') or (ksize, every) == (12, 4) else img
+            key = 'ff_%s_k%d_e%s_%s' % ('nan' if src is nan else 'img', ksize, every, fn)
+            out[key] = fastFilter(src, ksize, every, resize=False, fn=fn)
+    out['ff_img_k12_e4_median_smooth2'] = fastFilter(img, 12, 4, resize=False, fn='median',
+                                                     smoothksize=2)
+    np.savez_compressed(os.path.join(HERE, 'fast_filter.npz'), **out)
+
+
 def gen_interp_more():
     """interp_more.npz: the three interpolate/ functions SURVEY §2 lists next to the IDW pair,
     run from the reference's own source through the numba identity shim"""
@@ -856,8 +889,12 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['interp_more']:
         gen_interp_more()
         sys.exit(0)
+    if sys.argv[1:] == ['fast_filter']:
+        gen_fast_filter()
+        sys.exit(0)
     gen_stencils()
     gen_interp_more()
+    gen_fast_filter()
     gen_remap_scipy()
     gen_cv_modes()
     gen_warp_skimage()

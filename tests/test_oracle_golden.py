@@ -485,3 +485,71 @@ def test_interp_more(oracle):
     # a grid with fewer columns than rows indexes out of bounds in the circular source
     with pytest.raises(RuntimeError):
         oracle.interpolateCircular2dStructuredIDW(np.zeros((8, 6)), np.zeros((8, 6), bool))
+
+
+def fast_filter_cases(g):
+    """(key, image, ksize, every, fn, smooth) of fast_filter.npz"""
+    cases = []
+    for key in g:
+        if not key.startswith('ff_'):
+            continue
+        p = key.split('_')
+        every = None if p[3] == 'eNone' else int(p[3][1:])
+        cases.append((key, g['img_nan' if p[1] == 'nan' else 'img'], int(p[2][1:]), every, p[4],
+                      2 if key.endswith('smooth2') else 0))
+    return cases
+
+
+def test_fast_filter_statistics(oracle):
+    """filters/fastFilter.py with resize=False against the reference's own output"""
+    g = load_golden('fast_filter.npz')
+    cases = fast_filter_cases(g)
+    assert len(cases) == 21
+    for key, img, ksize, every, fn, smooth in cases:
+        got = oracle.fastFilter(img, ksize, every, resize_=False, fn=fn, smoothksize=smooth)
+        assert_close(got, g[key], 1e-12, 0, key)
+
+
+def test_cv_resize_restatement_properties(oracle):
+    """cv2.resize cannot run here (cv2-unpinned): what the restatement must satisfy whatever the
+    OpenCV version - identities of the published algorithm, checked against plain numpy"""
+    rng = np.random.default_rng(3)
+    for dt in (np.float32, np.float64):
+        a = rng.random((37, 53)).astype(dt)
+        L, Cb, A, Z = (oracle.RESIZE_LINEAR, oracle.RESIZE_CUBIC, oracle.RESIZE_AREA,
+                       oracle.RESIZE_LANCZOS4)
+        # same size: every position has fraction 0 -> the image itself, for every kernel
+        for interp in (L, Cb, Z, A):
+            assert np.array_equal(oracle.resize(a, a.shape, interp), a), interp
+        # integer-factor area = block mean; sums grouped by four, scaled by float32(1 / area)
+        b = rng.random((36, 52)).astype(dt)
+        want = b.reshape(18, 2, 26, 2).transpose(0, 2, 1, 3).reshape(18, 26, 4).astype(dt)
+        want = ((want[..., 0] + want[..., 1] + want[..., 2] + want[..., 3]) *
+                dt(np.float32(0.25))).astype(dt)
+        assert np.array_equal(oracle.resize(b, (18, 26), A), want)
+        # (the scale is float32(1 / 12) also for float64 images)
+        assert_close(oracle.resize(b, (12, 13), A), b.reshape(12, 3, 13, 4).mean(axis=(1, 3)), 1e-6)
+        # fractional area: weights of a destination cell sum to 1 -> constants stay constant,
+        # the mean is kept up to rounding
+        c = oracle.resize(a, (10, 17), A)
+        assert abs(c.mean() - a.mean()) < 2e-3
+        assert_close(oracle.resize(np.full((37, 53), 3.5, dt), (10, 17), A), np.full((10, 17), 3.5),
+                     1e-6)
+        # bilinear upscaling by 2 of a ramp: interior values are the ramp at (d + 0.5) / 2 - 0.5
+        ramp = np.tile(np.arange(20, dtype=dt), (6, 1))
+        up = oracle.resize(ramp, (12, 40), L)
+        x = (np.arange(40) + 0.5) / 2 - 0.5
+        assert_close(up[3, 1:-1], x[1:-1], 1e-6)
+        assert up[3, 0] == 0 and up[3, -1] == 19            # clamped to the edge pixels
+        # kernels that sum to 1 keep constants (float32 coefficients: to rounding)
+        for interp in (L, Cb, Z):
+            assert_close(oracle.resize(np.full((9, 11), 2.0, dt), (31, 40), interp),
+                         np.full((31, 40), 2.0), 1e-6)
+    with pytest.raises(RuntimeError):   # INTER_AREA upscaling is a different algorithm in OpenCV
+        oracle.resize(np.zeros((4, 4), np.float32), (8, 8), oracle.RESIZE_AREA)
+    # fastFilter / fastMean end to end run (shape and smoothness only: cv2-unpinned)
+    img = rng.random((120, 171)) * 100
+    out = oracle.fastFilter(img, 30)
+    assert out.shape == img.shape and np.isfinite(out).all()
+    fm = oracle.fastMean(img.astype(np.float32), 10)
+    assert fm.shape == img.shape and fm.dtype == np.float32 and abs(fm.mean() - img.mean()) < 1.0
