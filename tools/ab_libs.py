@@ -64,6 +64,13 @@ def main():
     k5 = np.outer(g, g)
     g7 = np.exp(-0.5 * (np.arange(-3, 4) / 1.5) ** 2)
     k7 = np.outer(g7, g7) / g7.sum() ** 2
+    quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+    rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+    A, rhs = [], []
+    for (x, y), (u, v) in zip(rect, quad):   # rectangle (destination) -> quad (source)
+        A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
+        rhs += [u, v]
+    Hq = np.append(np.linalg.solve(np.array(A), np.array(rhs)), 1.0).reshape(3, 3)
     k9 = np.random.default_rng(99).random((9, 9))
     k9 /= k9.sum()
     k11 = np.random.default_rng(321).random((11, 11))
@@ -106,6 +113,7 @@ def main():
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
             'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
+            'lz4': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'lanczos4', out=m.dst),
             'conv9': lambda o=ops, m=mod: o.conv2d(m.src, k9, out=m.dst),
             'conv11': lambda o=ops, m=mod: o.conv2d(m.src, k11, out=m.dst),
             'fused9': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k9, out=m.dst),
