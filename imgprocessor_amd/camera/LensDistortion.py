@@ -186,9 +186,9 @@ class LensDistortion(object):
         if roi is not None and (roi[2] <= 0 or roi[3] <= 0):
             # the optimal camera matrix left no valid rectangle: the reference's crop
             # dst[y:y+h, x:x+w] (:327-329) is then an empty array
-            if isinstance(image, DeviceArray):
+            if isinstance(image, DeviceArray):   # device in, device out - also when empty
                 lead = tuple(shape[:-2])
-                self.img = np.empty(lead + (max(roi[3], 0), max(roi[2], 0)), image.dtype)
+                self.img = image.ctx.empty(lead + (max(roi[3], 0), max(roi[2], 0)), image.dtype)
             else:
                 a = np.asarray(image)
                 self.img = np.empty((max(roi[3], 0), max(roi[2], 0)) + a.shape[2:], a.dtype)

@@ -66,6 +66,7 @@ struct ipa_ctx {
   unsigned* ring_hint = nullptr;
   double ring_hint_key[40];
   int ring_hint_n = 0;
+  unsigned ring_hint_skips = 0;   // calls that skipped the planning pass on the hint's word
   // float32 coordinate maps of the last lens model a fused undistort + filter call was made
   // with (what LensDistortion.getUndistortRectifyMap caches, camera/LensDistortion.py:344-345):
   // the next call with the same K, distortion, newK and size reads them instead of evaluating

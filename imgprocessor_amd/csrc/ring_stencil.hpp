@@ -268,8 +268,12 @@ static int ring_plan_prepare(ipa_ctx* ctx, const RingGeom& gm, const Coord& coor
   // hint only: the results are the same bits either way.
   const bool same = ctx->ring_hint_n == kn &&
                     memcmp(ctx->ring_hint_key, key, (size_t)kn * sizeof(double)) == 0;
+  // (a stale "few clean strips" - a read-back that landed after the key changed, maps rewritten
+  // at the same address - would otherwise keep the ring path off for as long as the key stays:
+  // every 16th skipped call plans again and refreshes the hint)
   if (same && ctx->ring_hint && ctx->ring_hint[1] == (unsigned)gm.pairs &&
-      ctx->ring_hint[0] != 0xffffffffu && 2u * ctx->ring_hint[0] < (unsigned)gm.pairs)
+      ctx->ring_hint[0] != 0xffffffffu && 2u * ctx->ring_hint[0] < (unsigned)gm.pairs &&
+      (++ctx->ring_hint_skips & 15u) != 0)
     return 1;
   const bool hit = kByValue && ctx->plan_key_n == kn &&
                    memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0;
@@ -290,8 +294,9 @@ static int ring_plan_prepare(ipa_ctx* ctx, const RingGeom& gm, const Coord& coor
       IPA_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->ring_hint), 2 * sizeof(unsigned)));
     if (!same) {
       // another source / geometry: nothing known yet (a read-back of the old one still in
-      // flight may land here once - a wrong hint for one call, corrected by the next)
+      // flight may land here once - a wrong hint, corrected by the next planning pass)
       ctx->ring_hint[0] = 0xffffffffu;
+      ctx->ring_hint_skips = 0;
       memcpy(ctx->ring_hint_key, key, (size_t)kn * sizeof(double));
       ctx->ring_hint_n = kn;
     }

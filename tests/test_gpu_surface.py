@@ -142,6 +142,10 @@ def test_lens_distortion_quirks(ia):
     assert e.shape == (0, 0) and e.dtype == img.dtype
     rgb = np.stack([img, img], axis=2)
     assert ld.correct(rgb, keepSize=False).shape == (0, 0, 2)
+    # device in, device out - the empty crop too
+    d = ia.default_context(0).to_device(np.stack([img, img]))
+    ed = ld.correct(d, keepSize=False)
+    assert isinstance(ed, ia.device.DeviceArray) and ed.shape == (2, 0, 0) and ed.get().size == 0
 
 
 def test_device_argument_validation(ia):
