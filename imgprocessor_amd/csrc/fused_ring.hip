@@ -17,7 +17,9 @@ static int ring_launch(ipa_ctx* ctx, FusedCall& f, const Coord& c) {
   gm.strips_x = (gm.dw + G::OW - 1) / G::OW;
   gm.pairs_x = (gm.strips_x + 1) / 2;
   // the per-frame kernel's strip height for this launch (fused_launch_one computes the same)
-  gm.strip_h = wave_strip_height(ctx, gm.dh, gm.dw, f.n_frames, K);
+  using Src = SampleRowSrc<ST, kLinear, Coord>;
+  gm.strip_h = wave_strip_height(ctx, gm.dh, gm.dw, f.n_frames, K, false,
+                                 shared_capable<Src, K>::value && IPA_PIPE ? 2 : 0);
   const int rows = (gm.dh + gm.strip_h - 1) / gm.strip_h;
   gm.strips = gm.strips_x * rows;
   gm.pairs = gm.pairs_x * rows;
