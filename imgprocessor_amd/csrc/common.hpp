@@ -37,6 +37,9 @@ struct ipa_tuning {
   int ring_big = 0;       // batches, 7x7..11x11 after a remap in one kernel with the taps in LDS (1: bicubic, 2: all; measured slower)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
+  int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
+                          // by value (homography, lens model) that the ring kernel does not take: the coordinates
+                          // are evaluated ONCE into the plan buffer and the gather kernel reads them (0: never)
 };
 
 struct ipa_ctx {

@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) remap_kernel(RemapParams p, Coord coord) 
   // (map-based remaps only: the analytic coordinate sources measured 3-13 % slower this way)
   // (float destinations only: integer ones - uint8 / uint16, bound by their arithmetic - measured
   // level (uint8) to 8-20 % slower (uint16) this way)
-  constexpr bool kIlv = !FIXED && sizeof(DT) == 4 && std::is_same<Coord, MapCoord>::value;
+  constexpr bool kIlv = !FIXED && sizeof(DT) == 4 && coord_is_table<Coord>::value;
   if constexpr (kIlv) {
     __shared__ __attribute__((aligned(16))) DT xpose[4][256];
     const int xw = (int)(txi * 256u);  // wave-uniform (threadIdx.y = wave)
@@ -459,6 +459,55 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
   return 0;
 }
 
+// ------------------------------------------------------------ stored coordinates --
+// A coordinate source given by value (homography: double coordinates, ~40 float64 operations
+// per pixel; lens model) evaluated ONCE per (source, geometry) into the context's plan buffer, in
+// the source's own type - the frames of a batch then sample through remap_kernel<StoredCoord>
+// exactly what the per-pixel evaluation would give (same coordinate bits), in the
+// lane-interleaved order of the map-based kernel.  16 x 4K, 7 degrees + perspective (no clean
+// strips for the ring kernel): bicubic 0.648 -> 0.600 ms, Lanczos4 1.853 -> 1.467 ms (the same warp
+// from float32 maps, i.e. other coordinate bits: 0.502 / 1.344).
+template <typename Coord>
+__global__ void __launch_bounds__(256)
+store_coords_kernel(Coord c, int dh, int dw, typename Coord::coord_t* __restrict__ ox,
+                    typename Coord::coord_t* __restrict__ oy) {
+  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
+  if (u >= dw) return;
+  typename Coord::coord_t sx, sy;
+  c.get(u, v, sx, sy);
+  ox[(long)v * dw + u] = sx;
+  oy[(long)v * dw + u] = sy;
+}
+
+template <typename Coord>
+static int stored_coords_prepare(ipa_ctx* ctx, const Coord& coord, int dh, int dw,
+                                 StoredCoord<typename Coord::coord_t>* sc) {
+  using CT = typename Coord::coord_t;
+  if (dh > 65535) return 1;
+  double key[40];
+  int kn = coord_key(coord, key);
+  key[kn++] = (double)dh; key[kn++] = (double)dw; key[kn++] = (double)sizeof(CT);
+  key[kn++] = 7777.0;   // (not a ring plan: those keys are longer)
+  const size_t plane = (((size_t)dh * dw * sizeof(CT)) + 255) & ~(size_t)255;
+  const bool hit = ctx->plan_key_n == kn &&
+                   memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0 &&
+                   ctx->plan_bytes >= 2 * plane;
+  if (!hit) {
+    int rc = ipa_plan_reserve(ctx, 2 * plane);
+    if (rc) return rc;
+  }
+  CT* ox = reinterpret_cast<CT*>(ctx->plan);
+  CT* oy = reinterpret_cast<CT*>(reinterpret_cast<char*>(ctx->plan) + plane);
+  if (!hit) {
+    hipLaunchKernelGGL((store_coords_kernel<Coord>), dim3((unsigned)((dw + 255) / 256), (unsigned)dh),
+                       dim3(256), 0, ctx->stream, coord, dh, dw, ox, oy);
+    memcpy(ctx->plan_key, key, (size_t)kn * sizeof(double));
+    ctx->plan_key_n = kn;
+  }
+  *sc = StoredCoord<CT>{ox, oy, (long)dw};
+  return 0;
+}
+
 template <typename Coord>
 static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, int map_vec) {
   if (!ctx) return IPA_ERR_BAD_ARG;
@@ -564,6 +613,22 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
                        dim3(1024), 0, ctx->stream, p, coord);
     IPA_HIP(ctx, hipGetLastError());
     return IPA_OK;
+  }
+  if constexpr (!coord_is_table<Coord>::value) {
+    const int smin = ctx->tune.stored_coords;
+    if (!p.skip && smin > 0 && a.n_frames >= smin && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
+        (base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS || base == IPA_INTER_LANCZOS4)) {
+      StoredCoord<typename Coord::coord_t> sc;
+      rc = stored_coords_prepare<Coord>(ctx, coord, a.dh, a.dw, &sc);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        RemapParams q = p;
+        q.map_vec = 1;   // rows of dw coordinates, 256-byte aligned planes
+        launch_interp<float, float, StoredCoord<typename Coord::coord_t>, false>(ctx, q, sc, base, grid);
+        IPA_HIP(ctx, hipGetLastError());
+        return IPA_OK;
+      }
+    }
   }
   int s = a.src_dt, d = a.dst_dt;
   if (p.skip) {

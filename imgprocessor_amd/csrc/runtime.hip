@@ -69,6 +69,7 @@ const TuneName kTuneNames[] = {
     {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
     {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
+    {"stored_coords", "IPA_STORED_COORDS", &ipa_tuning::stored_coords},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
@@ -96,7 +97,7 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "ring_remap") == 0 || strcmp(name, "ring_big") == 0 ||
       strcmp(name, "pair") == 0)
     return v >= 0 && v <= 2;
-  if (strcmp(name, "ring_ablate") == 0) return v >= 0;
+  if (strcmp(name, "ring_ablate") == 0 || strcmp(name, "stored_coords") == 0) return v >= 0;
   return v == 0 || v == 1;
 }
 

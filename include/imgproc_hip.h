@@ -79,7 +79,9 @@ int ipa_ctx_destroy(ipa_ctx* ctx);
 int ipa_ctx_synchronize(ipa_ctx* ctx);
 /* Launch-shape knobs of a context (csrc/runtime.hip::kTuneNames is the list):
  *   "strip_h" (0 = by launch size), "frames_inner", "frames_wg", "frame_major", "big_wave",
- *   "big_fused", "stream_k", "pipe7", "ring_remap", "ring_min", "lens_cache", "u8_lz_lds";
+ *   "big_fused", "stream_k", "pipe7", "ring_remap", "ring_min", "lens_cache", "u8_lz_lds",
+ *   "stored_coords" (smallest batch whose homography / lens coordinates are evaluated once
+ *   for all frames, 0 = never);
  *   only in `make EXPERIMENTAL=1` builds (rejected with IPA_ERR_UNSUPPORTED otherwise):
  *   "group", "group_min", "group_ring", "ring", "pair", "ring_big", "ring_ablate";
  *   read-only: "experimental" (1 in such a build).

@@ -73,6 +73,13 @@ def main():
     ang = np.deg2rad(7.0)   # C5's warp: rotation + mild perspective
     R7 = np.array([[np.cos(ang), -np.sin(ang), 150.0], [np.sin(ang), np.cos(ang), -100.0],
                    [4e-6, -2e-6, 1.0]])
+    r7x = r7y = None
+    if 'rot7cubicmap' in what or 'rot7lz4map' in what or 'rot7linearmap' in what:
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+        W = R7[2, 0] * xx + R7[2, 1] * yy + R7[2, 2]
+        r7x = ctx.to_device(((R7[0, 0] * xx + R7[0, 1] * yy + R7[0, 2]) / W).astype(np.float32))
+        r7y = ctx.to_device(((R7[1, 0] * xx + R7[1, 1] * yy + R7[1, 2]) / W).astype(np.float32))
+        del yy, xx, W
     calls = {
         'c3': lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, 'linear', out=dst),
         'warp5': lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k5, 'linear', out=dst),
@@ -87,6 +94,10 @@ def main():
         'rot7cubic': lambda: ops.warp_perspective(src, R7, (h, w), 'cubic', out=dst),
         'rot7lz4': lambda: ops.warp_perspective(src, R7, (h, w), 'lanczos4', out=dst),
         'c5': lambda: ops.warp_perspective_conv2d(src, R7, (h, w), k11, 'cubic', out=dst),
+        'rot7cubicmap': lambda: ops.remap(src, r7x, r7y, 'cubic', out=dst),
+        'rot7lz4map': lambda: ops.remap(src, r7x, r7y, 'lanczos4', out=dst),
+        'rot7linear': lambda: ops.warp_perspective(src, R7, (h, w), 'linear', out=dst),
+        'rot7linearmap': lambda: ops.remap(src, r7x, r7y, 'linear', out=dst),
         'remap': lambda: ops.remap(src, dmx, dmy, out=dst),
         'copy': lambda: dst.copy_from(src),
     }
