@@ -377,22 +377,17 @@ def main():
             return timed(ctx, lambda: ops.undistort_conv2d(s_, K, dcoef, K, k5, out=d_), 8, 4)
         for _ in range(5):
             trial(d_src, d_dst)                                   # clocks up from idle first
-        srcs, dsts = [d_src], [d_dst]
-        for _ in range(args.placements - 1):
-            c_ = ctx.empty((B, h, w), np.float32)
-            c_.copy_from(d_src)
-            srcs.append(c_)
-            dsts.append(ctx.empty((B, h, w), np.float32))
-        t_src = [trial(s_, dsts[0]) for s_ in srcs]
-        bi = min(range(len(srcs)), key=lambda i: t_src[i])
-        t_dst = [trial(srcs[bi], d_) for d_ in dsts]
-        bj = min(range(len(dsts)), key=lambda j: t_dst[j])
-        d_src, d_dst = srcs[bi], dsts[bj]
+        first = d_src
+        d_src, t_src = ctx.empty_placed((B, h, w), np.float32, lambda a: trial(a, d_dst),
+                                        args.placements, fill=lambda a: a.copy_from(first))
+        del first
+        d_dst, t_dst = ctx.empty_placed((B, h, w), np.float32, lambda a: trial(d_src, a),
+                                        args.placements)
         placement = {'candidates': args.placements,
-                     'source_ms': [round(t, 4) for t in t_src], 'source_kept': bi,
-                     'result_ms': [round(t, 4) for t in t_dst], 'result_kept': bj}
-        del srcs, dsts, c_
-        ctx.trim()   # the candidates that were not kept go back to the driver
+                     'source_ms': [round(t, 4) for t in t_src],
+                     'source_kept': int(np.argmin(t_src)),
+                     'result_ms': [round(t, 4) for t in t_dst],
+                     'result_kept': int(np.argmin(t_dst))}
 
     px = B * h * w
     # bytes per launch.  `compulsory`: what must cross the HBM interface - source and result

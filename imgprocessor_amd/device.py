@@ -111,6 +111,26 @@ class Context(object):
     def empty(self, shape, dtype):
         return DeviceArray(self, shape, dtype)
 
+    def empty_placed(self, shape, dtype, probe, candidates=4, fill=None):
+        """An uninitialised array like `empty`, chosen among `candidates` allocations by what
+        `probe(array)` measures (milliseconds of the caller's own streaming launch on it; the
+        smallest wins), the others freed.  Where a large buffer lands in physical memory moves
+        the streaming kernels of this library by up to 10 % on MI355X; a
+        caller that allocates its frame batches once can afford the few launches this costs.
+        `fill(array)` (e.g. ``lambda a: a.copy_from(src)``) initialises every candidate before
+        it is probed.  Returns (array, [milliseconds per candidate])."""
+        held, times = [], []
+        for _ in range(max(1, int(candidates))):
+            a = DeviceArray(self, shape, dtype)   # (every candidate is held until the choice is
+            if fill is not None:                  # made: a freed one would be handed out again)
+                fill(a)
+            times.append(float(probe(a)))
+            held.append(a)
+        best = held[int(np.argmin(times))]
+        del held, a
+        self.trim()   # the candidates that were not kept go back to the driver
+        return best, times
+
     def to_device(self, arr):
         arr = np.ascontiguousarray(arr)
         d = DeviceArray(self, arr.shape, arr.dtype)

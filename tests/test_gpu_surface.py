@@ -224,3 +224,20 @@ def test_headline_64x4k_every_frame(ia, orc):
         worst = max(worst, float(np.max(np.abs(got[i] - want)) / np.max(np.abs(want))))
     print('headline 64 x 4K: max |err| / max |ref| = %.3g' % worst)
     assert worst < 1e-5
+
+
+def test_empty_placed_keeps_the_fastest_candidate(ia):
+    """Context.empty_placed: candidates are distinct allocations, the one the probe likes best
+    is returned, the others go back to the driver"""
+    ctx = ia.default_context(0)
+    seen = []
+
+    def probe(a):
+        seen.append(a.ptr.value)
+        return {0: 3.0, 1: 1.0, 2: 2.0}[len(seen) - 1]
+    src = ctx.to_device(np.arange(12, dtype=np.float32).reshape(3, 4))
+    a, times = ctx.empty_placed((3, 4), np.float32, probe, candidates=3,
+                                fill=lambda c: c.copy_from(src))
+    assert times == [3.0, 1.0, 2.0] and len(set(seen)) == 3
+    assert a.ptr.value == seen[1] and a.shape == (3, 4)
+    assert np.array_equal(a.get(), src.get())
