@@ -248,3 +248,48 @@ def test_ring_remap_hint_skips_the_ring_for_rotations(ia):
             same_bits(ops.remap(d_src, d2x, d2y, 'cubic').get(), want_r, 'radial, call %d' % i)
     finally:
         ctx.set_tuning(**old)
+
+
+def test_stored_coordinates_have_the_bits_of_the_per_pixel_evaluation(oracle):
+    """batches of bicubic / Lanczos4 warps that the ring kernel declines (rotation): the
+    homography / lens model is evaluated once into the plan buffer and every frame reads it
+    (knob stored_coords) - identical bits to evaluating it per pixel and frame, and the oracle's
+    values"""
+    import imgprocessor_amd as ia
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(13)
+    n, h, w = 6, 150, 331
+    src = rng.random((n, h, w), dtype=np.float32)
+    d = ctx.to_device(src)
+    a = np.deg2rad(11.0)
+    M = np.array([[np.cos(a), -np.sin(a), 40.0], [np.sin(a), np.cos(a), -30.0], [3e-5, -2e-5, 1.0]])
+    Kc = np.array([[300.0, 0, (w - 1) / 2.0], [0, 300.0, (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([-0.2, 0.05, 1e-3, -1e-3, 0.0])
+    oi = {'cubic': oracle.CUBIC_KEYS, 'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5,
+          'lanczos4': oracle.LANCZOS4}
+    old = ctx.set_tuning(stored_coords=0)
+    try:
+        for interp in ('cubic', 'cubic_cv_q5', 'lanczos4'):
+            for border in ('constant', 'reflect'):
+                for name, call in (
+                        ('warp', lambda: ops.warp_perspective(d, M, (h - 7, w + 5), interp, border, 0.25)),
+                        ('undistort', lambda: ops.undistort(d, Kc, dist, Kc, interp, border, 0.25))):
+                    ctx.set_tuning(stored_coords=0)
+                    ref = call().get()
+                    ctx.set_tuning(stored_coords=4)
+                    for rep in range(2):      # the second call reuses the stored coordinates
+                        got = call().get()
+                        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), \
+                            (name, interp, border, rep)
+                    if name == 'warp':
+                        want = oracle.warp_perspective(src[2], M, (h - 7, w + 5), oi[interp],
+                                                       border, 0.25)
+                        assert np.abs(got[2] - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+        # below the batch threshold nothing is stored (and nothing changes)
+        ctx.set_tuning(stored_coords=0)
+        ref = ops.warp_perspective(d, M, (h, w), 'lanczos4').get()
+        ctx.set_tuning(stored_coords=8)
+        assert np.array_equal(ops.warp_perspective(d, M, (h, w), 'lanczos4').get(), ref)
+    finally:
+        ctx.set_tuning(**old)
