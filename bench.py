@@ -321,7 +321,7 @@ def main():
     ap.add_argument('--height', type=int, default=H4K)
     ap.add_argument('--width', type=int, default=W4K)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--placements', type=int, default=6,
+    ap.add_argument('--placements', type=int, default=8,
                     help='setup: candidate allocations per batch buffer, the one that streams '
                          'fastest is kept (1 = take the first as it comes)')
     ap.add_argument('--no-settle', action='store_true',
