@@ -71,6 +71,8 @@ def main():
         A += [[x, y, 1, 0, 0, 0, -u * x, -u * y], [0, 0, 0, x, y, 1, -v * x, -v * y]]
         rhs += [u, v]
     Hq = np.append(np.linalg.solve(np.array(A), np.array(rhs)), 1.0).reshape(3, 3)
+    g9 = np.exp(-0.5 * np.arange(-4, 5) ** 2)
+    g9 /= g9.sum()
     k9 = np.random.default_rng(99).random((9, 9))
     k9 /= k9.sum()
     k11 = np.random.default_rng(321).random((11, 11))
@@ -113,6 +115,8 @@ def main():
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
             'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
+            'cubic': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'cubic', out=m.dst),
+            'c3cubic': lambda o=ops, m=mod: o.warp_perspective_sepconv2d(m.src, Hq, (h, w), g9, g9, 'cubic', out=m.dst),
             'lz4': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'lanczos4', out=m.dst),
             'conv9': lambda o=ops, m=mod: o.conv2d(m.src, k9, out=m.dst),
             'conv11': lambda o=ops, m=mod: o.conv2d(m.src, k11, out=m.dst),
