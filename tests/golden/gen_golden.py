@@ -788,6 +788,161 @@ def gen_warp_skimage():
     np.savez_compressed(os.path.join(HERE, 'warp_skimage.npz'), **d)
 
 
+# ---- cv2.resize, second restatement (numpy, vectorised; independent of oracle.c) -------------
+def _resize_axis_np(ssize, dsize, kind, clamp_x):
+    """per destination index: first-tap offset and float32 coefficients (resize.cpp)"""
+    ks = {'linear': 2, 'cubic': 4, 'lanczos4': 8}[kind]
+    scale = 1.0 / (float(dsize) / float(ssize))
+    f = ((np.arange(dsize) + 0.5) * scale - 0.5).astype(np.float32)
+    s0 = np.floor(f).astype(np.int64)
+    f = (f - s0.astype(np.float32)).astype(np.float32)
+    xmax = dsize
+    if clamp_x:
+        if kind == 'linear':
+            lo = s0 < 0
+            f[lo], s0[lo] = 0, 0
+        over = s0 + ks // 2 >= ssize
+        if over.any():
+            xmax = int(np.argmax(over))
+        if kind == 'linear':
+            hi = s0 >= ssize - 1
+            f[hi], s0[hi] = 0, ssize - 1
+    one = np.float32(1)
+    if kind == 'linear':
+        co = np.stack([one - f, f], 1)
+    elif kind == 'cubic':
+        A = np.float32(-0.75)
+        c0 = ((A * (f + one) - np.float32(5) * A) * (f + one) + np.float32(8) * A) * (f + one) - np.float32(4) * A
+        c1 = ((A + np.float32(2)) * f - (A + np.float32(3))) * f * f + one
+        g = one - f
+        c2 = ((A + np.float32(2)) * g - (A + np.float32(3))) * g * g + one
+        co = np.stack([c0, c1, c2, one - c0 - c1 - c2], 1).astype(np.float32)
+    else:
+        s45 = 0.70710678118654752440084436210485
+        cs = np.array([[1, 0], [-s45, -s45], [0, 1], [s45, -s45], [-1, 0], [s45, s45], [0, -1], [-s45, s45]])
+        x = f.astype(np.float64)
+        y0 = -(x + 3) * np.pi * 0.25
+        s_, c_ = np.sin(y0), np.cos(y0)
+        i = np.arange(8)
+        y = -(x[:, None] + 3 - i[None, :]) * np.pi * 0.25
+        with np.errstate(divide='ignore', invalid='ignore'):
+            co = ((cs[None, :, 0] * s_[:, None] + cs[None, :, 1] * c_[:, None]) / (y * y)).astype(np.float32)
+        tot = np.zeros(dsize, np.float32)
+        for j in range(8):
+            tot = tot + co[:, j]
+        co = (co * (one / tot)[:, None]).astype(np.float32)
+        small = f < np.finfo(np.float32).eps
+        co[small] = 0
+        co[small, 3] = 1
+    return s0, co.astype(np.float32), ks, xmax
+
+
+def resize_np(img, dsize_hw, kind):
+    """cv2.resize(img, (w, h), interpolation=kind) for 2-D float32 / float64, numpy restatement"""
+    img = np.asarray(img)
+    wt = img.dtype.type
+    sh, sw = img.shape
+    dh, dw = dsize_hw
+    if kind == 'area':
+        sx_, sy_ = 1.0 / (float(dw) / sw), 1.0 / (float(dh) / sh)
+        ix, iy = int(np.rint(sx_)), int(np.rint(sy_))
+        eps = np.finfo(np.float64).eps
+        if abs(sx_ - ix) < eps and abs(sy_ - iy) < eps:
+            out = np.zeros((dh, dw), img.dtype)
+            w1 = sw // ix
+            for dy in range(dh):
+                sy0 = dy * iy
+                if sy0 >= sh:
+                    continue
+                wfull = min(w1 if sy0 + iy <= sh else 0, dw)
+                for dx in range(dw):
+                    sx0 = dx * ix
+                    if dx < wfull:
+                        blk = img[sy0:sy0 + iy, sx0:sx0 + ix].reshape(-1)   # row-major = ofs[k]
+                        acc = wt(0)
+                        k = 0
+                        while k <= blk.size - 4:
+                            acc = wt(acc + wt(wt(wt(blk[k] + blk[k + 1]) + blk[k + 2]) + blk[k + 3]))
+                            k += 4
+                        while k < blk.size:
+                            acc = wt(acc + blk[k])
+                            k += 1
+                        out[dy, dx] = wt(acc * wt(np.float32(1) / np.float32(ix * iy)))
+                    elif sx0 < sw:
+                        blk = img[sy0:min(sy0 + iy, sh), sx0:min(sx0 + ix, sw)].reshape(-1)
+                        acc = wt(0)
+                        for v in blk:
+                            acc = wt(acc + v)
+                        out[dy, dx] = wt(np.float32(acc) / np.float32(blk.size))
+            return out
+
+        def tab(ssize, dsize, scale):
+            t = []
+            for d in range(dsize):
+                f1 = d * scale
+                f2 = f1 + scale
+                cell = min(scale, ssize - f1)
+                s1, s2 = int(np.ceil(f1)), int(np.floor(f2))
+                s2 = min(s2, ssize - 1)
+                s1 = min(s1, s2)
+                if s1 - f1 > 1e-3:
+                    t.append((d, s1 - 1, np.float32((s1 - f1) / cell)))
+                for s in range(s1, s2):
+                    t.append((d, s, np.float32(1.0 / cell)))
+                if f2 - s2 > 1e-3:
+                    t.append((d, s2, np.float32(min(min(f2 - s2, 1.0), cell) / cell)))
+            return t
+        xt, yt = tab(sw, dw, sx_), tab(sh, dh, sy_)
+        out = np.zeros((dh, dw), img.dtype)
+        for dy in range(dh):
+            acc = np.zeros(dw, img.dtype)
+            for (d, sy, beta) in [e for e in yt if e[0] == dy]:
+                buf = np.zeros(dw, img.dtype)
+                for (dx, sxx, alpha) in xt:
+                    buf[dx] = wt(buf[dx] + wt(img[sy, sxx] * wt(alpha)))
+                acc = (acc + wt(beta) * buf).astype(img.dtype)
+            out[dy] = acc
+        return out
+    sx0, ax, ks, xmax = _resize_axis_np(sw, dw, kind, True)
+    sy0, ay, _, _ = _resize_axis_np(sh, dh, kind, False)
+    tmp = np.zeros((sh, dw), img.dtype)
+    if ks == 2:
+        cols = np.arange(dw)
+        inner = cols < xmax
+        a0, a1 = ax[:, 0].astype(img.dtype), ax[:, 1].astype(img.dtype)
+        sx1 = np.minimum(sx0 + 1, sw - 1)
+        tmp[:] = img[:, sx0] * wt(1)
+        tmp[:, inner] = (img[:, sx0[inner]] * a0[inner] + img[:, sx1[inner]] * a1[inner])
+    else:
+        for j in range(ks):
+            idx = np.clip(sx0 - (ks // 2 - 1) + j, 0, sw - 1)
+            tmp = (tmp + img[:, idx] * ax[:, j].astype(img.dtype)[None, :]).astype(img.dtype)
+    out = None
+    for k in range(ks):
+        idx = np.clip(sy0 - ks // 2 + 1 + k, 0, sh - 1)
+        term = (tmp[idx, :] * ay[:, k].astype(img.dtype)[:, None]).astype(img.dtype)
+        out = term if out is None else (out + term).astype(img.dtype)
+    return out
+
+
+def gen_cv_resize():
+    """cv_resize.npz: inputs and the numpy restatement's outputs (cv2 itself cannot run here)"""
+    out = {}
+    rng = np.random.default_rng(31)
+    for dt in (np.float32, np.float64):
+        tag = 'f32' if dt == np.float32 else 'f64'
+        a = rng.standard_normal((37, 53)).astype(dt)
+        out['img_' + tag] = a
+        for kind in ('linear', 'cubic', 'lanczos4'):
+            for (dh, dw) in ((120, 171), (20, 31), (37, 53), (50, 40)):
+                out['%s_%s_%dx%d' % (kind, tag, dh, dw)] = resize_np(a, (dh, dw), kind)
+        b = rng.random((36, 52)).astype(dt)
+        out['aimg_' + tag] = b
+        for (dh, dw) in ((18, 26), (12, 13), (10, 17), (36, 52), (17, 25)):
+            out['area_%s_%dx%d' % (tag, dh, dw)] = resize_np(b, (dh, dw), 'area')
+    np.savez_compressed(os.path.join(HERE, 'cv_resize.npz'), **out)
+
+
 def gen_fast_filter():
     """fast_filter.npz: the strided window statistics of filters/fastFilter.py run from the
     reference's own source (resize=False: the cv2.resize that follows cannot run here).  The
@@ -892,9 +1047,13 @@ if __name__ == '__main__':
     if sys.argv[1:] == ['fast_filter']:
         gen_fast_filter()
         sys.exit(0)
+    if sys.argv[1:] == ['cv_resize']:
+        gen_cv_resize()
+        sys.exit(0)
     gen_stencils()
     gen_interp_more()
     gen_fast_filter()
+    gen_cv_resize()
     gen_remap_scipy()
     gen_cv_modes()
     gen_warp_skimage()

@@ -130,3 +130,18 @@ def test_fast_filter_and_fast_mean_end_to_end(ia, oracle):
     d = ctx.to_device(a.astype(np.float32))
     r = ia.ops.resize(d, (24, 34), 'area')
     assert np.array_equal(r.get(), oracle.resize(a.astype(np.float32), (24, 34), oracle.RESIZE_AREA))
+
+
+def test_resize_vs_second_restatement(ia):
+    """the GPU against the numpy restatement's fixture (cv_resize.npz), independent of oracle.c"""
+    from .test_oracle_golden import cv_resize_cases
+    g = load_golden('cv_resize.npz')
+    n = 0
+    for key, src, dsize, kind, _ in cv_resize_cases(g):
+        got = ia.ops.resize(src, dsize, kind)
+        if kind == 'lanczos4':
+            assert_close(got, g[key], 0, 2e-6, key)
+        else:
+            assert np.array_equal(got, g[key]), key
+        n += 1
+    assert n == 34

@@ -553,3 +553,30 @@ def test_cv_resize_restatement_properties(oracle):
     assert out.shape == img.shape and np.isfinite(out).all()
     fm = oracle.fastMean(img.astype(np.float32), 10)
     assert fm.shape == img.shape and fm.dtype == np.float32 and abs(fm.mean() - img.mean()) < 1.0
+
+
+def cv_resize_cases(g):
+    ids = {'linear': 1, 'cubic': 2, 'area': 3, 'lanczos4': 4}
+    for key in g:
+        if key.startswith('img_') or key.startswith('aimg_'):
+            continue
+        kind, tag, size = key.split('_')
+        dh, dw = (int(v) for v in size.split('x'))
+        yield key, g[('aimg_' if kind == 'area' else 'img_') + tag], (dh, dw), kind, ids[kind]
+
+
+def test_cv_resize_independent_restatement(oracle):
+    """cv2.resize: oracle.c against the second, vectorised numpy restatement
+    (tests/golden/gen_golden.py::resize_np).  Bilinear, bicubic and both INTER_AREA forms agree bit
+    for bit; Lanczos4 to the last bits of the float32 coefficients (numpy's vectorised sin / cos
+    against libm's, as for the remap table in cv_modes.npz)."""
+    g = load_golden('cv_resize.npz')
+    n = 0
+    for key, src, dsize, kind, oid in cv_resize_cases(g):
+        got = oracle.resize(src, dsize, oid)
+        if kind == 'lanczos4':
+            assert_close(got, g[key], 0, 2e-6, key)
+        else:
+            assert np.array_equal(got, g[key]), key
+        n += 1
+    assert n == 34
