@@ -780,7 +780,12 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
   const int4* wrow = tab2d + (((qy & 31) << 5) | (qx & 31)) * kU8LzRow;
   // pr[r][j] = taps 2j, 2j+1 of row r as two 16-bit lanes (the table packs its shorts the same way)
   unsigned pr[8][4];
-  if (ix0 >= 0 && iy0 >= 0 && ix0 + 8 <= s.w && iy0 + 8 <= s.h) {
+  // (the three dwords of a tap row reach up to 3 bytes past the footprint: in the LAST row of the
+  // frame that is past the frame's buffer descriptor, which answers the whole dword with 0 -
+  // such footprints take the byte path.  Found by tests/fuzz_oracle.py: one pixel in the
+  // bottom-right corner off by one level.)
+  const bool tail_ok = iy0 + 8 < s.h || (ix0 & ~3) + 12 <= s.w;
+  if (ix0 >= 0 && iy0 >= 0 && ix0 + 8 <= s.w && iy0 + 8 <= s.h && tail_ok) {
     // three ALIGNED dwords per tap row (two dwords at the sample's odd byte offset cost the
     // texture addresser a third more); one v_perm_b32 per tap pair picks bytes sh + 2j, sh + 2j + 1
     // out of two of them and widens them to 16 bits

@@ -47,6 +47,8 @@ def main():
         iname = str(rng.choice(list(INTERPS)))
         bname = str(rng.choice(list(BORDERS)))
         cval = float(rng.choice([0.0, 0.3, 17.0])) if dt != np.float32 else float(rng.choice([0.0, 0.3]))
+        if os.environ.get('FUZZ_ONLY') and int(os.environ['FUZZ_ONLY']) != case:
+            continue   # (every random draw of the case is above: the stream stays in step)
         got = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), iname, bname,
                         cval).get()
         for f in range(n):
@@ -62,6 +64,11 @@ def main():
                 fails += 1
                 print('MISMATCH case %d frame %d: %s %dx%d -> %dx%d %s %s cval %g'
                       % (case, f, np.dtype(dt).name, h, w, dh, dw, iname, bname, cval))
+                df = np.abs(got[f].astype(np.float64) - want.astype(np.float64))
+                idx = np.argwhere(df > 0)
+                print('   %d values differ, max |d| %g; first at %s: got %r want %r, map (%r, %r)'
+                      % (len(idx), np.nanmax(df), idx[0].tolist(), got[f][tuple(idx[0])],
+                         want[tuple(idx[0])], mx[tuple(idx[0])], my[tuple(idx[0])]))
                 break
         if (case + 1) % 50 == 0:
             print('%d cases, %d mismatches, worst float error %.2e' % (case + 1, fails, worst), flush=True)

@@ -861,3 +861,20 @@ def test_cv_modes_vs_independent_restatements(ia, oracle):
                 want = g['%s_%s_%s' % (key, kind, name)]
                 d = np.abs(ia.ops.remap(img8, mx, my, iname, border_value=cv).astype(np.int32) - want)
                 assert d.max() <= 1 and (d != 0).mean() <= frac, (kind, name, key)
+
+
+def test_u8_lanczos4_footprints_ending_on_the_last_pixel(ia, oracle):
+    """uint8 Lanczos4 (OpenCV's 8U table arithmetic): a footprint whose last tap is the LAST pixel of
+    the frame - its aligned tap dwords would reach past the frame's buffer descriptor - must still
+    be bit-exact (found by tests/fuzz_oracle.py in the bottom-right corner of a 204 x 155 frame)"""
+    rng = np.random.default_rng(21)
+    for (h, w) in ((204, 155), (37, 53), (40, 64), (33, 67)):
+        for n in (1, 3):
+            src = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
+            yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+            mx = (xx * ((w - 4.2) / (w - 1))).astype(np.float32)      # last column -> x = w - 4.2
+            my = (yy * ((h - 4.22) / (h - 1))).astype(np.float32)     # last row -> footprint ends on h - 1
+            got = ia.ops.remap(src, mx, my, 'lanczos4', 'constant', 0.3)
+            for f in range(n):
+                want = oracle.remap(src[f], mx, my, oracle.LANCZOS4, oracle.CONSTANT, 0.3)
+                assert np.array_equal(got[f], want), (h, w, n, f)
