@@ -47,6 +47,10 @@ def main():
         iname = str(rng.choice(list(INTERPS)))
         bname = str(rng.choice(list(BORDERS)))
         cval = float(rng.choice([0.0, 0.3, 17.0])) if dt != np.float32 else float(rng.choice([0.0, 0.3]))
+        K = int(rng.choice([3, 5, 7, 9]))          # (the fused chain's filter, see below)
+        kern = rng.random((K, K))
+        kern /= kern.sum()
+        cmode = str(rng.choice(['reflect', 'constant', 'wrap', 'mirror', 'nearest']))
         if os.environ.get('FUZZ_ONLY') and int(os.environ['FUZZ_ONLY']) != case:
             continue   # (every random draw of the case is above: the stream stays in step)
         got = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), iname, bname,
@@ -70,6 +74,29 @@ def main():
                       % (len(idx), np.nanmax(df), idx[0].tolist(), got[f][tuple(idx[0])],
                          want[tuple(idx[0])], mx[tuple(idx[0])], my[tuple(idx[0])]))
                 break
+        # the fused chain (remap -> K x K filter in one kernel) on the same case: float32 and uint16
+        # frames, every interpolation the fused entry point takes
+        if dt in (np.float32, np.uint16) and iname != 'nearest':
+            try:
+                gotf = ops.remap_conv2d(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), kern,
+                                        iname, bname, cval, cmode).get()
+            except NotImplementedError:
+                gotf = None
+            if gotf is not None:
+                for f in range(n):
+                    mid = oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval,
+                                       out_dtype=np.float32)
+                    want = oracle.conv2d(mid, kern, cmode)
+                    ok = np.isnan(gotf[f]) == np.isnan(want)
+                    d = np.abs(np.nan_to_num(gotf[f]) - np.nan_to_num(want)).max() if ok.all() else np.inf
+                    scale = max(1.0, float(np.abs(np.nan_to_num(want)).max()))
+                    worst = max(worst, float(d) / scale)
+                    if d > 1e-5 * scale:
+                        fails += 1
+                        print('MISMATCH fused case %d frame %d: %s %dx%d -> %dx%d n=%d %s %s cval %g K=%d %s: '
+                              'max |d| %g' % (case, f, np.dtype(dt).name, h, w, dh, dw, n, iname, bname, cval,
+                                              K, cmode, d))
+                        break
         if (case + 1) % 50 == 0:
             print('%d cases, %d mismatches, worst float error %.2e' % (case + 1, fails, worst), flush=True)
     print('done: %d cases, %d mismatches, worst float error %.2e' % (n_cases, fails, worst))
