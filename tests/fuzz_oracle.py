@@ -47,6 +47,7 @@ def main():
         iname = str(rng.choice(list(INTERPS)))
         bname = str(rng.choice(list(BORDERS)))
         cval = float(rng.choice([0.0, 0.3, 17.0])) if dt != np.float32 else float(rng.choice([0.0, 0.3]))
+        pp = rng.normal(0, 2e-5, 2)                # (the warp's perspective terms, see below)
         K = int(rng.choice([3, 5, 7, 9]))          # (the fused chain's filter, see below)
         kern = rng.random((K, K))
         kern /= kern.sum()
@@ -97,6 +98,27 @@ def main():
                               'max |d| %g' % (case, f, np.dtype(dt).name, h, w, dh, dw, n, iname, bname, cval,
                                               K, cmode, d))
                         break
+        # the same case as a homography warp (coordinates evaluated in the kernel - or, for batches
+        # of bicubic / Lanczos4 warps, once into stored coordinates) against the oracle's
+        M = np.array([[sc * np.cos(ang), -sc * np.sin(ang), w / 2 - sc * (np.cos(ang) * dw / 2 - np.sin(ang) * dh / 2)],
+                      [sc * np.sin(ang), sc * np.cos(ang), h / 2 - sc * (np.sin(ang) * dw / 2 + np.cos(ang) * dh / 2)],
+                      [pp[0], pp[1], 1.0]])
+        gotw = ops.warp_perspective(ctx.to_device(src), M, (dh, dw), iname, bname, cval).get()
+        for f in range(n):
+            want = oracle.warp_perspective(src[f], M, (dh, dw), INTERPS[iname], BORDERS[bname], cval)
+            if dt == np.float32:
+                ok = np.isnan(gotw[f]) == np.isnan(want)
+                d = np.abs(np.nan_to_num(gotw[f]) - np.nan_to_num(want)).max() if ok.all() else np.inf
+                bad = d > 1e-5 * max(1.0, float(np.abs(np.nan_to_num(want)).max()))
+            else:
+                bad = not np.array_equal(gotw[f], want)
+            if bad:
+                fails += 1
+                df = np.abs(gotw[f].astype(np.float64) - want.astype(np.float64))
+                print('MISMATCH warp case %d frame %d: %s %dx%d -> %dx%d n=%d %s %s cval %g: %d values, max |d| %g'
+                      % (case, f, np.dtype(dt).name, h, w, dh, dw, n, iname, bname, cval,
+                         int((df > 0).sum()), np.nanmax(df)))
+                break
         if (case + 1) % 50 == 0:
             print('%d cases, %d mismatches, worst float error %.2e' % (case + 1, fails, worst), flush=True)
     print('done: %d cases, %d mismatches, worst float error %.2e' % (n_cases, fails, worst))
