@@ -27,9 +27,11 @@ def main():
     fails = 0
     worst = 0.0
     for case in range(n_cases):
-        h, w = int(rng.integers(20, 300)), int(rng.integers(40, 700))
-        dh, dw = (h, w) if rng.random() < 0.6 else (int(rng.integers(20, 300)), int(rng.integers(40, 700)))
-        n = int(rng.integers(1, 5))
+        big = bool(os.environ.get('FUZZ_BIG'))    # frames up to 1300 x 2700, batches of 4 / 8
+        hm, wm = (1300, 2700) if big else (300, 700)
+        h, w = int(rng.integers(20, hm)), int(rng.integers(40, wm))
+        dh, dw = (h, w) if rng.random() < 0.6 else (int(rng.integers(20, hm)), int(rng.integers(40, wm)))
+        n = int(rng.choice([4, 8])) if big else int(rng.integers(1, 5))
         dt = rng.choice([np.float32, np.float32, np.uint8, np.uint16])
         a = rng.random((n, h, w))
         src = a.astype(np.float32) if dt == np.float32 else np.round(
