@@ -49,6 +49,8 @@ def main():
         iname = str(rng.choice(list(INTERPS)))
         bname = str(rng.choice(list(BORDERS)))
         cval = float(rng.choice([0.0, 0.3, 17.0])) if dt != np.float32 else float(rng.choice([0.0, 0.3]))
+        sep = rng.choice([3, 5, 7, 9, 13], 2)       # (the separable chain's taps, see below)
+        sepw = rng.random(13) + 0.1
         pp = rng.normal(0, 2e-5, 2)                # (the warp's perspective terms, see below)
         K = int(rng.choice([3, 5, 7, 9]))          # (the fused chain's filter, see below)
         kern = rng.random((K, K))
@@ -100,6 +102,28 @@ def main():
                               'max |d| %g' % (case, f, np.dtype(dt).name, h, w, dh, dw, n, iname, bname, cval,
                                               K, cmode, d))
                         break
+        # ... and the separable form (remap -> ky then kx), 3 / 5 / 7 / 9 / 13 taps per axis
+        if dt == np.float32 and iname != 'nearest':
+            ny_, nx_ = int(sep[0]), int(sep[1])
+            if ny_ < dh and nx_ < dw:
+                ky_, kx_ = sepw[:ny_] / sepw[:ny_].sum(), sepw[:nx_][::-1] / sepw[:nx_].sum()
+                try:
+                    gots = ops.remap_sepconv2d(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), ky_, kx_,
+                                               iname, bname, cval, cmode).get()
+                except NotImplementedError:
+                    gots = None
+                if gots is not None:
+                    for f in range(n):
+                        mid = oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval,
+                                           out_dtype=np.float32)
+                        want = oracle.sepconv2d(mid, ky_, kx_, cmode)
+                        ok = np.isnan(gots[f]) == np.isnan(want)
+                        d = np.abs(np.nan_to_num(gots[f]) - np.nan_to_num(want)).max() if ok.all() else np.inf
+                        if d > 1e-5 * max(1.0, float(np.abs(np.nan_to_num(want)).max())):
+                            fails += 1
+                            print('MISMATCH sep case %d frame %d: %dx%d -> %dx%d n=%d %s %s cval %g taps %d+%d %s: '
+                                  'max |d| %g' % (case, f, h, w, dh, dw, n, iname, bname, cval, ny_, nx_, cmode, d))
+                            break
         # the same case as a homography warp (coordinates evaluated in the kernel - or, for batches
         # of bicubic / Lanczos4 warps, once into stored coordinates) against the oracle's
         M = np.array([[sc * np.cos(ang), -sc * np.sin(ang), w / 2 - sc * (np.cos(ang) * dw / 2 - np.sin(ang) * dh / 2)],
