@@ -121,8 +121,13 @@ class Context(object):
         it is probed.  Returns (array, [milliseconds per candidate])."""
         held, times = [], []
         for _ in range(max(1, int(candidates))):
-            a = DeviceArray(self, shape, dtype)   # (every candidate is held until the choice is
-            if fill is not None:                  # made: a freed one would be handed out again)
+            try:
+                a = DeviceArray(self, shape, dtype)   # (every candidate is held until the choice
+            except MemoryError:                       # is made: a freed one would be handed out
+                if not held:                          # again)
+                    raise
+                break   # out of device memory: choose among what there is
+            if fill is not None:
                 fill(a)
             times.append(float(probe(a)))
             held.append(a)
