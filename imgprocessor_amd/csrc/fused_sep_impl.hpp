@@ -23,6 +23,16 @@ struct FusedSep {
 template <typename ST, int INTERP, typename Coord, int K>
 static void fused_sep_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const FusedSep& q) {
   using Src = SampleRowSrc<ST, INTERP, Coord>;
+  if (sep_shared<Src, K>::value && fused_split_tail<Src, 5>(ctx, f)) {   // (see fused_impl.hpp)
+    FusedCall head = f, tail = f;
+    head.n_frames = f.n_frames - f.n_frames % IPA_WPB;
+    tail.n_frames = IPA_WPB;
+    tail.src = f.src + (long)(f.n_frames - IPA_WPB) * f.src_frame_bytes;
+    tail.p.dst = f.p.dst + (long)(f.n_frames - IPA_WPB) * f.p.dst_frame_elems * 4;
+    fused_sep_one<ST, INTERP, Coord, K>(ctx, head, c, q);
+    fused_sep_one<ST, INTERP, Coord, K>(ctx, tail, c, q);
+    return;
+  }
   Src s;
   s.coord = c;
   s.src = f.src; s.src_frame_bytes = f.src_frame_bytes; s.src_bytes = f.src_bytes;

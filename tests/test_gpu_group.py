@@ -259,3 +259,33 @@ def test_frame_pair_kernel_matches_per_frame(ia, K, n, knob):
             finally:
                 ctx.set_tuning(**old)
             same_bits(got, ref, 'pair=%d kernel K=%d n=%d %r %r' % (knob, K, n, (h, w), kw))
+
+
+def test_batches_that_are_no_multiple_of_the_workgroup_frames(ia):
+    """n frames with n % 4 != 0: the shared-record loop runs the first n - n % 4 frames and then
+    the last 4 (up to three of them a second time) - every frame must have the bits of the
+    single-frame call, for the dense and the separable chain, float32 and uint16 frames"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(17)
+    h, w = 150, 700
+    mx, my = radial_maps(h, w)[:2]
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    k5 = rng.random((5, 5))
+    k5 /= k5.sum()
+    g = np.exp(-0.5 * np.arange(-4, 5) ** 2)
+    g /= g.sum()
+    for n in (5, 7, 9, 10, 15):
+        f32 = rng.random((n, h, w), dtype=np.float32)
+        u16 = (f32 * 4095).astype(np.uint16)
+        for src in (f32, u16):
+            d = ctx.to_device(src)
+            got = ops.remap_conv2d(d, dmx, dmy, k5).get()
+            gots = ops.remap_sepconv2d(d, dmx, dmy, g, g).get() if src.dtype == np.float32 else None
+            for f in range(n):
+                one = ctx.to_device(src[f])
+                ref = ops.remap_conv2d(one, dmx, dmy, k5).get()
+                assert np.array_equal(got[f].view(np.uint32), ref.view(np.uint32)), (n, f, src.dtype)
+                if gots is not None:
+                    refs = ops.remap_sepconv2d(one, dmx, dmy, g, g).get()
+                    assert np.array_equal(gots[f].view(np.uint32), refs.view(np.uint32)), (n, f, 'sep')
