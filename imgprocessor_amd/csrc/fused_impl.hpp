@@ -44,6 +44,18 @@ struct FusedCall {
 // instead: the first n - n % IPA_WPB frames, then the LAST IPA_WPB frames - up to three of those a
 // second time, with the same bits.  (Not when source and result may overlap: the second launch
 // would then read what the first wrote.)
+// which strip-height table a fused launch takes (wave_strip_height's `piped`): the tall strips of
+// the shared-record loop only where that loop runs - the frames of a workgroup are frames of one
+// strip (knobs frames_wg / frames_inner, n a multiple of IPA_WPB); the per-frame loop, whose rim
+// strips are on the chunked path, keeps the short ones (64 x 4K with frames_wg = 0: 1.53 ms on
+// 144-row strips)
+template <typename Src, int K> static int fused_strip_piped(const ipa_ctx* ctx, int n_frames) {
+  const bool shared_run = shared_capable<Src, K>::value && IPA_PIPE && IPA_PIPE_SHARED &&
+                          ctx->tune.frames_wg != 0 && ctx->tune.frames_inner != 0 &&
+                          n_frames % IPA_WPB == 0;
+  return shared_run ? 2 : 0;
+}
+
 template <typename Src, int K> static bool fused_split_tail(const ipa_ctx* ctx, const FusedCall& f) {
   if (!(shared_capable<Src, K>::value && IPA_PIPE && IPA_PIPE_SHARED)) return false;
   if (!ctx->tune.frames_wg || !ctx->tune.frames_inner) return false;
@@ -81,7 +93,7 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false,
-                                shared_capable<Src, K>::value && IPA_PIPE ? 2 : 0);
+                                fused_strip_piped<Src, K>(ctx, f.n_frames));
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   // frames of one strip block run together: map-based remaps share their map rows between
   // frames (L2 fetch traffic -62 % on 16 x 4K), and even without shared rows the order measured

@@ -19,7 +19,7 @@ static int ring_launch(ipa_ctx* ctx, FusedCall& f, const Coord& c) {
   // the per-frame kernel's strip height for this launch (fused_launch_one computes the same)
   using Src = SampleRowSrc<ST, kLinear, Coord>;
   gm.strip_h = wave_strip_height(ctx, gm.dh, gm.dw, f.n_frames, K, false,
-                                 shared_capable<Src, K>::value && IPA_PIPE ? 2 : 0);
+                                 fused_strip_piped<Src, K>(ctx, f.n_frames));
   const int rows = (gm.dh + gm.strip_h - 1) / gm.strip_h;
   gm.strips = gm.strips_x * rows;
   gm.pairs = gm.pairs_x * rows;

@@ -279,8 +279,10 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
     w.kx[i] = (float)kx[i];
   }
   p.strips_x = (p.dw + 247) / 248;
-  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false,
-                                sep_shared<Src, K>::value ? 2 : 0);
+  // (the tall strips of the shared-record loop only where that loop runs, see fused_strip_piped)
+  const bool shared_run = sep_shared<Src, K>::value && sep_shares_maps<Src>::value &&
+                          ctx->tune.frames_wg != 0 && ctx->tune.frames_inner != 0 && n_frames % 4 == 0;
+  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false, shared_run ? 2 : 0);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
