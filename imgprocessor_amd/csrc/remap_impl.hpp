@@ -592,7 +592,15 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   // the lens model and the homography read the coordinates the planning pass stored; the
   // homography's are doubles, 16 B per pixel and frame.  ring_remap = 2: every covered case)
   constexpr bool kHom = std::is_same<Coord, HomographyCoord>::value;
-  const bool ring_pays = !(base == IPA_INTER_LINEAR && kHom);
+  // ... and from which batch size (4K frames, ring against gather kernel, profiles/r03_micro.txt):
+  // a map pair is planned anew on every call (its contents may have changed) - ~50 us that 2
+  // bilinear frames do not earn back (79 against 30 us; level at 16) -, a source given by value
+  // only on its first call
+  constexpr bool kMapSrc = std::is_same<Coord, MapCoord>::value;
+  const int ring_from = base == IPA_INTER_LINEAR ? (kMapSrc ? 16 : 4)
+                        : base == IPA_INTER_LANCZOS4 ? (kMapSrc ? 3 : 2)
+                                                     : (kMapSrc ? 8 : 4);
+  const bool ring_pays = !(base == IPA_INTER_LINEAR && kHom) && a.n_frames >= ring_from;
   if ((ctx->tune.ring_remap > 1 || (ctx->tune.ring_remap == 1 && ring_pays)) &&
       a.n_frames >= ctx->tune.ring_min && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
       base != IPA_INTER_NEAREST) {

@@ -62,7 +62,7 @@ def main():
         u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
                             if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
     Hm = None
-    if {'c3', 'warp5', 'lz4', 'cubic'} & set(what):
+    if {'c3', 'warp5', 'lz4', 'cubic', 'warplin'} & set(what):
         from imgprocessor_amd.utils import getPerspectiveTransform
         quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
         rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
@@ -99,6 +99,11 @@ def main():
         'rot7linear': lambda: ops.warp_perspective(src, R7, (h, w), 'linear', out=dst),
         'rot7linearmap': lambda: ops.remap(src, r7x, r7y, 'linear', out=dst),
         'remap': lambda: ops.remap(src, dmx, dmy, out=dst),
+        'remapcubic': lambda: ops.remap(src, dmx, dmy, 'cubic', out=dst),
+        'remaplz4': lambda: ops.remap(src, dmx, dmy, 'lanczos4', out=dst),
+        'undist': lambda: ops.undistort(src, K, dist, K, out=dst),
+        'undistcubic': lambda: ops.undistort(src, K, dist, K, 'cubic', out=dst),
+        'warplin': lambda: ops.warp_perspective(src, Hm, (h, w), 'linear', out=dst),
         'copy': lambda: dst.copy_from(src),
     }
     n = max(10, 1600 // batch)
