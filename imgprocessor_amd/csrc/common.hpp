@@ -12,6 +12,15 @@
 
 #include "../../include/imgproc_hip.h"
 
+// Byte alignment of rows and frames that the 16-byte row loads / stores of the fast paths ask for.
+// 4: gfx950 serves a global dwordx4 at any dword address (the HSA ABI runs the memory unit in its
+// unaligned mode), so float32 images of ANY width take the fast paths - until round 3 they had to
+// be 16-byte aligned, and a width that is no multiple of 4 cost 1.4 - 1.7 x (2160 x 3838: fused
+// undistort + 5x5 550 -> 429 us, plain 5x5 370 -> 252; the rest is the last partial lane per row).
+#ifndef IPA_VEC_ALIGN
+#define IPA_VEC_ALIGN 4
+#endif
+
 // Launch-shape knobs of a context.  Defaults are the measured optima;
 // ipa_ctx_create() reads the IPA_* environment variables ONCE into this struct and
 // ipa_ctx_set_tuning() changes a field afterwards - nothing in a launch path calls getenv().

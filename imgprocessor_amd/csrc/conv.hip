@@ -337,9 +337,9 @@ extend_kernel(const T* __restrict__ src, int h, int w, long spitch, int px, int 
 using namespace ipa;
 
 static bool rows_aligned16(const void* base, long pitch, long frame, int n_frames, size_t es) {
-  if (((uintptr_t)base) & 15) return false;
-  if ((pitch * (long)es) & 15) return false;
-  if (n_frames > 1 && ((frame * (long)es) & 15)) return false;
+  if (((uintptr_t)base) & (IPA_VEC_ALIGN - 1)) return false;
+  if ((pitch * (long)es) & (IPA_VEC_ALIGN - 1)) return false;
+  if (n_frames > 1 && ((frame * (long)es) & (IPA_VEC_ALIGN - 1))) return false;
   return true;
 }
 

@@ -73,8 +73,8 @@ static int fused_fill(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dty
   p.dst_frame_elems = dst_frame_stride;
   p.dh = dh; p.dw = dw; p.dpitch = dst_pitch;
   p.cbx = cbx; p.cby = cby;
-  p.vec_out = (((uintptr_t)d_dst) % 16 == 0) && ((dst_pitch * (long)ds) % 16 == 0) &&
-              (n_frames == 1 || (dst_frame_stride * (long)ds) % 16 == 0);
+  p.vec_out = (((uintptr_t)d_dst) % IPA_VEC_ALIGN == 0) && ((dst_pitch * (long)ds) % IPA_VEC_ALIGN == 0) &&
+              (n_frames == 1 || (dst_frame_stride * (long)ds) % IPA_VEC_ALIGN == 0);
   f.src = (const char*)d_src;
   f.src_frame_bytes = src_frame_stride * (long)ss;
   f.src_bytes = (unsigned)frame_bytes;
@@ -84,8 +84,8 @@ static int fused_fill(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dty
   f.cval = border_value;
   f.conv_cval = 0.0;
   if (f.coord_kind == 0)
-    f.map_vec = (((uintptr_t)f.map.mx) % 16 == 0) && (((uintptr_t)f.map.my) % 16 == 0) &&
-                ((f.map.pitch * 4) % 16 == 0);
+    f.map_vec = (((uintptr_t)f.map.mx) % IPA_VEC_ALIGN == 0) && (((uintptr_t)f.map.my) % IPA_VEC_ALIGN == 0) &&
+                ((f.map.pitch * 4) % IPA_VEC_ALIGN == 0);
   else
     f.map_vec = 0;
   f.src_dt = src_dtype; f.dst_dt = dst_dtype; f.interp_base = base; f.n_frames = n_frames;

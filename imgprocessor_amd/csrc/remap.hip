@@ -297,7 +297,8 @@ int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dis
   UndistortCoord c;
   int rc = make_undistort_coord(ctx, K, dist5, newK, &c);
   if (rc) return rc;
-  int vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, 16) && aligned_rows(d_mapy, map_pitch, 0, 1, 4, 16);
+  int vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, IPA_VEC_ALIGN) &&
+            aligned_rows(d_mapy, map_pitch, 0, 1, 4, IPA_VEC_ALIGN);
   dim3 grid((w + 255) / 256, (h + 3) / 4), block(64, 4);
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   hipLaunchKernelGGL(build_map_kernel, grid, block, 0, ctx->stream, c, h, w, d_mapx, d_mapy,
@@ -331,7 +332,8 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
   MapCoord c{d_mapx, d_mapy, map_pitch};
-  int map_vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, 16) && aligned_rows(d_mapy, map_pitch, 0, 1, 4, 16);
+  int map_vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, IPA_VEC_ALIGN) &&
+            aligned_rows(d_mapy, map_pitch, 0, 1, 4, IPA_VEC_ALIGN);
   RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
               n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
   return ipa_remap_launch_map(ctx, a, c, map_vec);

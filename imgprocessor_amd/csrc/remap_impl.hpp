@@ -563,7 +563,8 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   p.tiles_x = (unsigned)((a.dw + 255) / 256);
   unsigned tiles_y = (unsigned)((a.dh + 3) / 4);
   p.tiles = p.tiles_x * tiles_y;
-  p.dst_vec = aligned_rows(a.dst, a.dpitch, a.dst_fs, a.n_frames, ds, 4 * ds > 16 ? 16 : 4 * ds);
+  p.dst_vec = aligned_rows(a.dst, a.dpitch, a.dst_fs, a.n_frames, ds,
+                           4 * ds > IPA_VEC_ALIGN ? (size_t)IPA_VEC_ALIGN : 4 * ds);
   p.map_vec = map_vec;
   // frame index fastest only where frames share data and the gathers are light: map-based
   // nearest / bilinear (16 x 4K: nearest 281 -> 260 us, bilinear level; bicubic level,
