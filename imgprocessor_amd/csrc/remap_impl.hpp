@@ -346,39 +346,44 @@ __global__ void __launch_bounds__(1024) remap_u8_lz_kernel(RemapParams p, Coord 
   const unsigned nf = (unsigned)p.frames_inner, t = blockIdx.x / nf, frame = blockIdx.x - t * nf;
   const unsigned tyb = t / p.tiles_x, txi = t - tyb * p.tiles_x;
   SrcView s;
-  s.rsrc = make_rsrc(p.src + (long)frame * p.src_frame_bytes, p.src_bytes);
+  const char* fbase = p.src + (long)frame * p.src_frame_bytes;
+  const unsigned mis = (unsigned)(uintptr_t)fbase & 3u;   // odd h x w: every other frame
+  s.rsrc = make_rsrc(fbase - mis, p.src_bytes + mis);
+  s.org = (int)mis;
   s.h = p.sh; s.w = p.sw; s.pitch = p.spitch;
   s.border = p.border; s.q5 = 1; s.cubic_a = p.cubic_a; s.lanczos = nullptr;
   const double rv = rint(p.cval);
   const uint8_t cv8 = (uint8_t)(rv > 0 ? (rv < 255 ? rv : 255) : 0);
   const int xw = (int)(txi * 256u);
-  const bool whole = xw + 256 <= p.dw && p.dst_vec;
+  // rows that are not dword aligned (an odd width) and the last, partial strip of a row keep the
+  // lane-interleaved sampling and store bytes (16 x 2160 x 3838: 1423 -> 937 us with the tap
+  // dwords aligned in memory, sampler.hpp; profiles/r03_micro.txt)
+  const bool whole = xw + 256 <= p.dw;
   uint8_t* dst = reinterpret_cast<uint8_t*>(p.dst) + (long)frame * p.dst_frame_elems;
   for (unsigned it = 0; it < p.tile_rows; it++) {
     const int y = (int)((tyb * p.tile_rows + it) * 16u + wave);
     if (y >= p.dh) return;
-    if (whole) {
 #pragma unroll 1
-      for (int k = 0; k < 4; k++) {  // one sample at a time: 16 tap dwords + 32 weight dwords live
+    for (int k = 0; k < 4; k++) {  // one sample at a time: 16 tap dwords + 32 weight dwords live
+      const int x = xw + (int)lane + 64 * k;
+      if (whole || x < p.dw) {     // (the last strip of a row samples the same way, lanes past it idle)
         typename Coord::coord_t sx, sy;
-        coord.get(xw + (int)lane + 64 * k, y, sx, sy);
+        coord.get(x, y, sx, sy);
         xrow[wave][64u * k + lane] = sample_u8_lanczos_lds(s, tab, sx, sy, cv8);
       }
-      __builtin_amdgcn_wave_barrier();
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (whole && p.dst_vec) {
       const unsigned q = *reinterpret_cast<const unsigned*>(&xrow[wave][4u * lane]);
       *reinterpret_cast<unsigned*>(dst + (long)y * p.dpitch + xw + 4u * lane) = q;
-      __builtin_amdgcn_wave_barrier();
     } else {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int x = xw + 4 * (int)lane + k;
-        if (x < p.dw) {
-          typename Coord::coord_t sx, sy;
-          coord.get(x, y, sx, sy);
-          dst[(long)y * p.dpitch + x] = sample_u8_lanczos_lds(s, tab, sx, sy, cv8);
-        }
+      for (int k = 0; k < 4; k++) {   // (lane-interleaved: 64 consecutive bytes per store)
+        const int x = xw + 64 * k + (int)lane;
+        if (x < p.dw) dst[(long)y * p.dpitch + x] = xrow[wave][64u * k + lane];
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 

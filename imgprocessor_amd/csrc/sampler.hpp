@@ -40,6 +40,9 @@ struct SrcView {
   // dword gathers - which cost by the cache lines the wave touches - instead of one dwordx2
   // (16 clocks whatever its addresses).  0: one lane = 4 consecutive pixels, the dwordx2 wins.
   int pair_split = 0;
+  // byte offset of pixel (0, 0) from the descriptor's base (sample_u8_lanczos_lds only): the
+  // descriptor starts on the dword below a frame that does not start on one
+  int org = 0;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
@@ -784,16 +787,21 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
   // frame that is past the frame's buffer descriptor, which answers the whole dword with 0 -
   // such footprints take the byte path.  Found by tests/fuzz_oracle.py: one pixel in the
   // bottom-right corner off by one level.)
-  const bool tail_ok = iy0 + 8 < s.h || (ix0 & ~3) + 12 <= s.w;
+  const int e7 = s.org + (iy0 + 7) * s.pitch + ix0;   // first tap of the last tap row
+  const bool tail_ok = iy0 + 8 < s.h || (e7 & ~3) + 12 <= s.org + (s.h - 1) * s.pitch + s.w;
   if (ix0 >= 0 && iy0 >= 0 && ix0 + 8 <= s.w && iy0 + 8 <= s.h && tail_ok) {
     // three ALIGNED dwords per tap row (two dwords at the sample's odd byte offset cost the
     // texture addresser a third more); one v_perm_b32 per tap pair picks bytes sh + 2j, sh + 2j + 1
-    // out of two of them and widens them to 16 bits
-    const unsigned sh = (unsigned)ix0 & 3u;
-    const unsigned sel01 = 0x0c010c00u + sh * 0x00010001u, sel23 = sel01 + 0x00020002u;
+    // out of two of them and widens them to 16 bits.  Aligned in MEMORY, row by row: a pitch that
+    // is no multiple of 4 (an odd width) shifts every row differently (16 x 2160 x 3838: 1318 us
+    // with the dwords aligned to the row's start only, 937 in memory; 919 at width 3840), and an
+    // odd frame size every other frame (s.org; 16 x 1079 x 1919: 449 -> 259 us)
 #pragma unroll
     for (int r = 0; r < 8; r++) {
-      const int a = (iy0 + r) * s.pitch + (ix0 & ~3);
+      const int e = s.org + (iy0 + r) * s.pitch + ix0;
+      const int a = e & ~3;
+      const unsigned sh = (unsigned)e & 3u;
+      const unsigned sel01 = 0x0c010c00u + sh * 0x00010001u, sel23 = sel01 + 0x00020002u;
       const unsigned d0 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a, 0, 0);
       const unsigned d1 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 4, 0, 0);
       const unsigned d2 = __builtin_amdgcn_raw_buffer_load_b32(s.rsrc, a + 8, 0, 0);
@@ -814,7 +822,7 @@ __device__ __forceinline__ uint8_t sample_u8_lanczos_lds(const SrcView& s, const
           const int xx = resolve_idx(ix0 + 4 * q + c, s.w, s.border);
           const unsigned b = (yy < 0 || xx < 0) ? (unsigned)cv8
                                                 : (unsigned)__builtin_amdgcn_raw_buffer_load_b8(
-                                                      s.rsrc, yy * s.pitch + xx, 0, 0) & 0xffu;
+                                                      s.rsrc, s.org + yy * s.pitch + xx, 0, 0) & 0xffu;
           t |= b << (8 * c);
         }
         pr[r][2 * q] = (t & 0xffu) | ((t & 0xff00u) << 8);
