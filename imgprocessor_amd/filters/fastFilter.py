@@ -28,11 +28,18 @@ def fastFilter(arr, ksize=30, every=None, resize=True, fn='median', interpolatio
         every = max(ksize // 3, 1)
     else:
         assert ksize >= 3 * every
-    arr = np.asarray(arr)
+    dev = ops._is_dev(arr)   # device-resident array: statistics and enlargement stay on the device
+    if not dev:
+        arr = np.asarray(arr)
     s0, s1 = arr.shape[:2]
     ss0 = s0 // every
     every = s0 // ss0
     grid = ops.fast_filter_stat(arr, ksize, every, fn, ctx=ctx)
+    if dev:
+        if resize and not smoothksize:
+            return ops.resize(grid, (s0, s1), interpolation, ctx=ctx,
+                              src_shape=(grid.shape[0] - 1, grid.shape[1] - 1))
+        grid = grid.get()
     out = np.ascontiguousarray(grid[:grid.shape[0] - 1, :grid.shape[1] - 1])
     if smoothksize:
         out = ops.gaussian_filter(out, smoothksize, ctx=ctx)

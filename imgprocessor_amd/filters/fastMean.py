@@ -13,6 +13,10 @@ from .. import ops
 
 
 def fastMean(img, f=10, inplace=False, ctx=None):
+    if ops._is_dev(img):   # device-resident image (float32 / float64): stays on the device
+        s0, s1 = img.shape
+        small = ops.resize(img, (int(round(s0 / f)), int(round(s1 / f))), 'area', ctx=ctx)
+        return ops.resize(small, (s0, s1), 'linear', out=img if inplace else None, ctx=ctx)
     src = np.asarray(img)
     s0, s1 = src.shape[:2]
     ss0 = int(round(s0 / f))

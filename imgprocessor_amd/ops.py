@@ -789,9 +789,10 @@ RESIZE_INTERP = {'linear': 1, 'cubic': 2, 'area': 3, 'lanczos4': 4, 1: 1, 2: 2, 
 FAST_FILTER_FN = {'median': 0, 'nanmedian': 1, 'mean': 2, 'nanmean': 3}
 
 
-def resize(img, dsize_hw, interpolation='linear', out=None, ctx=None):
+def resize(img, dsize_hw, interpolation='linear', out=None, ctx=None, src_shape=None):
     """cv2.resize(img, (w, h), interpolation=...) for 2-D float32 / float64 images;
-    dsize_hw = (rows, columns) of the result"""
+    dsize_hw = (rows, columns) of the result.  ``src_shape`` (device arrays): resize only the
+    top-left (rows, columns) of ``img`` - fastFilter's cropped grid, without a copy"""
     interp = RESIZE_INTERP[interpolation]
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
     if _is_dev(img):
@@ -799,10 +800,17 @@ def resize(img, dsize_hw, interpolation='linear', out=None, ctx=None):
         if img.ndim != 2:
             raise ValueError('resize takes one 2-D image')
         sh, sw = img.shape
+        pitch = sw
+        if src_shape is not None:
+            if not (0 < int(src_shape[0]) <= sh and 0 < int(src_shape[1]) <= sw):
+                raise ValueError('src_shape %r outside the %r array' % (tuple(src_shape), img.shape))
+            sh, sw = int(src_shape[0]), int(src_shape[1])
         dst = _dev_out(ctx, out, (dh, dw), img.dtype)
-        ctx._check(ctx._lib.ipa_resize_dev(ctx.handle, img.ptr, dtype_id(img.dtype), sh, sw, sw,
+        ctx._check(ctx._lib.ipa_resize_dev(ctx.handle, img.ptr, dtype_id(img.dtype), sh, sw, pitch,
                                            dst.ptr, dh, dw, dw, interp), 'resize')
         return dst
+    if src_shape is not None:
+        img = np.asarray(img)[:int(src_shape[0]), :int(src_shape[1])]
     ctx = ctx or default_context()
     img = _float_img(img)
     if img.ndim != 2:

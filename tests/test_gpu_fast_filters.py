@@ -130,6 +130,23 @@ def test_fast_filter_and_fast_mean_end_to_end(ia, oracle):
     d = ctx.to_device(a.astype(np.float32))
     r = ia.ops.resize(d, (24, 34), 'area')
     assert np.array_equal(r.get(), oracle.resize(a.astype(np.float32), (24, 34), oracle.RESIZE_AREA))
+    # ... through fastMean and fastFilter too (same bits as from host arrays)
+    a32 = a.astype(np.float32)
+    m = fastMean(d, 10)
+    assert isinstance(m, ia.DeviceArray) and np.array_equal(m.get(), oracle.fastMean(a32, 10))
+    d2 = ctx.to_device(a32)
+    assert fastMean(d2, 7.3, inplace=True) is d2 and np.array_equal(d2.get(), oracle.fastMean(a32, 7.3))
+    src = np.nan_to_num(img, nan=50.0)
+    for kw in (dict(ksize=30), dict(ksize=12, every=4, fn='mean', interpolation=1),
+               dict(ksize=20, every=5, fn='median', smoothksize=1), dict(ksize=30, resize=False)):
+        got = fastFilter(ctx.to_device(src), **kw)
+        host = fastFilter(src, **kw)
+        if kw.get('smoothksize') or not kw.get('resize', True):
+            assert isinstance(got, np.ndarray)      # the small grid comes back to the host
+        else:
+            assert isinstance(got, ia.DeviceArray)
+            got = got.get()
+        assert got.dtype == np.float64 and np.array_equal(got, host), kw
 
 
 def test_resize_vs_second_restatement(ia):
