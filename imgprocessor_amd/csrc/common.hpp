@@ -64,6 +64,11 @@ struct ipa_ctx {
   // small device scratch for per-call tables (IDW weights, Lanczos table, ...)
   void* tab = nullptr;
   size_t tab_bytes = 0;
+  size_t tab_valid = 0;        // bytes of the last upload (the same table again is not re-sent)
+  unsigned long tab_serial = 0;   // counts uploads: a caller's tables are still there while it stands
+  long resize_key[5] = {0, 0, 0, 0, 0};   // sw, dw, sh, dh, interp of the resize tables in `tab`
+  unsigned long resize_serial = 0;
+  int resize_xmax = 0;
   void* tab_pinned = nullptr;  // pinned staging so the H2D is truly stream-ordered
   // per-call strip plans of the ring kernels (device only, stream-ordered reuse)
   void* plan = nullptr;

@@ -74,6 +74,29 @@ vresize_kernel(const T* __restrict__ tmp, int sh, int dw, T* __restrict__ dst, l
   dst[(long)dy * dpitch + dx] = v;
 }
 
+// four result pixels per lane (rows of the intermediate and of the result 4-element aligned):
+// the same per-element arithmetic on vector loads / stores
+template <typename T, int KS>
+__global__ void __launch_bounds__(256)
+vresize4_kernel(const T* __restrict__ tmp, int sh, int dw, T* __restrict__ dst, long dpitch,
+                const int* __restrict__ yofs, const float* __restrict__ beta) {
+  IPA_NO_FMA
+  typedef T V __attribute__((ext_vector_type(4)));
+  const int dx = (blockIdx.x * 256 + threadIdx.x) * 4, dy = blockIdx.y;
+  if (dx >= dw) return;
+  const float* b = beta + (long)dy * KS;
+  const int sy0 = yofs[dy];
+  V v = 0;
+#pragma unroll
+  for (int k = 0; k < KS; k++) {
+    int sy = sy0 - KS / 2 + 1 + k;
+    sy = sy >= 0 ? (sy < sh ? sy : sh - 1) : 0;
+    const V t = *reinterpret_cast<const V*>(tmp + (long)sy * dw + dx) * (T)b[k];
+    v = k == 0 ? t : v + t;
+  }
+  *reinterpret_cast<V*>(dst + (long)dy * dpitch + dx) = v;
+}
+
 // ------------------------------------------------------------- INTER_AREA --
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -296,11 +319,18 @@ static void launch_separable(ipa_ctx* ctx, int ks, const T* src, long spitch, in
                              T* dst, long dpitch, int dh, int dw, const int* xofs,
                              const float* alpha, int xmax, const int* yofs, const float* beta) {
   dim3 block(256), gh((unsigned)((dw + 255) / 256), (unsigned)sh), gv((unsigned)((dw + 255) / 256), (unsigned)dh);
+  dim3 gv4((unsigned)((dw / 4 + 255) / 256), (unsigned)dh);
+  const bool vec4 = dw % 4 == 0 && dpitch % 4 == 0 && (uintptr_t)dst % (4 * sizeof(T)) == 0 &&
+                    (uintptr_t)tmp % (4 * sizeof(T)) == 0;
 #define IPA_RS(KS)                                                                                 \
   hipLaunchKernelGGL((hresize_kernel<T, KS>), gh, block, 0, ctx->stream, src, spitch, sh, sw, tmp,  \
                      dw, xofs, alpha, xmax);                                                        \
-  hipLaunchKernelGGL((vresize_kernel<T, KS>), gv, block, 0, ctx->stream, (const T*)tmp, sh, dw, dst, \
-                     dpitch, yofs, beta)
+  if (vec4)                                                                                        \
+    hipLaunchKernelGGL((vresize4_kernel<T, KS>), gv4, block, 0, ctx->stream, (const T*)tmp, sh, dw,  \
+                       dst, dpitch, yofs, beta);                                                    \
+  else                                                                                             \
+    hipLaunchKernelGGL((vresize_kernel<T, KS>), gv, block, 0, ctx->stream, (const T*)tmp, sh, dw,   \
+                       dst, dpitch, yofs, beta)
   if (ks == 2) { IPA_RS(2); } else if (ks == 4) { IPA_RS(4); } else { IPA_RS(8); }
 #undef IPA_RS
 }
@@ -374,21 +404,35 @@ int ipa_resize_dev(ipa_ctx* ctx, const void* d_src, int dtype, int sh, int sw, l
     IPA_UNSUPPORTED(ctx, "resize: interpolation %d (INTER_LINEAR 1, INTER_CUBIC 2, INTER_AREA 3, "
                          "INTER_LANCZOS4 4 are built)", interp);
   const int ks = interp == IPA_RESIZE_LINEAR ? 2 : (interp == IPA_RESIZE_CUBIC ? 4 : 8);
-  std::vector<int> xofs, yofs;
-  std::vector<float> alpha, beta;
+  // the tables of the last resize are still on the device (a sequence of frames of one shape:
+  // building OpenCV's Lanczos4 coefficients for an 8K result costs the host ~0.2 ms)
+  const long key[5] = {sw, dw, sh, dh, interp};
+  const size_t b0 = up((size_t)dw * 4), b1 = up((size_t)dw * ks * 4), b2 = up((size_t)dh * 4),
+               b3 = up((size_t)dh * ks * 4);
   int xmax = dw;
-  axis_tables(sw, dw, scale_x, interp, ks, true, xofs, alpha, &xmax);
-  axis_tables(sh, dh, scale_y, interp, ks, false, yofs, beta, nullptr);
-  const size_t b0 = up(xofs.size() * 4), b1 = up(alpha.size() * 4), b2 = up(yofs.size() * 4),
-               b3 = up(beta.size() * 4);
-  std::vector<char> blob(b0 + b1 + b2 + b3);
-  memcpy(blob.data(), xofs.data(), xofs.size() * 4);
-  memcpy(blob.data() + b0, alpha.data(), alpha.size() * 4);
-  memcpy(blob.data() + b0 + b1, yofs.data(), yofs.size() * 4);
-  memcpy(blob.data() + b0 + b1 + b2, beta.data(), beta.size() * 4);
   void* d = nullptr;
-  int rc = ipa_tab_upload(ctx, blob.data(), blob.size(), &d);
-  if (rc) return rc;
+  int rc = 0;
+  if (ctx->tab && ctx->resize_serial == ctx->tab_serial && ctx->resize_serial &&
+      memcmp(key, ctx->resize_key, sizeof key) == 0) {
+    d = ctx->tab;
+    xmax = ctx->resize_xmax;
+  } else {
+    std::vector<int> xofs, yofs;
+    std::vector<float> alpha, beta;
+    axis_tables(sw, dw, scale_x, interp, ks, true, xofs, alpha, &xmax);
+    axis_tables(sh, dh, scale_y, interp, ks, false, yofs, beta, nullptr);
+    std::vector<char> blob(b0 + b1 + b2 + b3);
+    memcpy(blob.data(), xofs.data(), xofs.size() * 4);
+    memcpy(blob.data() + b0, alpha.data(), alpha.size() * 4);
+    memcpy(blob.data() + b0 + b1, yofs.data(), yofs.size() * 4);
+    memcpy(blob.data() + b0 + b1 + b2, beta.data(), beta.size() * 4);
+    ctx->resize_serial = 0;
+    rc = ipa_tab_upload(ctx, blob.data(), blob.size(), &d);
+    if (rc) return rc;
+    memcpy(ctx->resize_key, key, sizeof key);
+    ctx->resize_serial = ctx->tab_serial;
+    ctx->resize_xmax = xmax;
+  }
   rc = ipa_plan_reserve(ctx, (size_t)sh * dw * es);   // the horizontally resized rows
   if (rc) return rc;
   const char* t = (const char*)d;

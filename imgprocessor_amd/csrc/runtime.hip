@@ -351,6 +351,13 @@ int ipa_plan_reserve(ipa_ctx* c, size_t bytes) {
 // secondary entry points (IDW, Lanczos), never by the per-frame hot loop.
 int ipa_tab_upload(ipa_ctx* c, const void* host, size_t bytes, void** d) {
   IPA_HIP(c, hipSetDevice(c->device));
+  // the same table as last time (resizes of one shape over the frames of a sequence): nothing to
+  // send, and no host synchronisation between the calls
+  if (c->tab && bytes && c->tab_valid == bytes && memcmp(c->tab_pinned, host, bytes) == 0) {
+    *d = c->tab;
+    return IPA_OK;
+  }
+  c->tab_valid = 0;
   if (c->tab_bytes < bytes) {
     IPA_HIP(c, hipStreamSynchronize(c->stream));
     if (c->tab) IPA_HIP(c, hipFree(c->tab));
@@ -366,6 +373,8 @@ int ipa_tab_upload(ipa_ctx* c, const void* host, size_t bytes, void** d) {
   IPA_HIP(c, hipStreamSynchronize(c->stream));
   memcpy(c->tab_pinned, host, bytes);
   IPA_HIP(c, hipMemcpyAsync(c->tab, c->tab_pinned, bytes, hipMemcpyHostToDevice, c->stream));
+  c->tab_valid = bytes;
+  c->tab_serial++;
   *d = c->tab;
   return IPA_OK;
 }

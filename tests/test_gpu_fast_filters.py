@@ -162,3 +162,29 @@ def test_resize_vs_second_restatement(ia):
             assert np.array_equal(got, g[key]), key
         n += 1
     assert n == 34
+
+
+def test_resize_tables_kept_between_calls(ia, oracle):
+    """the coefficient tables of the last resize stay on the device for the next call of the same
+    shape; other shapes, interpolations and other uploads in between must not be served stale
+    tables"""
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(12)
+    a = rng.random((90, 131)).astype(np.float32)
+    b = rng.random((90, 131)).astype(np.float32)
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    o = oracle
+    seq = ((da, a, (200, 300), 'lanczos4', o.RESIZE_LANCZOS4), (db, b, (200, 300), 'lanczos4', o.RESIZE_LANCZOS4),
+           (da, a, (200, 300), 'cubic', o.RESIZE_CUBIC), (da, a, (200, 301), 'cubic', o.RESIZE_CUBIC),
+           (db, b, (200, 300), 'cubic', o.RESIZE_CUBIC), (da, a, (40, 57), 'area', o.RESIZE_AREA),
+           (db, b, (200, 300), 'cubic', o.RESIZE_CUBIC), (db, b, (200, 300), 'cubic', o.RESIZE_CUBIC),
+           (da, a, (30, 131), 'area', o.RESIZE_AREA), (da, a, (200, 300), 'linear', o.RESIZE_LINEAR),
+           (db, b, (200, 300), 'linear', o.RESIZE_LINEAR))
+    for i, (d, h, dsz, name, oi) in enumerate(seq):
+        got = ia.ops.resize(d, dsz, name).get()
+        assert np.array_equal(got, o.resize(h, dsz, oi), equal_nan=True), (i, dsz, name)
+        if i == 6:   # another user of the table buffer in between
+            src8 = (rng.random((64, 80)) * 255).astype(np.uint8)
+            yy, xx = np.mgrid[0:64, 0:80].astype(np.float32)
+            r = ia.ops.remap(src8, xx * 0.9 + 1.3, yy * 0.9 + 0.7, 'lanczos4')
+            assert np.array_equal(r, o.remap(src8, xx * 0.9 + 1.3, yy * 0.9 + 0.7, o.LANCZOS4, o.CONSTANT, 0.0))
