@@ -1,7 +1,7 @@
 """Round-3 additions (interpolate/ fills, fastFilter / fastMean, cv2.resize) timed on device-resident
 arrays next to the CPU oracle on the same input.  GPU box only; the oracle is the checker here.
 
-    python tools/bench_more.py
+    python tools/bench_more.py [--no-cpu]
 """
 import os
 import sys
@@ -32,7 +32,12 @@ def gpu_us(fn, n=20, warm=3):
     return e0.elapsed_ms(e1) / n * 1e3
 
 
+NO_CPU = '--no-cpu' in sys.argv   # (profiling passes: kernels only)
+
+
 def cpu_ms(fn):
+    if NO_CPU:
+        return float('nan'), None
     t = time.perf_counter()
     r = fn()
     return (time.perf_counter() - t) * 1e3, r
@@ -44,6 +49,8 @@ def line(name, us, cms, nbytes, ok):
 
 
 def close(a, b, tol):
+    if b is None:
+        return True
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     if not np.array_equal(np.isnan(a), np.isnan(b)):
         return False
@@ -102,7 +109,7 @@ for (name, oi, dsz) in (('linear', oracle.RESIZE_LINEAR, (1080, 1920)), ('linear
     us = gpu_us(lambda: ops.resize(dimg, dsz, name, out=out))
     cms, want = cpu_ms(lambda: oracle.resize(img, dsz, oi))
     line('resize 4K f32 -> %dx%d %s' % (dsz[0], dsz[1], name), us, cms, (h * w + dsz[0] * dsz[1]) * 4,
-         np.array_equal(out.get(), want, equal_nan=True))
+         NO_CPU or np.array_equal(out.get(), want, equal_nan=True))
 
 # fastFilter window statistics (the reference's defaults: ksize 30, every = ksize // 3 ... ) and fastMean
 for (fn, ks, ev) in (('median', 30, 10), ('mean', 30, 10), ('median', 60, 20), ('nanmedian', 30, 10)):
@@ -125,4 +132,4 @@ us = gpu_us(lambda: fastMean(dimg, 10, ctx=ctx), n=10)
 got = fastMean(dimg, 10, ctx=ctx)
 got = got.get()
 cms, want = cpu_ms(lambda: oracle.fastMean(img, 10))
-line('fastMean 4K f32 f=10 (area down + linear up)', us, cms, h * w * 8, np.array_equal(got, want))
+line('fastMean 4K f32 f=10 (area down + linear up)', us, cms, h * w * 8, NO_CPU or np.array_equal(got, want))
