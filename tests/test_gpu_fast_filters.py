@@ -188,3 +188,11 @@ def test_resize_tables_kept_between_calls(ia, oracle):
             yy, xx = np.mgrid[0:64, 0:80].astype(np.float32)
             r = ia.ops.remap(src8, xx * 0.9 + 1.3, yy * 0.9 + 0.7, 'lanczos4')
             assert np.array_equal(r, o.remap(src8, xx * 0.9 + 1.3, yy * 0.9 + 0.7, o.LANCZOS4, o.CONSTANT, 0.0))
+    # the top-left part of an array through its pitch (fastFilter's cropped grid)
+    g = rng.random((20, 30))
+    want = o.resize(np.ascontiguousarray(g[:19, :29]), (60, 90), o.RESIZE_LANCZOS4)
+    got = ia.ops.resize(ctx.to_device(g), (60, 90), 'lanczos4', src_shape=(19, 29))
+    assert np.array_equal(got.get(), want, equal_nan=True)
+    assert np.array_equal(ia.ops.resize(g, (60, 90), 'lanczos4', src_shape=(19, 29)), want, equal_nan=True)
+    with pytest.raises(ValueError):
+        ia.ops.resize(ctx.to_device(g), (60, 90), 'linear', src_shape=(21, 30))
