@@ -115,6 +115,13 @@ circular_idw_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int 
 }
 
 // ---------------------------------------------------------------- cross average --
+// pixels of a row one wave looks after: the wave works through ITS masked pixels one after the
+// other, so a hole costs the launch the time of the wave with the most hole pixels (4K with a
+// 200 x 400 hole + 2 % scattered, kernel 5: 64 per wave 906 us, 16 per wave 852)
+#ifndef IPA_CROSS_SEG
+#define IPA_CROSS_SEG 16
+#endif
+constexpr int kCrossSeg = IPA_CROSS_SEG;
 // Pass 1: _localAvg (:21-44) at every unmasked pixel that can be the end of a search - one with
 // a masked 4-neighbour - stored in the grid's dtype (the reference's `vals` array).
 template <typename T>
@@ -126,10 +133,10 @@ cross_local_avg_kernel(const T* __restrict__ grid, const uint8_t* __restrict__ m
   const long seg = (long)blockIdx.x * 4 + wave;
   const int row = (int)(seg / segs_x);
   if (row >= h) return;
-  const int xs = (int)(seg - (long)row * segs_x) * 64;
+  const int xs = (int)(seg - (long)row * segs_x) * kCrossSeg;
   const int x = xs + lane;
   bool flag = false;
-  if (x < w && mask[(long)row * w + x] == 0) {
+  if (lane < kCrossSeg && x < w && mask[(long)row * w + x] == 0) {
     flag = (row > 0 && mask[(long)(row - 1) * w + x]) || (row < h - 1 && mask[(long)(row + 1) * w + x]) ||
            (x > 0 && mask[(long)row * w + x - 1]) || (x < w - 1 && mask[(long)row * w + x + 1]);
   }
@@ -144,10 +151,34 @@ cross_local_avg_kernel(const T* __restrict__ grid, const uint8_t* __restrict__ m
     const int ymn = j - ksize < 0 ? 0 : j - ksize, ymx = j + ksize > w - 1 ? w - 1 : j + ksize;
     const int ny = ymx - ymn + 1, nt = (xmx - xmn + 1) * ny;
     double sv = 0.0, sn = 0.0;
-    for (int t = lane; t < nt; t += 64) {
-      const int a = t / ny, xi = xmn + a, yi = ymn + (t - a * ny);
-      if (mask[(long)xi * w + yi] == 0) {
-        sv += (double)grid[(long)xi * pitch + yi];
+    // t / ny by a multiplication while t * ny < 2^20 (exact there: M = ceil(2^20 / ny) errs by
+    // less than one part in 2^20 / ny) - the integer division was a third of the loop
+    const bool fastdiv = (long)nt * ny < (1l << 20);
+    const unsigned M = ((1u << 20) + (unsigned)ny - 1u) / (unsigned)ny;
+    // two positions per pass, mask and value loaded side by side (the value of a masked
+    // position is dropped): one memory round trip per 128 positions instead of two per 64 - the
+    // loop waits for its loads and nothing else.  Per-lane order of the sums unchanged.
+    auto at = [&](int t, long& mi, long& gi) {
+      const int a = fastdiv ? (int)(((unsigned long long)(unsigned)t * M) >> 20) : t / ny;
+      const int xi = xmn + a, yi = ymn + (t - a * ny);
+      mi = (long)xi * w + yi;
+      gi = (long)xi * pitch + yi;
+    };
+    for (int t = lane; t < nt; t += 128) {
+      long m0i, g0i, m1i = 0, g1i = 0;
+      at(t, m0i, g0i);
+      const bool two = t + 64 < nt;
+      if (two) at(t + 64, m1i, g1i);
+      const uint8_t m0 = mask[m0i];
+      const T g0 = grid[g0i];
+      const uint8_t m1 = two ? mask[m1i] : (uint8_t)1;
+      const T g1 = two ? grid[g1i] : (T)0;
+      if (m0 == 0) {
+        sv += (double)g0;
+        sn += 1.0;
+      }
+      if (m1 == 0) {
+        sv += (double)g1;
         sn += 1.0;
       }
     }
@@ -224,17 +255,30 @@ cross_fill_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int h,
   const long seg = (long)blockIdx.x * 4 + wave;
   const int row = (int)(seg / segs_x);
   if (row >= h) return;
-  const int xs = (int)(seg - (long)row * segs_x) * 64;
+  const int xs = (int)(seg - (long)row * segs_x) * kCrossSeg;
   const int x = xs + lane;
-  unsigned long long todo = __ballot(x < w && mask[(long)row * w + x] != 0);
+  unsigned long long todo = __ballot(lane < kCrossSeg && x < w && mask[(long)row * w + x] != 0);
   while (todo) {
     const int b = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
     const int j = xs + b;
-    const int d0 = cross_search(mask, w, row, j, -1, 0, row, lane);
-    const int d1 = cross_search(mask, w, row, j, 1, 0, h - 1 - row, lane);
-    int d2 = cross_search(mask, w, row, j, 0, -1, j, lane);
-    const int d3 = row < w - 1 ? cross_search(mask, w, row, j, 0, 1, w - 1 - j, lane) : 0;
+    // the first 8 steps of all four searches in ONE load (lanes 8 d .. 8 d + 7 = direction d): an
+    // isolated masked pixel ends every search there - one memory round trip instead of four
+    // (4K, 2 % scattered + a 200 x 400 hole, kernel 5: 615 -> 566 us for the whole fill)
+    const int c0 = row, c1 = h - 1 - row, c2n = j, c3 = row < w - 1 ? w - 1 - j : 0;
+    const int dir = lane >> 3, t = (lane & 7) + 1;
+    const int cnt = dir == 0 ? c0 : (dir == 1 ? c1 : (dir == 2 ? c2n : c3));
+    const int pr = row + (dir == 0 ? -t : (dir == 1 ? t : 0)), pc = j + (dir == 2 ? -t : (dir == 3 ? t : 0));
+    const unsigned long long hit8 = __ballot(lane < 32 && t <= cnt && mask[(long)pr * w + pc] == 0);
+    auto near = [&](int d, int count, int dr, int dc) {
+      const unsigned hd = (unsigned)(hit8 >> (8 * d)) & 0xffu;
+      if (hd) return (int)__ffs((int)hd);
+      return count > 8 ? cross_search(mask, w, row, j, dr, dc, count, lane) : 0;
+    };
+    const int d0 = near(0, c0, -1, 0);
+    const int d1 = near(1, c1, 1, 0);
+    int d2 = near(2, c2n, 0, -1);
+    const int d3 = near(3, c3, 0, 1);
     int r2 = row, c2 = j - d2;
     bool v2 = d2 > 0;
     if (!v2 && d1 > 0) {  // the stale slot
@@ -258,7 +302,9 @@ cross_fill_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int h,
 #pragma unroll
       for (int s = 0; s < 3; s++) {
         const double dd = (double)(unsigned short)dist[s];
-        wt[s] = ok[s] ? (float)(1.0 / pow(dd, half_power)) : 0.f;
+        // (power 2: pow(d, 1.0) is d itself, exactly - and the library call is most of what
+        // lane 0 does for a pixel)
+        wt[s] = ok[s] ? (float)(1.0 / (half_power == 1.0 ? dd : pow(dd, half_power))) : 0.f;
         if (ok[s]) wsumf += wt[s];
       }
       if constexpr (sizeof(T) == 4) {
@@ -357,7 +403,7 @@ int ipa_cross_avg_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t*
   char* avg = (char*)ctx->plan;
   int* rowlast = (int*)(avg + avg_b);
   int* prev = (int*)(avg + avg_b + row_b);
-  const int segs_x = (w + 63) / 64;
+  const int segs_x = (w + kCrossSeg - 1) / kCrossSeg;
   const long segs = (long)segs_x * h;
   dim3 grid((unsigned)((segs + 3) / 4)), block(256);
   hipLaunchKernelGGL(cross_row_last_kernel, dim3((unsigned)((h + 3) / 4)), block, 0, ctx->stream,
