@@ -111,8 +111,11 @@ circular_idw_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int 
     for (int t = lane; t < nx * ny; t += 64) {
       const int a = fastdiv ? (int)(((unsigned long long)(unsigned)t * M) >> 20) : t / ny;
       const int xi = xmn + a, yi = ymn + (t - a * ny);
-      if ((xi != row || yi != j) && mask[(long)xi * w + yi] == 0) {
-        const double2 rp = polar[(long)xi * g + yi];
+      // (mask, table entry and value loaded side by side: one round trip per pass)
+      const uint8_t mk = mask[(long)xi * w + yi];
+      const double2 rp = polar[(long)xi * g + yi];
+      const T gv = grid[(long)xi * pitch + yi];
+      if ((xi != row || yi != j) && mk == 0) {
         const double nR = rp.x;
         const double dr = R - nR, midR = 0.5 * (R + nR);
         const double d = fabs(PHI - rp.y), e = kTwoPi - d;
@@ -121,7 +124,7 @@ circular_idw_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int 
         const double s = p * p + q * q;
         const double wi = inv_dist_pow<PW>(s * s, half_power);
         sw += wi;
-        sv += wi * (double)grid[(long)xi * pitch + yi];
+        sv += wi * (double)gv;
       }
     }
     sw = wsum(sw);
