@@ -46,6 +46,9 @@ struct ipa_tuning {
   int ring_big = 0;       // batches, 7x7..11x11 after a remap in one kernel with the taps in LDS (1: bicubic, 2: all; measured slower)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
+  int lring = 0;          // batches of float32 frames, bilinear remap -> 3x3 / 5x5: clean strips take their
+                          // source rows through an LDS ring filled by LDS-DMA (wave_lring.hpp); 0: gather loop
+  int lring_min = 8;      // ... from this many frames on
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates
                           // are evaluated ONCE into the plan buffer and the gather kernel reads them (0: never)
@@ -92,6 +95,19 @@ struct ipa_ctx {
   size_t lens_map_bytes = 0;
   double lens_key[25];
   int lens_key_n = 0;
+  unsigned long lens_serial = 0;   // counts rebuilds of lens_map
+  // strip plans of the LDS-ring fused kernel (wave_lring.hpp), reused while the key (coordinate
+  // source given by value or the context's own lens maps, geometry) stands; clean strips of the
+  // last planning pass per key (page-locked, written by an async copy): a source that leaves most
+  // strips to the gather loop skips the ring kernel
+  void* lplan = nullptr;
+  size_t lplan_bytes = 0;
+  double lplan_key[48];
+  int lplan_key_n = 0;
+  unsigned* lring_hint = nullptr;
+  double lring_hint_key[48];
+  int lring_hint_n = 0;
+  unsigned lring_hint_strips = 0, lring_skips = 0;
   // No lock here: a context (stream + workspaces) belongs to ONE host thread at a time
   // (INTEGRATION.md section 4); the Python layer hands every thread its own default context.
 };

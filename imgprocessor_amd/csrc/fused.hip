@@ -363,6 +363,10 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
   FusedCall f;
   f.coord_kind = 0;
   f.map = MapCoord{d_mapx, d_mapy, map_pitch};
+  // the context's own lens maps (ipa_undistort_conv2d_dev with lens_cache): plans made for them
+  // stand until the maps are rebuilt
+  if (ctx->lens_map && ctx->lens_key_n && (const void*)d_mapx == (const void*)ctx->lens_map)
+    f.map_static = ctx->lens_serial + 1;
   return fused_common(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst, dst_dtype,
                       dh, dw, dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
                       border_mode, border_value, conv_border_x, conv_border_y);

@@ -70,6 +70,8 @@ const TuneName kTuneNames[] = {
     {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
     {"stored_coords", "IPA_STORED_COORDS", &ipa_tuning::stored_coords},
+    {"lring", "IPA_LRING", &ipa_tuning::lring},
+    {"lring_min", "IPA_LRING_MIN", &ipa_tuning::lring_min},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
@@ -93,7 +95,8 @@ static bool tune_is_experimental(const char* name) {
 static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "strip_h") == 0) return v >= 0 && v <= 4096;
   if (strcmp(name, "stream_k") == 0) return v >= 7 && v <= 99;
-  if (strcmp(name, "ring_min") == 0 || strcmp(name, "group_min") == 0) return v >= 1;
+  if (strcmp(name, "ring_min") == 0 || strcmp(name, "group_min") == 0 || strcmp(name, "lring_min") == 0) return v >= 1;
+  if (strcmp(name, "lring") == 0) return v >= 0 && v <= 2;   // 2: whatever the last plan found clean
   if (strcmp(name, "ring_remap") == 0 || strcmp(name, "ring_big") == 0 ||
       strcmp(name, "pair") == 0)
     return v >= 0 && v <= 2;
@@ -125,6 +128,15 @@ int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
   if (strcmp(name, "experimental") == 0) {  // read-only: is this a make EXPERIMENTAL=1 build?
     *value = IPA_EXPERIMENTAL;
+    return IPA_OK;
+  }
+  // read-only: what the last planning pass of the LDS-ring kernel found (wave_lring.hpp)
+  if (strcmp(name, "lring_clean") == 0) {
+    *value = ctx->lring_hint ? (int)ctx->lring_hint[0] : -1;
+    return IPA_OK;
+  }
+  if (strcmp(name, "lring_strips") == 0) {
+    *value = (int)ctx->lring_hint_strips;
     return IPA_OK;
   }
   for (const TuneName& t : kTuneNames)
@@ -187,6 +199,8 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   if (c->tab) (void)hipFree(c->tab);
   if (c->plan) (void)hipFree(c->plan);
   if (c->lens_map) (void)hipFree(c->lens_map);
+  if (c->lplan) (void)hipFree(c->lplan);
+  if (c->lring_hint) (void)hipHostFree(c->lring_hint);
   if (c->ring_hint) (void)hipHostFree(c->ring_hint);
   if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
   (void)hipStreamDestroy(c->stream);

@@ -807,3 +807,4 @@ static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_fr
 }
 
 }  // namespace ipa
+#include "wave_lring.hpp"  // clean strips of fused batches: source rows through an LDS ring (round 4)
