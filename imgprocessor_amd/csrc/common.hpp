@@ -28,27 +28,19 @@ struct ipa_tuning {
   int strip_h = 0;        // rows per strip of the marching kernels (0: by launch size)
   int frames_inner = 1;   // batches dispatched strip by strip (frames of a strip adjacent)
   int frames_wg = 1;      // map-based fused kernels: the waves of a workgroup are frames of ONE strip
+  int pipe = 1;           // 0: no strip on the hand-scheduled loops of wave_pipe.hpp (hand-counted vmcnt
+                          // waits) - the compiler-scheduled chunked loops everywhere: the fallback
+                          // and cross-check of that scheme (same bits, slower)
   int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
   int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
                           // XCD streaming through frames of its own
   int big_wave = 1;       // 9x9 / 11x11 filter on the marching wave (0: LDS-tiled kernel)
   int big_fused = 1;      // remap -> 7x7 / 9x9 / 11x11 in one kernel
   int stream_k = 7;       // smallest K whose coefficients are streamed through SGPRs
-  int group = 0;          // 1: batches of >= group_min frames on the frame-group kernel
-  int group_min = 2;
-  int group_ring = 1;     // frame-group kernel samples from its LDS ring of source rows
-  int ring = 0;           // 1: clean strips of batches >= ring_min frames on the ring kernel
-  int ring_min = 2;
-  int ring_ablate = 0;    // measurement only: parts of the ring kernel switched off (wrong results)
+  int ring_min = 2;       // smallest batch the ring remap kernel takes
   int u8_lz_lds = 1;      // uint8 Lanczos4: OpenCV's 128 KB weight table in LDS (0: weights formed per sample)
-  int pair = 0;           // fused bilinear map remap + 3x3 / 5x5 of batches: 1 = one wave per frame PAIR
-                          // (wave_pair.hpp), 2 = sampler wave + filter wave per strip (wave_split.hpp)
-  int ring_big = 0;       // batches, 7x7..11x11 after a remap in one kernel with the taps in LDS (1: bicubic, 2: all; measured slower)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
-  int lring = 0;          // batches of float32 frames, bilinear remap -> 3x3 / 5x5: clean strips take their
-                          // source rows through an LDS ring filled by LDS-DMA (wave_lring.hpp); 0: gather loop
-  int lring_min = 8;      // ... from this many frames on
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates
                           // are evaluated ONCE into the plan buffer and the gather kernel reads them (0: never)
@@ -95,19 +87,6 @@ struct ipa_ctx {
   size_t lens_map_bytes = 0;
   double lens_key[25];
   int lens_key_n = 0;
-  unsigned long lens_serial = 0;   // counts rebuilds of lens_map
-  // strip plans of the LDS-ring fused kernel (wave_lring.hpp), reused while the key (coordinate
-  // source given by value or the context's own lens maps, geometry) stands; clean strips of the
-  // last planning pass per key (page-locked, written by an async copy): a source that leaves most
-  // strips to the gather loop skips the ring kernel
-  void* lplan = nullptr;
-  size_t lplan_bytes = 0;
-  double lplan_key[48];
-  int lplan_key_n = 0;
-  unsigned* lring_hint = nullptr;
-  double lring_hint_key[48];
-  int lring_hint_n = 0;
-  unsigned lring_hint_strips = 0, lring_skips = 0;
   // No lock here: a context (stream + workspaces) belongs to ONE host thread at a time
   // (INTEGRATION.md section 4); the Python layer hands every thread its own default context.
 };

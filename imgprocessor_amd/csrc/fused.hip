@@ -11,16 +11,6 @@ int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
-#ifndef IPA_EXPERIMENTAL
-#define IPA_EXPERIMENTAL 0   // make EXPERIMENTAL=1: the shelved round-2 batch kernels
-#endif
-// fused_group.hip: batches, one workgroup per strip of 4 frames; 1 = not covered
-int ipa_fused_group_launch(ipa_ctx*, const FusedCall&, int K, int use_ring);
-// fused_ring.hip: plans the strips, runs the clean ones on the ring kernel and sets f.p.skip for
-// the per-frame kernel launched afterwards; 1 = not covered (f untouched)
-int ipa_fused_ring_launch(ipa_ctx*, FusedCall&, int K);
-int ipa_fused_pair_launch(ipa_ctx*, const FusedCall&, int K);      // fused_pair.hip; 1 = not covered
-int ipa_fused_ring_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_ring_big.hip; 1 = not covered
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
 
 static int inv3f(const double* m, double* o) {
@@ -93,35 +83,6 @@ static int fused_fill(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dty
   return IPA_OK;
 }
 
-// batches of float32 frames, 7x7 / 9x9 / 11x11: the one-kernel chain with the taps in LDS
-// (ring_big.hpp).  f.coord_kind and the coordinate source are set; 0 = launched, 1 = not covered.
-static int ring_big_try(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh, int sw,
-                        long src_pitch, const double* kernel, int kh, int kw, void* d_dst,
-                        int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
-                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
-                        double border_value, int cbx, int cby) {
-#if !IPA_EXPERIMENTAL
-  return 1;
-#else
-  if (!ctx->tune.ring_big || n_frames < ctx->tune.ring_min || kh != kw || !kernel ||
-      !(kh == 7 || kh == 9 || kh == 11) || src_dtype != IPA_F32 || dst_dtype != IPA_F32)
-    return 1;
-  const int base = interp & 0xff;
-  // (ring_big = 1: bicubic; bilinear from maps stays on the per-frame one-kernel form unless
-  // ring_big = 2)
-  if (base == IPA_INTER_LINEAR && f.coord_kind == 0 && ctx->tune.ring_big < 2) return 1;
-  int rc = fused_fill(ctx, f, d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw,
-                      dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp, border_mode,
-                      border_value, cbx, cby);
-  if (rc) return rc < 0 ? rc : -1;
-  f.kernel = kernel;
-  IPA_HIP(ctx, hipSetDevice(ctx->device));
-  rc = ipa_fused_ring_big_launch(ctx, f, kh);
-  if (rc == 0) IPA_HIP(ctx, hipGetLastError());
-  return rc;
-#endif
-}
-
 static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_dtype, int sh,
                         int sw, long src_pitch, const double* kernel, int kh, int kw, void* d_dst,
                         int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
@@ -137,28 +98,6 @@ static int fused_common(ipa_ctx* ctx, FusedCall& f, const void* d_src, int src_d
   if (rc) return rc;
   f.kernel = kernel;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-#if IPA_EXPERIMENTAL
-  if (ctx->tune.group && n_frames >= ctx->tune.group_min) {
-    rc = ipa_fused_group_launch(ctx, f, kh, ctx->tune.group_ring);
-    if (rc < 0) return rc;
-    if (rc == 0) {
-      IPA_HIP(ctx, hipGetLastError());
-      return IPA_OK;
-    }
-  }
-  if (ctx->tune.ring && n_frames >= ctx->tune.ring_min) {
-    rc = ipa_fused_ring_launch(ctx, f, kh);
-    if (rc < 0) return rc;
-  }
-  if (ctx->tune.pair && !f.p.skip) {
-    rc = ipa_fused_pair_launch(ctx, f, kh);
-    if (rc < 0) return rc;
-    if (rc == 0) {
-      IPA_HIP(ctx, hipGetLastError());
-      return IPA_OK;
-    }
-  }
-#endif
   switch (kh) {
     case 3: rc = ipa_fused_launch_k3(ctx, f); break;
     case 5: rc = ipa_fused_launch_k5(ctx, f); break;
@@ -319,16 +258,6 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
                        n_frames % 4 == 0 && dst_dtype == IPA_F32 &&
                        src_dtype == IPA_U16;
   const bool streamed = kh >= stream_k && kh >= 7 && kh <= 11 && !shared7;
-  {
-    FusedCall f;
-    f.coord_kind = 0;
-    f.map = MapCoord{d_mapx, d_mapy, map_pitch};
-    int rc = ring_big_try(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst,
-                          dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
-                          dst_frame_stride, interp, border_mode, border_value, conv_border_x,
-                          conv_border_y);
-    if (rc <= 0) return rc;
-  }
   if (big_fused && kh == kw && streamed &&
       (src_dtype == IPA_F32 || (kh == 7 && src_dtype == IPA_U16)) && dst_dtype == IPA_F32 &&
       kernel) {
@@ -363,10 +292,6 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
   FusedCall f;
   f.coord_kind = 0;
   f.map = MapCoord{d_mapx, d_mapy, map_pitch};
-  // the context's own lens maps (ipa_undistort_conv2d_dev with lens_cache): plans made for them
-  // stand until the maps are rebuilt
-  if (ctx->lens_map && ctx->lens_key_n && (const void*)d_mapx == (const void*)ctx->lens_map)
-    f.map_static = ctx->lens_serial + 1;
   return fused_common(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst, dst_dtype,
                       dh, dw, dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
                       border_mode, border_value, conv_border_x, conv_border_y);
@@ -425,16 +350,6 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
                                     double border_value, int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, M, "null matrix");
-  {
-    FusedCall f;
-    f.coord_kind = 2;
-    for (int i = 0; i < 9; i++) f.hom.m[i] = M[i];
-    int rc = ring_big_try(ctx, f, d_src, src_dtype, sh, sw, src_pitch, kernel, kh, kw, d_dst,
-                          dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
-                          dst_frame_stride, interp, border_mode, border_value, conv_border_x,
-                          conv_border_y);
-    if (rc <= 0) return rc;
-  }
   void* tmp = nullptr;
   int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;

@@ -36,10 +36,6 @@ struct FusedCall {
   HomographyCoord hom;
   int src_dt, dst_dt, interp_base, n_frames;
   const double* kernel;
-  // coord_kind 0: the maps are the context's own lens maps (ipa_lens_map_cached), identified by
-  // ctx->lens_serial - strip plans made for them can be reused; 0: the caller's maps, planned
-  // anew on every call (their contents may have changed)
-  unsigned long map_static = 0;
 };
 
 // Batches whose frame count is no multiple of the workgroup's IPA_WPB frames cannot share
@@ -72,107 +68,6 @@ template <typename Src, int K> static bool fused_split_tail(const ipa_ctx* ctx, 
   return s1 <= d0 || d1 <= s0;
 }
 
-
-// ---- the LDS-ring kernel (wave_lring.hpp): clean strips take their source rows through LDS ----
-static inline int lring_coord_key(const MapCoord& c, const FusedCall& f, double* k) {
-  k[0] = (double)reinterpret_cast<uintptr_t>(c.mx);
-  k[1] = (double)reinterpret_cast<uintptr_t>(c.my);
-  k[2] = (double)c.pitch;
-  k[3] = (double)f.map_static;
-  return 4;
-}
-static inline int lring_coord_key(const UndistortCoord& c, const FusedCall&, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.ir[i];
-  const double v[10] = {c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.k3, (double)c.affine};
-  for (int i = 0; i < 10; i++) k[9 + i] = v[i];
-  return 19;
-}
-static inline int lring_coord_key(const HomographyCoord& c, const FusedCall&, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.m[i];
-  return 9;
-}
-
-// 0 = launched, 1 = not covered (the caller runs the gather kernel), < 0 = error
-template <typename ST, int INTERP, typename Coord, int K>
-static int lring_try(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const Weights<float, K * K>& w,
-                     const SampleRowSrc<ST, INTERP, Coord>& s) {
-  using Src = SampleRowSrc<ST, INTERP, Coord>;
-  if constexpr (!lring_capable<Src, K>::value) {
-    return 1;
-  } else {
-    if (!ctx->tune.lring || f.q5 || f.n_frames % IPA_WPB != 0 || f.n_frames < ctx->tune.lring_min) return 1;
-    if (!ctx->tune.frames_wg || !ctx->tune.frames_inner) return 1;
-    if (!f.p.vec_out || (f.p.dw & 3) != 0 || (Src::kMap && !f.map_vec)) return 1;
-    WaveParams p = f.p;
-    p.strips_x = (p.dw + 255) / 256;
-    p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false, 2);
-    if (p.strip_h > kLrMaxRows - (K - 1)) p.strip_h = kLrMaxRows - (K - 1);
-    p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-    if ((unsigned long)p.strips * (unsigned long)(f.n_frames / IPA_WPB) >= (1ul << 31)) return 1;
-    p.frames_inner = f.n_frames;
-    p.frames_wg = 1;
-    p.frame_major = 0;
-    // key of the plan: coordinate source + everything the footprints and the schedule depend on
-    double key[48];
-    int kn = lring_coord_key(c, f, key);
-    const double g[12] = {(double)p.dh, (double)p.dw, (double)f.sh, (double)f.sw, (double)K,
-                          (double)p.strip_h, (double)p.cbx, (double)p.cby, (double)kLrR, (double)kLrD,
-                          (double)kLrPitch, (double)sizeof(typename Coord::coord_t)};
-    for (int i = 0; i < 12; i++) key[kn++] = g[i];
-    const bool reusable = !std::is_same<Coord, MapCoord>::value || f.map_static != 0;
-    const bool same = ctx->lring_hint_n == kn &&
-                      memcmp(ctx->lring_hint_key, key, (size_t)kn * sizeof(double)) == 0;
-    // what the last planning pass for this key found (read back without waiting: possibly one
-    // call old): a source that leaves most strips to the gather loop - a strong rotation,
-    // footprints outside the frame - stays on the gather kernel, whose strips overlap less LDS.
-    // Same bits either way.  Every 16th skipped call of a source that is planned per call plans
-    // again (its maps may have been rewritten in place).
-    if (ctx->tune.lring < 2 && same && ctx->lring_hint && ctx->lring_hint[0] != 0xffffffffu &&
-        ctx->lring_hint_strips == p.strips && 2u * ctx->lring_hint[0] < p.strips &&
-        (reusable || (++ctx->lring_skips & 15u) != 0))
-      return 1;
-    const bool hit = reusable && ctx->lplan_key_n == kn &&
-                     memcmp(ctx->lplan_key, key, (size_t)kn * sizeof(double)) == 0;
-    const size_t plan_b = (((size_t)p.strips * kLrPlanWords * sizeof(unsigned)) + 255) & ~(size_t)255;
-    if (!hit) {
-      ctx->lplan_key_n = 0;
-      if (ctx->lplan_bytes < plan_b + 256) {
-        IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->lplan) {
-          IPA_HIP(ctx, hipFree(ctx->lplan));
-          ctx->lplan = nullptr;
-          ctx->lplan_bytes = 0;
-        }
-        IPA_HIP(ctx, hipMalloc(&ctx->lplan, 2 * plan_b + 256));
-        ctx->lplan_bytes = 2 * plan_b + 256;
-      }
-      if (!ctx->lring_hint)
-        IPA_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&ctx->lring_hint), 2 * sizeof(unsigned)));
-      if (!same) {
-        ctx->lring_hint[0] = 0xffffffffu;   // nothing known about this source yet
-        ctx->lring_skips = 0;
-        memcpy(ctx->lring_hint_key, key, (size_t)kn * sizeof(double));
-        ctx->lring_hint_n = kn;
-      }
-      ctx->lring_hint_strips = p.strips;
-      unsigned* stats = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ctx->lplan) + plan_b);
-      IPA_HIP(ctx, hipMemsetAsync(stats, 0, sizeof(unsigned), ctx->stream));
-      hipLaunchKernelGGL((lring_plan_kernel<Coord, K>), dim3(p.strips), dim3(1024), 0, ctx->stream, p, c,
-                         f.sh, f.sw, f.q5, reinterpret_cast<unsigned*>(ctx->lplan), stats);
-      IPA_HIP(ctx, hipMemcpyAsync(ctx->lring_hint, stats, sizeof(unsigned), hipMemcpyDeviceToHost,
-                                  ctx->stream));
-      if (reusable) {
-        memcpy(ctx->lplan_key, key, (size_t)kn * sizeof(double));
-        ctx->lplan_key_n = kn;
-      }
-    }
-    dim3 grid(p.strips * (unsigned)(f.n_frames / IPA_WPB), 1), block(64 * IPA_WPB);
-    hipLaunchKernelGGL((lring_stencil_kernel<Src, K>), grid, block, 0, ctx->stream, p, s, w,
-                       reinterpret_cast<const unsigned*>(ctx->lplan));
-    return 0;
-  }
-}
-
 template <typename ST, int INTERP, typename Coord, int K>
 static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   using Src = SampleRowSrc<ST, INTERP, Coord>;
@@ -194,7 +89,6 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   s.sh = f.sh; s.sw = f.sw; s.spitch = f.spitch;
   s.border = f.border; s.q5 = f.q5; s.cubic_a = f.cubic_a; s.lanczos = nullptr;
   s.cval = (float)f.cval; s.ccval = (float)f.conv_cval; s.map_vec = f.map_vec;
-  if (lring_try<ST, INTERP, Coord, K>(ctx, f, c, w, s) == 0) return;
   WaveParams p = f.p;
   using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;

@@ -265,7 +265,6 @@ int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, cons
   const bool hit = ctx->lens_key_n == 25 && memcmp(ctx->lens_key, key, sizeof(key)) == 0;
   if (!hit) {
     ctx->lens_key_n = 0;
-    ctx->lens_serial++;
     if (ctx->lens_map_bytes < 2 * mb) {
       IPA_HIP(ctx, hipSetDevice(ctx->device));
       IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));  // earlier calls may still read the old maps

@@ -62,45 +62,24 @@ const TuneName kTuneNames[] = {
     {"big_wave", "IPA_BIG_WAVE", &ipa_tuning::big_wave},
     {"big_fused", "IPA_BIG_FUSED", &ipa_tuning::big_fused},
     {"stream_k", "IPA_STREAM_K", &ipa_tuning::stream_k},
-    {"group", "IPA_GROUP", &ipa_tuning::group},
-    {"group_min", "IPA_GROUP_MIN", &ipa_tuning::group_min},
-    {"group_ring", "IPA_GROUP_RING", &ipa_tuning::group_ring},
-    {"ring", "IPA_RING", &ipa_tuning::ring},
     {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
-    {"ring_ablate", "IPA_RING_ABLATE", &ipa_tuning::ring_ablate},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
     {"stored_coords", "IPA_STORED_COORDS", &ipa_tuning::stored_coords},
-    {"lring", "IPA_LRING", &ipa_tuning::lring},
-    {"lring_min", "IPA_LRING_MIN", &ipa_tuning::lring_min},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
-    {"ring_big", "IPA_RING_BIG", &ipa_tuning::ring_big},
-    {"pair", "IPA_PAIR", &ipa_tuning::pair},
+    {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };
 }  // namespace
 
-#ifndef IPA_EXPERIMENTAL
-#define IPA_EXPERIMENTAL 0
-#endif
-// knobs of kernels that only exist in a `make EXPERIMENTAL=1` build
-static bool tune_is_experimental(const char* name) {
-  for (const char* n : {"group", "ring", "pair", "ring_big", "ring_ablate"})
-    if (strcmp(n, name) == 0) return true;
-  return false;
-}
-// accepted range of a knob (everything else is an error, not a silent launch-shape surprise)
 static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "strip_h") == 0) return v >= 0 && v <= 4096;
   if (strcmp(name, "stream_k") == 0) return v >= 7 && v <= 99;
-  if (strcmp(name, "ring_min") == 0 || strcmp(name, "group_min") == 0 || strcmp(name, "lring_min") == 0) return v >= 1;
-  if (strcmp(name, "lring") == 0) return v >= 0 && v <= 2;   // 2: whatever the last plan found clean
-  if (strcmp(name, "ring_remap") == 0 || strcmp(name, "ring_big") == 0 ||
-      strcmp(name, "pair") == 0)
-    return v >= 0 && v <= 2;
-  if (strcmp(name, "ring_ablate") == 0 || strcmp(name, "stored_coords") == 0) return v >= 0;
+  if (strcmp(name, "ring_min") == 0) return v >= 1;
+  if (strcmp(name, "ring_remap") == 0) return v >= 0 && v <= 2;
+  if (strcmp(name, "stored_coords") == 0) return v >= 0;
   return v == 0 || v == 1;
 }
 
@@ -112,11 +91,6 @@ int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
         ipa_set_error(ctx, "tuning knob '%s': value %d out of range", name, value);
         return IPA_ERR_BAD_ARG;
       }
-      if (!IPA_EXPERIMENTAL && value != 0 && tune_is_experimental(name)) {
-        ipa_set_error(ctx, "tuning knob '%s' selects a kernel this build does not carry "
-                           "(make EXPERIMENTAL=1)", name);
-        return IPA_ERR_UNSUPPORTED;
-      }
       ctx->tune.*(t.field) = value;
       return IPA_OK;
     }
@@ -126,19 +100,6 @@ int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
 
 int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
-  if (strcmp(name, "experimental") == 0) {  // read-only: is this a make EXPERIMENTAL=1 build?
-    *value = IPA_EXPERIMENTAL;
-    return IPA_OK;
-  }
-  // read-only: what the last planning pass of the LDS-ring kernel found (wave_lring.hpp)
-  if (strcmp(name, "lring_clean") == 0) {
-    *value = ctx->lring_hint ? (int)ctx->lring_hint[0] : -1;
-    return IPA_OK;
-  }
-  if (strcmp(name, "lring_strips") == 0) {
-    *value = (int)ctx->lring_hint_strips;
-    return IPA_OK;
-  }
   for (const TuneName& t : kTuneNames)
     if (strcmp(t.name, name) == 0) {
       *value = ctx->tune.*(t.field);
@@ -176,7 +137,7 @@ int ipa_ctx_create(int device_id, ipa_ctx** out) {
   for (const TuneName& t : kTuneNames)
     if (const char* e = getenv(t.env)) {
       const int v = atoi(e);
-      if (tune_in_range(t.name, v) && (IPA_EXPERIMENTAL || v == 0 || !tune_is_experimental(t.name)))
+      if (tune_in_range(t.name, v))
         c->tune.*(t.field) = v;
     }
   c->device = device_id;
@@ -199,8 +160,6 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   if (c->tab) (void)hipFree(c->tab);
   if (c->plan) (void)hipFree(c->plan);
   if (c->lens_map) (void)hipFree(c->lens_map);
-  if (c->lplan) (void)hipFree(c->lplan);
-  if (c->lring_hint) (void)hipHostFree(c->lring_hint);
   if (c->ring_hint) (void)hipHostFree(c->ring_hint);
   if (c->tab_pinned) (void)hipHostFree(c->tab_pinned);
   (void)hipStreamDestroy(c->stream);

@@ -233,8 +233,8 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   const bool writer = lane >= 1 && lane < 63 && c.xo < p.dw;
   float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
-  const bool fast = src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw && y0 - H >= 0 &&
-                    y0 - H + rows_touched <= p.dh;
+  const bool fast = !p.no_pipe && src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
+                    y0 - H >= 0 && y0 - H + rows_touched <= p.dh;
   if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
@@ -259,7 +259,7 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
       c.uq[k] = resolve_idx(xs + lane + 64 * k, p.dw, p.cbx);
     }
     if constexpr (kShared) {
-      if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
+      if (p.frames_wg && !p.no_pipe && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         SepFilter<K> filt(w, xcval);
         if (src.q5) wave_run_strip_shared<K, 1, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         else wave_run_strip_shared<K, 0, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);

@@ -137,6 +137,10 @@ struct WaveParams {
                              // XCD-contiguous block order every XCD then streams through whole
                              // frames of its own (plain filters: no rows shared between frames;
                              // tools/pipe_micro.hip order 1: 835 -> 775 us per 64 x 4K copy)
+  int no_pipe = 0;     // 1 (context knob pipe = 0): no strip takes the hand-scheduled loops of
+                       // wave_pipe.hpp - every strip runs the compiler-scheduled chunked loop with
+                       // its columns and rows resolved (the fallback and cross-check of the
+                       // hand-counted waits; same bits, slower)
   int frames_wg = 0;   // 1: the waves of a workgroup are consecutive FRAMES of one strip - the strip's
                        // map rows then reach the CU's L1 once per workgroup instead of once per
                        // frame (64 x 4K fused 5x5: 1.361 -> 1.335 ms); set by wave_grid
@@ -151,13 +155,15 @@ static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, in
   frames_inner = frames_inner && ctx->tune.frames_inner != 0;
   p.frames_wg = 0;
   p.frame_major = 0;
+  p.no_pipe = ctx->tune.pipe == 0;
   if (may_frame_major && !share_maps && ctx->tune.frame_major != 0 && n_frames > 1 &&
       (unsigned long)blocks * n_frames < (1ul << 31)) {
     p.frames_inner = 0;
     p.frame_major = blocks;
     return dim3(blocks * (unsigned)n_frames, 1);
   }
-  if (frames_inner && share_maps && ctx->tune.frames_wg != 0 && n_frames % waves_per_block == 0 &&
+  if (frames_inner && share_maps && ctx->tune.frames_wg != 0 && !p.no_pipe &&
+      n_frames % waves_per_block == 0 &&
       (unsigned long)p.strips * n_frames < (1ul << 31)) {
     p.frames_inner = n_frames;
     p.frames_wg = 1;
@@ -677,9 +683,8 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
   // (HALO geometry: the halo columns of a FAST strip lie inside the image too)
   const int hx = HALO ? G::H : 0;
-  const bool fast = src.vectors_ok() && p.vec_out && xs - hx >= 0 && xs + 256 + hx <= p.dw &&
-                    y0 - G::H >= 0 &&
-                    y0 - G::H + rows_touched <= p.dh;
+  const bool fast = !p.no_pipe && src.vectors_ok() && p.vec_out && xs - hx >= 0 &&
+                    xs + 256 + hx <= p.dw && y0 - G::H >= 0 && y0 - G::H + rows_touched <= p.dh;
   if (fast && p.rim_only) return;
   if (fast) {
 #pragma unroll
@@ -718,7 +723,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     if constexpr (kShared) {
       // (vector alignment holds: the strip runs on the shared-map loop with its columns and
       // rows resolved through the filter's border mode; 15 % of a 4K frame's strips)
-      if (p.frames_wg && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
+      if (p.frames_wg && !p.no_pipe && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         DenseFilter<K> filt(wts);
         if (src.q5) wave_run_strip_shared<K, 1, true, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
         else wave_run_strip_shared<K, 0, true, HALO>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
@@ -727,7 +732,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
     }
     if constexpr (HALO && !Src::kHasQ5 && IPA_PIPE_EDGE) {
       // plain rows: the rim strips on the hand-scheduled loop too (resolved columns and rows)
-      if (p.vec_out && (p.dw & 3) == 0) {
+      if (!p.no_pipe && p.vec_out && (p.dw & 3) == 0) {
         wave_run_strip_pipe<K, HALO, true>(p, src, wts, xp, c, y0, nrows, writer, dst);
         return;
       }
@@ -807,4 +812,3 @@ static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_fr
 }
 
 }  // namespace ipa
-#include "wave_lring.hpp"  // clean strips of fused batches: source rows through an LDS ring (round 4)

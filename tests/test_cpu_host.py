@@ -344,21 +344,34 @@ def test_optimal_new_camera_matrix_independent_restatement():
 
 
 def test_hand_scheduled_kernels_static_check(tmp_path):
-    """the headline kernels (csrc/wave_pipe.hpp: inline-asm loads with hand-counted vmcnt waits)
-    compiled here for gfx950 and checked statically: no instruction touches a register whose
-    load is still in flight, no vector register is spilled (tools/check_pipe_asm.py)"""
+    """every translation unit that carries the hand-scheduled loops of csrc/wave_pipe.hpp (inline-asm
+    loads with hand-counted vmcnt waits: the dense 3x3 / 5x5 / 7x7 kernels, the separable ones)
+    compiled here for gfx950 and checked statically: no instruction touches a register whose load
+    is still in flight, every vector-memory asm statement carries the SGPR hazard guard, no vector
+    register is spilled (tools/check_pipe_asm.py; `make -C imgprocessor_amd/csrc check-asm` runs
+    the same)"""
     import shutil
     import subprocess
+    from concurrent.futures import ThreadPoolExecutor
     if not shutil.which('hipcc'):
         pytest.skip('no hipcc')
     src = os.path.join(ROOT, 'imgprocessor_amd', 'csrc')
-    cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-function',
-           '-save-temps=obj', '-c', os.path.join(src, 'fused_k5.hip'), '-I', src,
-           '-o', str(tmp_path / 'fused_k5.o')]
-    subprocess.run(cmd, check=True, cwd=str(tmp_path), capture_output=True)
-    asm = tmp_path / 'fused_k5-hip-amdgcn-amd-amdhsa-gfx950.s'
-    assert asm.exists()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_pipe_asm.py'), str(asm)],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert 'SampleRowSrc' in r.stdout and 'LoadRowSrc' in r.stdout, r.stdout
+    units = ['fused_k3', 'fused_k5', 'fused_k7', 'fused_sep_a', 'fused_sep_b']
+
+    def one(u):
+        d = tmp_path / u
+        d.mkdir()
+        cmd = ['hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-function',
+               '-save-temps=obj', '-c', os.path.join(src, u + '.hip'), '-I', src, '-o', str(d / (u + '.o'))]
+        subprocess.run(cmd, check=True, cwd=str(d), capture_output=True)
+        asm = d / (u + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+        assert asm.exists()
+        return subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'check_pipe_asm.py'), str(asm)],
+                              capture_output=True, text=True)
+
+    with ThreadPoolExecutor(max_workers=min(len(units), os.cpu_count() or 1)) as ex:
+        results = dict(zip(units, ex.map(one, units)))
+    for u, r in results.items():
+        assert r.returncode == 0, u + ':\n' + r.stdout + r.stderr
+        assert 'SampleRowSrc' in r.stdout, u + ':\n' + r.stdout
+    assert 'LoadRowSrc' in results['fused_k5'].stdout

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from .test_gpu_group import frames, kern, radial_maps, same_bits
+from .gpu_helpers import frames, kern, radial_maps, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -86,8 +86,7 @@ def test_uint8_remap_with_pitches(ia, interp, odd):
 
 @pytest.mark.parametrize('odd', [0, 1])
 @pytest.mark.parametrize('K', [5, 9])
-@pytest.mark.parametrize('tune', [dict(), dict(pair=1), dict(ring=1), dict(ring_big=2)])
-def test_remap_conv_with_pitches(ia, K, tune, odd):
+def test_remap_conv_with_pitches(ia, K, odd):
     from imgprocessor_amd import ops
     from imgprocessor_amd.device import dtype_id
     ctx = ia.default_context(0)
@@ -95,9 +94,7 @@ def test_remap_conv_with_pitches(ia, K, tune, odd):
     src = frames(n, h, w)
     mx, my, _, _ = radial_maps(h, w)
     k = np.ascontiguousarray(kern(K), dtype=np.float64)
-    if tune and not ctx.get_tuning('experimental'):
-        pytest.skip('shelved round-2 kernel: build with make EXPERIMENTAL=1')
-    old = ctx.set_tuning(ring_min=1, **tune)
+    old = ctx.set_tuning(ring_min=1)
     try:
         want = ops.remap_conv2d(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), k).get()
         sp, dp, mp = w + 20 + odd, w + 4 + odd, w + 16 + 3 * odd
@@ -114,5 +111,5 @@ def test_remap_conv_with_pitches(ia, K, tune, odd):
         got = dbig.get()
     finally:
         ctx.set_tuning(**old)
-    same_bits(np.ascontiguousarray(got[:, :h, :w]), want, 'pitched remap_conv K=%d %r' % (K, tune))
+    same_bits(np.ascontiguousarray(got[:, :h, :w]), want, 'pitched remap_conv K=%d' % K)
     assert (got[:, h:, :] == -5.0).all() and (got[:, :, w:] == -5.0).all(), 'wrote outside'

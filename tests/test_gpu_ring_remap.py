@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from .conftest import assert_close
-from .test_gpu_group import frames, radial_maps, rot_maps, same_bits
+from .gpu_helpers import frames, radial_maps, rot_maps, same_bits
 
 pytestmark = pytest.mark.gpu
 
@@ -187,7 +187,7 @@ def test_lens_map_cache_matches_per_pixel_model(ia):
     """fused undistort + filter: the cached float32 maps (default) against the lens model
     evaluated in the kernel (lens_cache=0) - bit for bit, across changes of model and size"""
     from imgprocessor_amd import ops
-    from .test_gpu_group import kern
+    from .gpu_helpers import kern
     ctx = ia.default_context(0)
     h, w, n = 140, 900, 3
     d_src = ctx.to_device(frames(n, h, w))

@@ -210,7 +210,7 @@ def main():
     i = 0
     while i < len(s):
         l = s[i]
-        if l.startswith('_Z') and l.split(';')[0].rstrip().endswith(':') and 'wave_stencil' in l:
+        if l.startswith('_Z') and l.split(';')[0].rstrip().endswith(':'):
             name = l.split(':')[0]
             j = i
             while 's_endpgm' not in s[j]:

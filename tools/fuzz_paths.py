@@ -92,10 +92,6 @@ def main():
         plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0)
         alts = [dict(ring_remap=2), dict(lens_cache=1), dict(frames_wg=1),
                 dict(ring_remap=2, lens_cache=1, frames_wg=1)]
-        if ctx.get_tuning('experimental'):  # make EXPERIMENTAL=1: the shelved round-2 kernels too
-            plain.update(ring_big=0, pair=0, ring=0, group=0)
-            alts += [dict(ring_big=2), dict(pair=1), dict(pair=2), dict(ring=1),
-                     dict(ring_remap=2, ring_big=2, pair=1, lens_cache=1, frames_wg=1)]
         for name, fn in calls.items():
             if fn is None:
                 continue
