@@ -212,7 +212,9 @@ def test_c3_4k_perspective_sep9(ia, orc):
     for interp, iid in (('linear', orc.LINEAR), ('cubic', orc.CUBIC_KEYS)):
         warped = ia.ops.warp_perspective(d_img, M, (h, w), interp)
         want_w = orc.warp_perspective(img, M, (h, w), iid)
-        close32p(warped.get(), want_w, 'C3 warp ' + interp, scale=1.0)
+        # (the pointwise bound where the weights are positive: a bicubic / Lanczos4 sample that
+        # cancels to ~0 carries the float32 rounding of its O(1) terms - 7e-8 absolute here)
+        (close32p if interp == 'linear' else close32)(warped.get(), want_w, 'C3 warp ' + interp, scale=1.0)
         out = ia.ops.sepconv2d(warped, g9, g9).get()
         close32p(out, orc.sepconv2d(want_w, g9, g9), 'C3 sep9 ' + interp, scale=1.0)
         # the chain as ONE kernel (remap -> separable 9+9)
@@ -227,7 +229,7 @@ def test_c3_4k_perspective_sep9(ia, orc):
     pc = PerspectiveCorrection(img.shape, new_size=(h, w))
     pc.setReference([(192, 108), (3648, 54), (3744, 2106), (96, 2052)])
     got = pc.correct(img)
-    close32p(got, orc.warp_perspective(img, np.linalg.inv(pc.homography), (h, w), orc.LANCZOS4),
+    close32(got, orc.warp_perspective(img, np.linalg.inv(pc.homography), (h, w), orc.LANCZOS4),
             'C3 lanczos4', scale=1.0)
 
 
