@@ -15,6 +15,7 @@
 
 #include "common.hpp"
 #include "wave_stencil.hpp"
+#include "stored_coords.hpp"
 
 namespace ipa {
 
@@ -68,9 +69,28 @@ template <typename Src, int K> static bool fused_split_tail(const ipa_ctx* ctx, 
   return s1 <= d0 || d1 <= s0;
 }
 
+// batches on the shared-record loop whose coordinates come from the homography: its double
+// coordinates (two fused-multiply-add chains and a division per pixel) are evaluated ONCE per
+// (matrix, geometry) into the plan buffer (stored_coords.hpp) and the record producers read them
+// as a table - the C3 chain spent a third of its time evaluating them once per four frames
+static inline bool fused_wants_stored_coords(const ipa_ctx* ctx, const FusedCall& f) {
+  const int smin = ctx->tune.stored_coords;
+  return smin > 0 && f.n_frames >= smin && ctx->tune.pipe != 0 && ctx->tune.frames_wg != 0 &&
+         ctx->tune.frames_inner != 0 && (f.n_frames % IPA_WPB == 0 || f.n_frames >= 2 * IPA_WPB - 1);
+}
+
 template <typename ST, int INTERP, typename Coord, int K>
 static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   using Src = SampleRowSrc<ST, INTERP, Coord>;
+  if constexpr (std::is_same<Coord, HomographyCoord>::value && shared_capable<Src, K>::value) {
+    if (fused_wants_stored_coords(ctx, f)) {
+      StoredCoord<double> sc;
+      if (stored_coords_prepare<Coord>(ctx, c, f.p.dh, f.p.dw, &sc) == 0) {
+        fused_launch_one<ST, INTERP, StoredCoord<double>, K>(ctx, f, sc);
+        return;
+      }
+    }
+  }
   if (fused_split_tail<Src, K>(ctx, f)) {
     FusedCall head = f, tail = f;
     head.n_frames = f.n_frames - f.n_frames % IPA_WPB;

@@ -23,6 +23,15 @@ struct FusedSep {
 template <typename ST, int INTERP, typename Coord, int K>
 static void fused_sep_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const FusedSep& q) {
   using Src = SampleRowSrc<ST, INTERP, Coord>;
+  if constexpr (std::is_same<Coord, HomographyCoord>::value && sep_shared<Src, K>::value) {
+    if (fused_wants_stored_coords(ctx, f)) {   // (see fused_impl.hpp)
+      StoredCoord<double> sc;
+      if (stored_coords_prepare<Coord>(ctx, c, f.p.dh, f.p.dw, &sc) == 0) {
+        fused_sep_one<ST, INTERP, StoredCoord<double>, K>(ctx, f, sc, q);
+        return;
+      }
+    }
+  }
   if (sep_shared<Src, K>::value && fused_split_tail<Src, 5>(ctx, f)) {   // (see fused_impl.hpp)
     FusedCall head = f, tail = f;
     head.n_frames = f.n_frames - f.n_frames % IPA_WPB;

@@ -19,6 +19,7 @@
 #include "common.hpp"
 #include "sampler.hpp"
 #include "ring_remap.hpp"
+#include "stored_coords.hpp"
 
 namespace ipa {
 
@@ -461,55 +462,6 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
   }
   p.skip = plan.pair_clean;
   p.tile_rows = (unsigned)gm.strip_h / 4u;
-  return 0;
-}
-
-// ------------------------------------------------------------ stored coordinates --
-// A coordinate source given by value (homography: double coordinates, ~40 float64 operations
-// per pixel; lens model) evaluated ONCE per (source, geometry) into the context's plan buffer, in
-// the source's own type - the frames of a batch then sample through remap_kernel<StoredCoord>
-// exactly what the per-pixel evaluation would give (same coordinate bits), in the
-// lane-interleaved order of the map-based kernel.  16 x 4K, 7 degrees + perspective (no clean
-// strips for the ring kernel): bicubic 0.648 -> 0.600 ms, Lanczos4 1.853 -> 1.467 ms (the same warp
-// from float32 maps, i.e. other coordinate bits: 0.502 / 1.344).
-template <typename Coord>
-__global__ void __launch_bounds__(256)
-store_coords_kernel(Coord c, int dh, int dw, typename Coord::coord_t* __restrict__ ox,
-                    typename Coord::coord_t* __restrict__ oy) {
-  const int u = blockIdx.x * 256 + threadIdx.x, v = blockIdx.y;
-  if (u >= dw) return;
-  typename Coord::coord_t sx, sy;
-  c.get(u, v, sx, sy);
-  ox[(long)v * dw + u] = sx;
-  oy[(long)v * dw + u] = sy;
-}
-
-template <typename Coord>
-static int stored_coords_prepare(ipa_ctx* ctx, const Coord& coord, int dh, int dw,
-                                 StoredCoord<typename Coord::coord_t>* sc) {
-  using CT = typename Coord::coord_t;
-  if (dh > 65535) return 1;
-  double key[40];
-  int kn = coord_key(coord, key);
-  key[kn++] = (double)dh; key[kn++] = (double)dw; key[kn++] = (double)sizeof(CT);
-  key[kn++] = 7777.0;   // (not a ring plan: those keys are longer)
-  const size_t plane = (((size_t)dh * dw * sizeof(CT)) + 255) & ~(size_t)255;
-  const bool hit = ctx->plan_key_n == kn &&
-                   memcmp(ctx->plan_key, key, (size_t)kn * sizeof(double)) == 0 &&
-                   ctx->plan_bytes >= 2 * plane;
-  if (!hit) {
-    int rc = ipa_plan_reserve(ctx, 2 * plane);
-    if (rc) return rc;
-  }
-  CT* ox = reinterpret_cast<CT*>(ctx->plan);
-  CT* oy = reinterpret_cast<CT*>(reinterpret_cast<char*>(ctx->plan) + plane);
-  if (!hit) {
-    hipLaunchKernelGGL((store_coords_kernel<Coord>), dim3((unsigned)((dw + 255) / 256), (unsigned)dh),
-                       dim3(256), 0, ctx->stream, coord, dh, dw, ox, oy);
-    memcpy(ctx->plan_key, key, (size_t)kn * sizeof(double));
-    ctx->plan_key_n = kn;
-  }
-  *sc = StoredCoord<CT>{ox, oy, (long)dw};
   return 0;
 }
 

@@ -21,6 +21,7 @@
 #pragma once
 
 #include "ring_geom.hpp"
+#include "stored_coords.hpp"
 
 namespace ipa {
 
@@ -192,24 +193,6 @@ ring_plan_kernel(RingGeom gm, Coord coord, int sh, int sw, RingTaps tp, RingPlan
 }
 
 // ------------------------------------------------------------------ host: plan + reuse --
-// the parameters of a coordinate source given by value, for the plan buffer's reuse key
-static inline int coord_key(const MapCoord& c, double* k) {
-  k[0] = (double)reinterpret_cast<uintptr_t>(c.mx);
-  k[1] = (double)reinterpret_cast<uintptr_t>(c.my);
-  k[2] = (double)c.pitch;
-  return 3;
-}
-static inline int coord_key(const UndistortCoord& c, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.ir[i];
-  const double v[10] = {c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2, c.k3, (double)c.affine};
-  for (int i = 0; i < 10; i++) k[9 + i] = v[i];
-  return 19;
-}
-static inline int coord_key(const HomographyCoord& c, double* k) {
-  for (int i = 0; i < 9; i++) k[i] = c.m[i];
-  return 9;
-}
-
 // the coordinate source the ring kernels read: maps as they are, sources given by value
 // through the coordinates the planning pass stored
 template <typename Coord> struct ring_kernel_coord {

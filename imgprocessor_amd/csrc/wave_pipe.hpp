@@ -99,6 +99,23 @@ template <int OFF> __device__ __forceinline__ void pipe_load1_masked(float& x, u
                : "v"(voff), "s"(sbase), "s"(m), "n"(OFF));
 }
 __device__ __forceinline__ void vm_pin(float& a) { asm volatile("; pin %0" : "+v"(a)); }
+// the same for tables of 8-byte entries (double coordinates stored by stored_coords.hpp)
+template <int OFF> __device__ __forceinline__ void pipe_load1(double& x, unsigned voff,
+                                                              const double* sbase) {
+  asm volatile(IPA_SGPR_HAZARD "global_load_dwordx2 %0, %1, %2 offset:%3" : "=v"(x) : "v"(voff), "s"(sbase), "n"(OFF));
+}
+template <int OFF> __device__ __forceinline__ void pipe_load1_masked(double& x, unsigned voff,
+                                                                     const double* sbase,
+                                                                     unsigned long long m) {
+  unsigned long long sv;
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, %4\n\t"
+               "global_load_dwordx2 %0, %2, %3 offset:%5\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(x), "=&s"(sv)
+               : "v"(voff), "s"(sbase), "s"(m), "n"(OFF));
+}
+__device__ __forceinline__ void vm_pin(double& a) { asm volatile("; pin %0" : "+v"(a)); }
 template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, unsigned voff,
                                                                float* sbase) {
   // (the s_nop: a VALU write of the data registers directly behind a 128-bit store needs one
@@ -617,14 +634,16 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
-  const unsigned voff = 16u * lane, moff = 4u * lane;
+  // (tables of float32 coordinates - maps - or of the 8-byte ones stored_coords.hpp keeps)
+  constexpr unsigned CB = sizeof(C);
+  const unsigned voff = 16u * lane, moff = CB * lane;
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
   const int yb = y0 - G::H;                          // first input row of the strip
   // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
   // filter's border mode per lane (c.uq, -1 = constant border), its rows per row on the scalar
   // unit; interior strips address the map rows as base + 4 lane + 256 k
-  const float* mxr = nullptr;
-  const float* myr = nullptr;
+  const C* mxr = nullptr;
+  const C* myr = nullptr;
   if constexpr (kTable) {
     mxr = src.coord.mx + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
     myr = src.coord.my + (EDGE ? 0 : (long)yb * src.coord.pitch + c.xs);
@@ -646,30 +665,30 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 
   // ---- producer: this wave's row of a block.  Table sources: the 8 map dwords (clamped to the
   // strip) into pm; the record is formed when they have arrived.
-  float pm[2 * NS] = {};
+  C pm[2 * NS] = {};
   auto issue_coords = [&](int r) {
     if constexpr (kTable) {
       if constexpr (EDGE) {
         const int rr = row_of(r < T ? r : T - 1);
         const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
 #pragma unroll
-        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
-        if constexpr (HALO) pipe_load1_masked<0>(pm[4], 4u * (unsigned)(c.uh < 0 ? 0 : c.uh), mxr + o, hmask);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], CB * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), mxr + o, hmask);
 #pragma unroll
-        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[NS + k], 4u * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
-        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], 4u * (unsigned)(c.uh < 0 ? 0 : c.uh), myr + o, hmask);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[NS + k], CB * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), myr + o, hmask);
       } else {
         const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          pipe_load1<256 * k>(pm[k], moff, mxr + o);
+          pipe_load1<64 * (int)CB * k>(pm[k], moff, mxr + o);
         });
-        if constexpr (HALO) pipe_load1_masked<0>(pm[4], 4u * hcol, mxr + o - G::H, hmask);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * hcol, mxr + o - G::H, hmask);
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          pipe_load1<256 * k>(pm[NS + k], moff, myr + o);
+          pipe_load1<64 * (int)CB * k>(pm[NS + k], moff, myr + o);
         });
-        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], 4u * hcol, myr + o - G::H, hmask);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], CB * hcol, myr + o - G::H, hmask);
       }
     }
   };

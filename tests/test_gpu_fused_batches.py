@@ -259,3 +259,36 @@ def test_sharded_runner_two_contexts_on_one_device(ia):
     assert runner.run(7, work7) == [4, 3]
     same_bits(out7, want[:7], 'ShardedRunner, 7 frames')
     assert ShardedRunner(devices=[0, 0, 0]).run(2, lambda c, a, b: (a, b)) == [(0, 1), (1, 2), None]
+
+
+@pytest.mark.parametrize('n', [4, 8, 7, 12])
+def test_homography_coordinates_stored_once_per_batch(ia, n):
+    """fused bilinear chains of a batch through a homography: the double coordinates are evaluated
+    once per (matrix, geometry) into the plan buffer and the record producers of the shared loop
+    read them as a table (csrc/stored_coords.hpp) - the bits of the per-pixel evaluation
+    (knob stored_coords = 0), for the dense and the separable chain, a second call on the cached
+    table, another matrix in between"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    for (h, w) in ((200, 1030), (333, 517)):
+        src = ctx.to_device(frames(n, h, w))
+        M1 = np.array([[0.98, 0.03, 4.0], [-0.02, 1.01, 2.5], [1e-5, -2e-5, 1.0]])
+        M2 = np.array([[1.05, -0.04, -7.0], [0.03, 0.97, 3.5], [-2e-5, 1e-5, 1.0]])
+        k = kern(5, 2)
+        g = np.exp(-0.5 * np.arange(-4, 5) ** 2)
+        g /= g.sum()
+        calls = {
+            'dense M1': lambda: ops.warp_perspective_conv2d(src, M1, (h, w), k),
+            'sep M1': lambda: ops.warp_perspective_sepconv2d(src, M1, (h, w), g, g),
+            'dense M2, smaller result': lambda: ops.warp_perspective_conv2d(src, M2, (h - 11, w - 6), k),
+            'sep M2, reflect border': lambda: ops.warp_perspective_sepconv2d(
+                src, M2, (h, w), g, g, 'linear', 'reflect'),
+        }
+        old = ctx.set_tuning(stored_coords=0)
+        try:
+            ref = {nm: fn().get() for nm, fn in calls.items()}
+        finally:
+            ctx.set_tuning(**old)
+        for rep in range(2):
+            for nm, fn in calls.items():
+                same_bits(fn().get(), ref[nm], 'stored coordinates: %s n=%d %r call %d' % (nm, n, (h, w), rep))
