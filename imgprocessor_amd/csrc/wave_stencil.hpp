@@ -287,8 +287,13 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     // wave_pipe.hpp for K <= 5 (K = 7 streams its coefficients: wave_stencil_big_kernel); the chunked loop is then the rim strips only: depth 1
     // kShared: batches share footprint records through LDS (any coordinate source);
     // kPiped: table sources, whose single frames run the hand-scheduled loop too
+    // (not float32 frames + 7x7 from a map pair: with 49 resident coefficients next to the
+    // two-dword tap rows and the map pointers that kernel overflowed its SGPR spill lanes into
+    // scratch memory - and scratch loads count in the hand-counted vmcnt waits; such batches run
+    // the streamed kernel of fused_big.hip anyway, knob stream_k)
     static constexpr bool kShared = IPA_PIPE && K <= IPA_PIPE_MAX_K && INTERP == kLinear &&
-                                    (std::is_same<ST, float>::value ||
+                                    ((std::is_same<ST, float>::value &&
+                                      (K <= 5 || !std::is_same<Coord, MapCoord>::value)) ||
                                      std::is_same<ST, uint16_t>::value);
     static constexpr bool kPiped = kShared && coord_is_table<Coord>::value && sizeof(C) == 4;
     static constexpr int value =

@@ -73,6 +73,8 @@ def main():
     Hq = np.append(np.linalg.solve(np.array(A), np.array(rhs)), 1.0).reshape(3, 3)
     g9 = np.exp(-0.5 * np.arange(-4, 5) ** 2)
     g9 /= g9.sum()
+    k7r = np.random.default_rng(123).random((7, 7))
+    k7r /= k7r.sum()
     k9 = np.random.default_rng(99).random((9, 9))
     k9 /= k9.sum()
     k11 = np.random.default_rng(321).random((11, 11))
@@ -95,6 +97,7 @@ def main():
                 mod.src = ctx.to_device(host)
                 mod.dst = ctx.empty((batch, h, w), np.float32)
                 mod.dmx, mod.dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
+                mod.u16 = ctx.to_device(np.round(host * 4095).astype(np.uint16)) if 'c4' in what else None
             else:
                 # the SAME device buffers for every build (one process, one device: a pointer of
                 # the first build's allocator is valid in the others) - where a buffer lands in
@@ -111,9 +114,11 @@ def main():
                     return v
                 mod.src, mod.dst = view(first.src), view(first.dst)
                 mod.dmx, mod.dmy = view(first.dmx), view(first.dmy)
+                mod.u16 = view(first.u16) if first.u16 is not None else None
         calls = {
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
             'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
+            'c4': lambda o=ops, m=mod: o.remap_conv2d(m.u16, m.dmx, m.dmy, k7r, out=m.dst),
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
             'cubic': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'cubic', out=m.dst),
             'c3cubic': lambda o=ops, m=mod: o.warp_perspective_sepconv2d(m.src, Hq, (h, w), g9, g9, 'cubic', out=m.dst),

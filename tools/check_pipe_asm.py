@@ -6,7 +6,8 @@ counted wait.  A forward "may be in flight" dataflow over the kernel's control-f
 blocks from the labels and branches of the assembly text), so loop back-edges and the branches
 around the border-aware sampler are followed.
 
-A kernel that carries such loops must not spill vector registers either (exit 1).
+A kernel that carries such loops must not spill vector registers either, nor contain flat / scratch
+accesses (they count in vmcnt) (exit 1).
 
     tools/check_pipe_asm.py file.s [name filter ...]       exit 1 on a violation
 """
@@ -75,6 +76,10 @@ def check(name, lines):
             continue
         code = t.split(';')[0].strip()
         op = code.split()[0]
+        # flat and scratch accesses count in vmcnt too (and complete out of order with it):
+        # neither may appear in a kernel whose waits are counted by hand
+        if op.startswith(('flat_', 'scratch_')):
+            unguarded.append((ln, 'counts in vmcnt behind the hand-counted waits: ' + code))
         if in_asm and op.startswith(('buffer_load', 'global_load')):
             dst = code.split()[1].rstrip(',')
             ins.append((ln, 'load', code, (regs_of(dst), regs_of(' '.join(code.split()[2:]))))); loop_of.append(cur_loop)
@@ -186,7 +191,8 @@ def check(name, lines):
     nload = sum(1 for x in ins if x[1] == 'load')
     npin = sum(1 for x in ins if x[1] == 'pin')
     for ln, t in unguarded:
-        bad.append((ln, 'vector-memory asm statement without the s_nop 4 hazard guard: ' + t, -1, ln))
+        bad.append((ln, t if t.startswith('counts in') else
+                    'vector-memory asm statement without the s_nop 4 hazard guard: ' + t, -1, ln))
     return bad, nload, npin
 
 
