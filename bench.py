@@ -180,11 +180,11 @@ def other_configs(ctx, ia, ops, budget_launches=60):
             e['note'] = note
         out.append(e)
 
-    def placed(shape, dtype, launch, candidates=4):
-        """result buffer of an HBM-bound configuration, chosen like the headline's (setup, not
-        measurement: Context.empty_placed, main() explains why)"""
-        return ctx.empty_placed(shape, dtype, lambda d: timed(ctx, lambda: launch(d), 5, 3),
-                                candidates)[0]
+    def placed(shape, dtype, launch=None):
+        """result buffer of a configuration: a plain Context.empty - blocks of 256 MiB and more
+        are placed by the context's block pool itself (device.py::_alloc_placed), like every
+        array a caller of the library allocates"""
+        return ctx.empty(shape, dtype)
 
     # C2: 1080p float32, radial undistort (maps) + 5x5 Gaussian, 1 GPU
     h, w, B = 1080, 1920, 64
@@ -321,9 +321,9 @@ def main():
     ap.add_argument('--height', type=int, default=H4K)
     ap.add_argument('--width', type=int, default=W4K)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
-    ap.add_argument('--placements', type=int, default=8,
-                    help='setup: candidate allocations per batch buffer, the one that streams '
-                         'fastest is kept (1 = take the first as it comes)')
+    ap.add_argument('--placements', type=int, default=0,
+                    help='candidate allocations per large block of the context pool (0 = the '
+                         "library's default, IMGPROC_HIP_PLACE; 1 = every allocation as it comes)")
     ap.add_argument('--no-settle', action='store_true',
                     help='skip the untimed clock-settling launches of the setup phase')
     ap.add_argument('--no-configs', action='store_true',
@@ -357,6 +357,8 @@ def main():
     from imgprocessor_amd import ops
     ndev = ia.device_count()
     ctx = ia.Context(local_rank % max(ndev, 1))
+    if args.placements > 0:
+        ctx._place_n = args.placements
     h, w, B = args.height, args.width, args.batch
     K, dcoef = camera(h, w)
     k5 = gauss5()
@@ -368,33 +370,16 @@ def main():
     d_tmp = ctx.empty((B, h, w), np.float32) if args.variant.startswith('two') else None
     dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
     ctx.synchronize()
-    # Setup, not measurement: WHERE a 2 GB batch buffer lands in physical memory moves this
-    # streaming kernel by up to 10 % on this part, per buffer and roughly additively (one
-    # allocation in four is "good"; tools/placement_probe4.py, profiles/r03_micro.txt: 0.98 -
-    # 1.09 ms over 4 x 4 source / result allocations of ONE process).  A service allocates its
-    # batch buffers once and keeps them, so it can afford what is done here: allocate
-    # --placements candidates per buffer, stream a few launches through each, keep the fastest
-    # source and the fastest result, free the rest.  Every candidate's time is reported
-    # (config.placement_*); --placements 1 takes the first allocation as it comes.
-    placement = None
-    if args.placements > 1 and args.variant.startswith('fused'):
-        def trial(s_, d_):
-            if args.variant == 'fused_map':
-                return timed(ctx, lambda: ops.remap_conv2d(s_, dmx, dmy, k5, out=d_), 8, 4)
-            return timed(ctx, lambda: ops.undistort_conv2d(s_, K, dcoef, K, k5, out=d_), 8, 4)
-        for _ in range(5):
-            trial(d_src, d_dst)                                   # clocks up from idle first
-        first = d_src
-        d_src, t_src = ctx.empty_placed((B, h, w), np.float32, lambda a: trial(a, d_dst),
-                                        args.placements, fill=lambda a: a.copy_from(first))
-        del first
-        d_dst, t_dst = ctx.empty_placed((B, h, w), np.float32, lambda a: trial(d_src, a),
-                                        args.placements)
-        placement = {'candidates': args.placements,
-                     'source_ms': [round(t, 4) for t in t_src],
-                     'source_kept': int(np.argmin(t_src)),
-                     'result_ms': [round(t, 4) for t in t_dst],
-                     'result_kept': int(np.argmin(t_dst))}
+    # WHERE a 2 GB batch buffer lands in physical memory moves this streaming kernel by up to 10 %
+    # on this part (a property of the allocation: profiles/r04_micro.txt).  Since round 4 the
+    # PRODUCT deals with it: the context's block pool chooses every block of 256 MiB and more
+    # among IMGPROC_HIP_PLACE candidate allocations (default 4) by a strip-shaped probe, once per
+    # block (device.py::_alloc_placed) - d_src / d_dst above were allocated that way, exactly as a
+    # caller's arrays are, and `config.buffer_placement` is the pool's own log.  --placements N
+    # overrides the candidate count for this run (1 = every allocation as it comes).
+    placement = {'by': 'Context block pool (product default: IMGPROC_HIP_PLACE=%d candidates per block '
+                       '>= 256 MiB, strip-shaped 3x3 probe)' % ctx._place_n,
+                 'candidates': ctx._place_n, 'blocks': list(ctx.placement_log)}
 
     px = B * h * w
     # bytes per launch.  `compulsory`: what must cross the HBM interface - source and result
@@ -497,6 +482,25 @@ def main():
         # (after the oracle check: it overwrites the result batch)
         copy_ms = timed(ctx, lambda: d_dst.copy_from(d_src), 20, 3)
         copy_gbs = 2.0 * d_src.nbytes / (copy_ms * 1e-3) / 1e9
+        # for reference: the same launches on a pair of buffers taken as the driver hands them out
+        # (placement off), allocated now - what a caller that bypasses the pool's choice would see
+        if args.variant.startswith('fused') and ctx._place_n > 1:
+            keep_n, ctx._place_n = ctx._place_n, 1
+            try:
+                s_raw = ctx.empty((B, h, w), np.float32)
+                d_raw = ctx.empty((B, h, w), np.float32)
+                s_raw.copy_from(d_src)
+                if args.variant == 'fused_map':
+                    raw_ms = timed(ctx, lambda: ops.remap_conv2d(s_raw, dmx, dmy, k5, out=d_raw), 20, 5)
+                else:
+                    raw_ms = timed(ctx, lambda: ops.undistort_conv2d(s_raw, K, dcoef, K, k5, out=d_raw), 20, 5)
+                placement['unplaced_pair_ms_per_step'] = round(raw_ms, 4)
+                del s_raw, d_raw
+                ctx.trim()
+            except MemoryError:
+                pass
+            finally:
+                ctx._place_n = keep_n
         line = {
             'metric': 'Mpix/s undistort+5x5 filter, 4K f32',
             'value': round(value, 1), 'unit': 'Mpix/s', 'n_gpus': world, 'steps': args.steps,
@@ -563,7 +567,16 @@ def main():
             line['other_configs'] = extra + other_configs(ctx, ia, ops)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(h, w, K, dcoef, k5)
+        # a result that is not the oracle's is not a measurement: say so in the line and fail
+        bad = checked is not None and not (checked['max_rel_err'] <= checked['tolerance'])
+        if bad:
+            line['invalid'] = ('result of the timed launches differs from the oracle: max relative '
+                               'error %.3g > %g' % (checked['max_rel_err'], checked['tolerance']))
         print(json.dumps(line))
+        if bad:
+            if dist_on:
+                dist.destroy_process_group()
+            sys.exit(1)
     if dist_on:
         dist.destroy_process_group()
 

@@ -42,6 +42,19 @@ class Context(object):
         self._pool_bytes = 0
         self._pool_limit = int(os.environ.get('IMGPROC_HIP_POOL_MB', '8192')) << 20
         self._pool_lock = threading.Lock()
+        # Placement of large blocks (round 4).  WHERE the driver puts a multi-GB batch buffer moves
+        # the strip-shaped streaming kernels of this library by up to 10 % on MI355X - a property
+        # of the allocation, not of the address inside it (profiles/r04_micro.txt: one offset is
+        # as good as another within an allocation; a linear copy does not see it at all; a plain
+        # 3x3 filter from one half of the block into the other does, and ranks the blocks like the
+        # fused kernel).  So a block of >= 256 MiB that the pool cannot serve is chosen among
+        # IMGPROC_HIP_PLACE candidate allocations (default 4; 1 = take the first) by that probe,
+        # ~1 ms per GiB and candidate, once per block - the pool hands it out again afterwards.
+        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '4')))
+        self._place_min = 256 << 20
+        self._place_max = 16 << 30
+        self._placing = False
+        self.placement_log = []   # one entry per placed block: nbytes, probe ms per candidate, kept
 
     # -- info -------------------------------------------------------------
     def device_info(self):
@@ -81,6 +94,12 @@ class Context(object):
             if blocks:
                 self._pool_bytes -= nbytes
                 return blocks.pop()
+        if (self._place_n > 1 and not self._placing and
+                self._place_min <= nbytes <= self._place_max):
+            return self._alloc_placed(nbytes)
+        return self._alloc_raw(nbytes)
+
+    def _alloc_raw(self, nbytes):
         p = C.c_void_p()
         try:
             self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
@@ -88,6 +107,60 @@ class Context(object):
             self.trim()  # give the pooled blocks back and retry once
             self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
         return p
+
+    def _alloc_placed(self, nbytes):
+        """the best of up to `_place_n` allocations of `nbytes` by `_probe_block`; the others go
+        back to the driver (all candidates are held until the choice is made: a freed one would
+        be handed out again)"""
+        self._placing = True
+        try:
+            cands, times = [], []
+            for _ in range(self._place_n):
+                try:
+                    p = self._alloc_raw(nbytes)
+                except MemoryError:
+                    if not cands:
+                        raise
+                    break   # out of device memory: choose among what there is
+                cands.append(p)
+                times.append(self._probe_block(p, nbytes))
+            best = int(np.argmin(times))
+            self.synchronize()
+            for i, p in enumerate(cands):
+                if i != best:
+                    self._lib.ipa_free(self.handle, p)
+            self.placement_log.append({'nbytes': int(nbytes), 'ms': [round(t, 4) for t in times],
+                                       'kept': best})
+            return cands[best]
+        finally:
+            self._placing = False
+
+    def _probe_block(self, ptr, nbytes):
+        """milliseconds of a plain 3x3 filter streaming the first half of the block into the
+        second (float32 rows of 3840 px, whatever the block will hold; the contents do not
+        matter): the strip-shaped access pattern of the hot kernels, reading and writing the
+        candidate"""
+        from . import ops
+        w = 3840
+        rows = (nbytes // 2) // (4 * w)
+
+        def view(off):
+            v = DeviceArray.__new__(DeviceArray)
+            v.ctx, v.shape, v.dtype, v.nbytes = self, (rows, w), np.dtype(np.float32), rows * w * 4
+            v.ptr = C.c_void_p(ptr.value + off)
+            v._owner = False
+            return v
+        lo, hi = view(0), view(rows * w * 4)
+        k3 = np.full((3, 3), 1.0 / 9)
+        for _ in range(2):
+            ops.conv2d(lo, k3, out=hi)
+        e0, e1 = self.event(), self.event()
+        e0.record()
+        for _ in range(4):
+            ops.conv2d(lo, k3, out=hi)
+        e1.record()
+        self.synchronize()
+        return e0.elapsed_ms(e1) / 4
 
     def _release(self, ptr, nbytes):
         if self.handle is None:

@@ -241,3 +241,33 @@ def test_empty_placed_keeps_the_fastest_candidate(ia):
     assert times == [3.0, 1.0, 2.0] and len(set(seen)) == 3
     assert a.ptr.value == seen[1] and a.shape == (3, 4)
     assert np.array_equal(a.get(), src.get())
+
+
+def test_large_blocks_are_placed_by_the_pool():
+    """device.py::_alloc_placed: a block of 256 MiB and more that the pool cannot serve is chosen
+    among several candidate allocations by a strip-shaped probe and logged; the pool hands the same
+    block out again; smaller blocks and contexts with one candidate take the first allocation"""
+    import imgprocessor_amd as ia
+    ctx = ia.Context(0)
+    try:
+        assert ctx._place_n >= 1 and ctx.placement_log == []
+        ctx._place_n = 3
+        small = ctx.empty((1024, 1024), np.float32)
+        assert ctx.placement_log == []
+        big = ctx.empty((72, 1024, 1024), np.float32)          # 288 MiB
+        assert len(ctx.placement_log) == 1
+        e = ctx.placement_log[0]
+        assert e['nbytes'] == big.nbytes and 1 <= len(e['ms']) <= 3 and 0 <= e['kept'] < len(e['ms'])
+        assert e['ms'][e['kept']] == min(e['ms']) and all(t > 0 for t in e['ms'])
+        ptr = big.ptr.value
+        big.set(np.ones(big.shape, np.float32))                 # the block is usable
+        assert float(big.frame(71).get()[5, 5]) == 1.0
+        del big
+        again = ctx.empty((72, 1024, 1024), np.float32)          # from the pool: the same block, no probe
+        assert again.ptr.value == ptr and len(ctx.placement_log) == 1
+        ctx._place_n = 1
+        other = ctx.empty((80, 1024, 1024), np.float32)
+        assert len(ctx.placement_log) == 1
+        del small, again, other
+    finally:
+        ctx.close()
