@@ -38,30 +38,44 @@ from .. import ops
 from ..device import DeviceArray
 from .LensDistortion import LensDistortion
 
-DATE_FORMAT = "%d %b %y - %H:%M"  # e.g. '30 Nov 15 - 13:20'  (:16)
+DATE_FORMAT = "%d %b %y - %H:%M"  # the reference's date strings, e.g. '30 Nov 15 - 13:20' (:16)
+
+# light-dependent sections of `coeffs` ({light: history}) and the plain histories; a history is a
+# list of entries [date, info, data(, error)] kept NEWEST FIRST (the order `.cal` files store)
+_BY_LIGHT = ('flat field', 'lens', 'psf', 'balance')
+_PLAIN = ('dark current', 'noise')
 
 
-def _toDate(date):
-    if date is None:
-        return time.localtime()
-    return time.strptime(date, DATE_FORMAT)
+def _stamp(date):
+    """time.struct_time of a date string in DATE_FORMAT; None = now"""
+    return time.localtime() if date is None else time.strptime(date, DATE_FORMAT)
 
 
-def _insertDateIndex(date, entries):
-    """index at which `date` keeps the newest-first order of `entries` (:29-34)"""
-    for i, e in enumerate(entries):
-        if e[0] < date:
-            return i
-    return len(entries)
+class _History(object):
+    """view of one newest-first entry list of `coeffs` (the list itself stays what is pickled)"""
 
+    def __init__(self, entries):
+        self.entries = entries
 
-def _getFromDate(entries, date):
-    """entry of the given or best fitting date (:37-49)"""
-    try:
-        i = _insertDateIndex(_toDate(date), entries) - 1
-        return entries[0] if i == -1 else entries[i]
-    except (ValueError, TypeError):
-        return entries[0]
+    def slot(self, stamp):
+        """position that keeps the order when an entry dated `stamp` is inserted (:29-34)"""
+        pos = 0
+        while pos < len(self.entries) and not self.entries[pos][0] < stamp:
+            pos += 1
+        return pos
+
+    def add(self, stamp, *fields):
+        self.entries.insert(self.slot(stamp), [stamp] + list(fields))
+
+    def at(self, date):
+        """the entry the reference picks for `date` (:37-49): the one in front of the insert
+        position of `date` (the nearest calibration that is not older), the newest entry when
+        `date` is None, unparsable or newer than everything stored"""
+        try:
+            pos = self.slot(time.strptime(date, DATE_FORMAT))
+        except (ValueError, TypeError):
+            return self.entries[0]
+        return self.entries[pos - 1 if pos > 0 else 0]
 
 
 class CameraCalibration(object):
@@ -70,194 +84,165 @@ class CameraCalibration(object):
     def __init__(self, ctx=None):
         self._ctx = ctx
         self.noise_level_function = None
-        self.coeffs = {
-            'name': 'no camera',
-            'depth': 16,
-            'light spectra': [],
-            'dark current': [],   # [[date, info, data, error], ...]
-            'flat field': {},     # {light: [[date, info, array, error], ...]}
-            'lens': {},           # {light: [[date, info, LensDistortion.coeffs], ...]}
-            'noise': [],
-            'psf': {},
-            'shape': None,
-            'balance': {},
-        }
+        self.coeffs = dict({'name': 'no camera', 'depth': 16, 'light spectra': [], 'shape': None},
+                           **{k: [] for k in _PLAIN}, **{k: {} for k in _BY_LIGHT})
         self.temp = {}
         self._lens_cache = {}
 
     # ------------------------------------------------------------ bookkeeping --
     @staticmethod
-    def _toDateStr(date_struct):
-        return time.strftime(DATE_FORMAT, date_struct)
-
-    @staticmethod
     def currentTime():
         return time.strftime(DATE_FORMAT)
 
-    def _getDate(self, typ, light):
-        d = self.coeffs[typ]
-        if type(d) is dict:
+    def setCamera(self, camera_name, bit_depth=16):
+        self.coeffs.update(name=camera_name, depth=bit_depth)
+
+    def _history(self, typ, light=None, create=False):
+        section = self.coeffs[typ]
+        if isinstance(section, dict):
             assert light is not None, 'need light spectrum given to access [%s]' % typ
-            d = d[light]
-        return d
+            if create:
+                if light not in self.coeffs['light spectra']:
+                    self.coeffs['light spectra'].append(light)
+                section.setdefault(light, [])
+            section = section[light]
+        return _History(section)
 
     def dates(self, typ, light=None):
         try:
-            return [self._toDateStr(c[0]) for c in self._getDate(typ, light)]
+            return [time.strftime(DATE_FORMAT, e[0]) for e in self._history(typ, light).entries]
         except KeyError:
             return []
 
     def infos(self, typ, light=None, date=None):
-        d = self._getDate(typ, light)
-        if date is None:
-            return [c[1] for c in d]
-        return _getFromDate(d, date)[1]
+        hist = self._history(typ, light)
+        return [e[1] for e in hist.entries] if date is None else hist.at(date)[1]
 
-    def _registerLight(self, light_spectrum):
-        if light_spectrum not in self.coeffs['light spectra']:
-            self.coeffs['light spectra'].append(light_spectrum)
-
-    def setCamera(self, camera_name, bit_depth=16):
-        self.coeffs['name'] = camera_name
-        self.coeffs['depth'] = bit_depth
-
-    def _checkShape(self, array):
-        if not isinstance(array, np.ndarray):
-            return
-        s = self.coeffs['shape']
-        if s is None:
-            self.coeffs['shape'] = array.shape
-        elif s[:2] != array.shape[:2]:
-            raise Exception('array shapes are different: stored(%s), given(%s)\n'
-                            'if shapes are transposed, execute self.transpose() once '
-                            % (s, array.shape))
-
-    def _insert(self, entries, date, entry):
-        entries.insert(_insertDateIndex(date, entries), entry)
+    def _adopt_shape(self, *arrays):
+        """the first array fixes the calibrated shape, every later one has to agree with it"""
+        for a in arrays:
+            if not isinstance(a, np.ndarray):
+                continue
+            known = self.coeffs['shape']
+            if known is None:
+                self.coeffs['shape'] = a.shape
+            elif tuple(known[:2]) != a.shape[:2]:
+                raise Exception('array shapes are different: stored(%s), given(%s)\n'
+                                'if shapes are transposed, execute self.transpose() once '
+                                % (known, a.shape))
 
     def addDarkCurrent(self, slope, intercept=None, date=None, info='', error=None):
-        date = _toDate(date)
-        self._checkShape(slope)
-        self._checkShape(intercept)
-        data = slope if intercept is None else (slope, intercept)
-        self._insert(self.coeffs['dark current'], date, [date, info, data, error])
+        self._adopt_shape(slope, intercept)
+        self._history('dark current').add(_stamp(date), info,
+                                          slope if intercept is None else (slope, intercept), error)
 
     def addNoise(self, nlf_coeff, date=None, info='', error=None):
-        date = _toDate(date)
-        self._insert(self.coeffs['noise'], date, [date, info, nlf_coeff, error])
-
-    def _add_light(self, name, light_spectrum, date, entry):
-        self._registerLight(light_spectrum)
-        f = self.coeffs[name]
-        self._insert(f.setdefault(light_spectrum, []), date, entry)
+        self._history('noise').add(_stamp(date), info, nlf_coeff, error)
 
     def addDeconvolutionBalance(self, balance, date=None, info='', light_spectrum='visible'):
-        date = _toDate(date)
-        self._add_light('balance', light_spectrum, date, [date, info, balance])
+        self._history('balance', light_spectrum, create=True).add(_stamp(date), info, balance)
 
     def addPSF(self, psf, date=None, info='', light_spectrum='visible'):
-        date = _toDate(date)
-        self._add_light('psf', light_spectrum, date, [date, info, psf])
+        self._history('psf', light_spectrum, create=True).add(_stamp(date), info, psf)
 
     def addFlatField(self, arr, date=None, info='', error=None, light_spectrum='visible'):
-        self._checkShape(arr)
-        date = _toDate(date)
-        self._add_light('flat field', light_spectrum, date, [date, info, arr, error])
+        self._adopt_shape(arr)
+        self._history('flat field', light_spectrum, create=True).add(_stamp(date), info, arr, error)
 
     def addLens(self, lens, date=None, info='', light_spectrum='visible'):
-        """lens: LensDistortion instance or the path of a saved one (:271-287)"""
-        date = _toDate(date)
+        """lens: a LensDistortion or the path of a saved one (:271-287); its coefficient dict is
+        what the calibration keeps"""
         if not isinstance(lens, LensDistortion):
-            ld = LensDistortion(ctx=self._ctx)
-            ld.readFromFile(lens)
-            lens = ld
-        self._add_light('lens', light_spectrum, date, [date, info, lens.coeffs])
+            path, lens = lens, LensDistortion(ctx=self._ctx)
+            lens.readFromFile(path)
+        self._history('lens', light_spectrum, create=True).add(_stamp(date), info, lens.coeffs)
 
     def clearOldCalibrations(self, date=None):
-        c = self.coeffs
-        c['dark current'] = [c['dark current'][-1]]
-        c['noise'] = [c['noise'][-1]]
-        for name in ('flat field', 'lens'):
-            for light in c[name]:
-                c[name][light] = [c[name][light][-1]]
+        """only the oldest entry of every history stays (:289-298)"""
+        for k in _PLAIN:
+            del self.coeffs[k][:-1]
+        for k in ('flat field', 'lens'):
+            for entries in self.coeffs[k].values():
+                del entries[:-1]
 
     def _correctPath(self, path):
         return path if path.endswith(self.ftype) else path + self.ftype
 
     @staticmethod
     def loadFromFile(path, ctx=None):
+        """a `.cal` file is the pickled `coeffs` dict (:305-316), python-2 pickles included"""
         cal = CameraCalibration(ctx=ctx)
-        path = cal._correctPath(path)
-        with open(path, 'rb') as f:
-            try:
-                d = pickle.load(f)
-            except UnicodeDecodeError:  # pickles written by python 2
-                f.seek(0)
-                d = pickle.load(f, encoding='latin1')
-        cal.coeffs.update(d)
+        with open(cal._correctPath(path), 'rb') as f:
+            blob = f.read()
+        try:
+            stored = pickle.loads(blob)
+        except UnicodeDecodeError:
+            stored = pickle.loads(blob, encoding='latin1')
+        cal.coeffs.update(stored)
         return cal
 
     def saveToFile(self, path):
         path = self._correctPath(path)
         with open(path, 'wb') as f:
-            pickle.dump(dict(self.coeffs), f, protocol=pickle.HIGHEST_PROTOCOL)
+            f.write(pickle.dumps(dict(self.coeffs), protocol=pickle.HIGHEST_PROTOCOL))
         return path
 
     def transpose(self):
-        """transpose every stored array of the calibrated shape (:324-349)"""
-        s = self.coeffs['shape']
-
-        def walk(item):
-            if type(item) == list:
-                for n, it in enumerate(item):
-                    if type(it) == tuple:
-                        it = item[n] = list(it)
-                    if type(it) == list:
-                        walk(it)
-                    if isinstance(it, np.ndarray) and it.shape == s:
-                        item[n] = it.T
-        for item in self.coeffs.values():
-            if type(item) == dict:
-                for sub in item.values():
-                    walk(sub)
-            else:
-                walk(item)
-        self.coeffs['shape'] = s[::-1]
+        """every stored array of the calibrated shape transposed, (slope, intercept) tuples turned
+        into lists on the way, the shape reversed (:324-349)"""
+        shape = self.coeffs['shape']
+        pending = [v for v in self.coeffs.values() if type(v) == list]
+        for section in self.coeffs.values():
+            if type(section) == dict:
+                pending.extend(section.values())
+        while pending:
+            seq = pending.pop()
+            if type(seq) != list:
+                continue
+            for i, v in enumerate(seq):
+                if type(v) == tuple:
+                    v = seq[i] = list(v)
+                if type(v) == list:
+                    pending.append(v)
+                elif isinstance(v, np.ndarray) and v.shape == shape:
+                    seq[i] = v.T
+        self.coeffs['shape'] = shape[::-1]
 
     def getCoeff(self, name, light=None, date=None):
-        """calibration entry for the light source, any other one if there is none (:583-604)"""
-        d = self.coeffs[name]
-        try:
-            c = d[light]
-        except KeyError:
-            try:
-                k, c = next(iter(d.items()))
-            except StopIteration:
-                return None
-            if light is not None:
-                print('no calibration found for [%s] - using [%s] instead' % (light, k))
-        except TypeError:
-            c = d  # not light dependent
-        return _getFromDate(c, date)
+        """the entry of `name` in force at `date` for `light` - for any other light (said so) when
+        there is none for it, None when the section is empty (:583-604)"""
+        section = self.coeffs[name]
+        if isinstance(section, dict):
+            if light not in section:
+                if not section:
+                    return None
+                other = next(iter(section))
+                if light is not None:
+                    print('no calibration found for [%s] - using [%s] instead' % (light, other))
+                light = other
+            section = section[light]
+        return _History(section).at(date)
 
     def calcDarkCurrent(self, exposuretime, date=None):
-        d = _getFromDate(self.coeffs['dark current'], date)
-        if type(d) == tuple:  # never true for the list entries addDarkCurrent stores (:509)
-            offs, ascent = d[2]
-            bg = offs + ascent * exposuretime
-            mx = 2 ** self.coeffs['depth'] - 1
-            with np.errstate(invalid='ignore'):
-                bg[bg > mx] = mx
-            return bg
-        return d[2]
+        entry = _History(self.coeffs['dark current']).at(date)
+        if type(entry) != tuple:
+            # what the reference's test on the ENTRY (:509) always yields for the lists
+            # addDarkCurrent stores: the data as they are, the (slope, intercept) model never run
+            return entry[2]
+        offset, ascent = entry[2]
+        limit = 2 ** self.coeffs['depth'] - 1
+        with np.errstate(invalid='ignore'):
+            return np.where(offset + ascent * exposuretime > limit, limit, offset + ascent * exposuretime)
 
     def getLens(self, light_spectrum, date):
-        d = self.getCoeff('lens', light_spectrum, date)
-        if d:
-            key = id(d[2])
-            if key not in self._lens_cache:  # keeps the device maps of a lens between frames
-                self._lens_cache[key] = LensDistortion(d[2], ctx=self._ctx)
-            return self._lens_cache[key]
+        entry = self.getCoeff('lens', light_spectrum, date)
+        if not entry:
+            return None
+        # one LensDistortion (and its device maps) per stored coefficient dict, kept between frames
+        key = id(entry[2])
+        if key not in self._lens_cache:
+            self._lens_cache[key] = LensDistortion(entry[2], ctx=self._ctx)
+        return self._lens_cache[key]
 
     # ----------------------------------------------------------------- correct --
     def correct(self, images, bgImages=None, exposure_time=None, light_spectrum=None,

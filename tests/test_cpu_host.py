@@ -202,7 +202,7 @@ def test_perspective_correction_host_side():
 
 def test_camera_calibration_host_side(tmp_path):
     """container, date lookup and .cal pickle round trip (CameraCalibration.py:60-322, 583-604)"""
-    from imgprocessor_amd.camera.CameraCalibration import CameraCalibration, _getFromDate
+    from imgprocessor_amd.camera.CameraCalibration import CameraCalibration, _History
     from imgprocessor_amd.camera.LensDistortion import LensDistortion
     cal = CameraCalibration()
     cal.setCamera('cam0', 12)
@@ -221,7 +221,7 @@ def test_camera_calibration_host_side(tmp_path):
     assert cal.getCoeff('flat field', 'visible', '15 Oct 15 - 00:00')[1] == 'old'
     assert cal.getCoeff('flat field', 'UV')[1] == 'new'        # falls back to the first light
     assert cal.getCoeff('psf', 'visible') is None
-    assert _getFromDate([['x']], 'not a date') == ['x']
+    assert _History([['x']]).at('not a date') == ['x']
     cal.addDarkCurrent(np.full((6, 8), 3.0), date='02 Nov 15 - 10:00')
     assert np.array_equal(cal.calcDarkCurrent(1.5), np.full((6, 8), 3.0))
     cal.addDarkCurrent(np.ones((6, 8)), np.zeros((6, 8)), date='03 Nov 15 - 10:00')
