@@ -48,9 +48,11 @@ class Context(object):
         # as good as another within an allocation; a linear copy does not see it at all; a plain
         # 3x3 filter from one half of the block into the other does, and ranks the blocks like the
         # fused kernel).  So a block of >= 256 MiB that the pool cannot serve is chosen among
-        # IMGPROC_HIP_PLACE candidate allocations (default 4; 1 = take the first) by that probe,
-        # ~1 ms per GiB and candidate, once per block - the pool hands it out again afterwards.
-        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '4')))
+        # IMGPROC_HIP_PLACE candidate allocations (default 8, at most 24 GiB of candidates at a
+        # time; 1 = take the first) by that probe, ~1 ms per GiB and candidate, once per block -
+        # the pool hands it out again afterwards.
+        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '8')))
+        self._place_bytes = 24 << 30
         self._place_min = 256 << 20
         self._place_max = 16 << 30
         self._placing = False
@@ -115,7 +117,7 @@ class Context(object):
         self._placing = True
         try:
             cands, times = [], []
-            for _ in range(self._place_n):
+            for _ in range(max(1, min(self._place_n, self._place_bytes // nbytes))):
                 try:
                     p = self._alloc_raw(nbytes)
                 except MemoryError:
