@@ -94,6 +94,8 @@ PROTOTYPES = {
     'ipa_circular_idw_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d, _d, _d, _d, _d],
     'ipa_cross_avg_fill_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _d],
     'ipa_cross_avg_fill': [_vp, _vp, _i, _vp, _i, _i, _i, _d],
+    'ipa_point_spread_idw_dev': [_vp, _vp, _i, _vp, _i, _i, _l, _i, _d, _l],
+    'ipa_point_spread_idw': [_vp, _vp, _i, _vp, _i, _i, _i, _d, _l],
     'ipa_resize_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _l, _i],
     'ipa_resize': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _i],
     'ipa_fast_filter_stat_dev': [_vp, _vp, _i, _i, _i, _l, _i, _i, _i, _vp],

@@ -2,6 +2,7 @@
 //   ipa_unstructured_idw*   interpolate/interpolate2dUnstructuredIDW.py:7-38
 //   ipa_circular_idw_fill*  interpolate/interpolateCircular2dStructuredIDW.py:7-69
 //   ipa_cross_avg_fill*     interpolate/interpolate2dStructuredCrossAvg.py:7-115
+//   ipa_point_spread_idw*   interpolate/interpolate2dStructuredPointSpreadIDW.py:7-141 (round 4)
 //
 // All three read only unmasked pixels and write only masked ones (the scattered-point fill
 // writes every pixel and reads none), so they run in place without a copy.  The arithmetic is
@@ -343,6 +344,115 @@ cross_fill_kernel(T* __restrict__ grid, const uint8_t* __restrict__ mask, int h,
   }
 }
 
+
+// ------------------------------------------------------------- point spread IDW --
+// interpolate/interpolate2dStructuredPointSpreadIDW.py.  _createBorder (:31-63) is a pair of
+// scans whose only state is "the previous pixel" - in raster order for the row scan, in column-major
+// order for the column scan, carried ACROSS the ends of rows / columns - and whose only effect
+// is to SET flags: every pixel can apply both rules by itself.
+__global__ void __launch_bounds__(256)
+ps_border_kernel(const uint8_t* __restrict__ mask, uint8_t* __restrict__ border, int gx, int gy,
+                 unsigned* __restrict__ any) {
+  const long n = (long)gx * gy;
+  const long p = (long)blockIdx.x * 256 + threadIdx.x;
+  bool found = false;
+  if (p < n) {
+    const int i = (int)(p / gy), j = (int)(p - (long)i * gy);
+    const uint8_t val = mask[p];
+    if (p > 0) {   // row-major predecessor: (i, j - 1), or the last pixel of the row above
+      const uint8_t last = mask[p - 1];
+      if (val != last) {
+        found = true;
+        if (val) border[p] = 1;
+        else border[(long)i * gy + (j > 0 ? j - 1 : gy - 1)] = 1;   // (index -1: the row's last pixel)
+      }
+    }
+    if (i > 0 || j > 0) {   // column-major predecessor: (i - 1, j), or the last pixel of column j - 1
+      const uint8_t last = i > 0 ? mask[p - gy] : mask[(long)(gx - 1) * gy + (j - 1)];
+      if (val != last) {
+        found = true;
+        if (val) border[p] = 1;
+        else border[(long)(i > 0 ? i - 1 : gx - 1) * gy + j] = 1;
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(found) != 0 && (threadIdx.x & 63) == 0) atomicOr(any, 1u);
+}
+
+// One sweep of _calc (:75-135): the border pixels in raster order, each filled from the unmasked
+// pixels of its window - the mask AS THE SWEEP HAS LEFT IT SO FAR - and then unmasked itself, so
+// a pixel depends on every border pixel before it inside its window and must not be overtaken by
+// a later one that would unmask a pixel it still has to see masked.  One workgroup of 16 waves:
+// wave w takes the rows w, w + 16, ... in order, its 64 lanes share a pixel's window; a pixel
+// (i, j) starts when each of the k rows above has finished its pixels left of the window's end + 1
+// (their progress, in LDS): what lies inside its window in those rows is final, and no pixel of a
+// row BELOW can have been filled inside it (that one waits for this row to pass ITS column + k).
+// The sums run over the lanes of a wave, not in the source's raster order: float64, equal to the
+// last bits only.
+template <typename T, int PW>
+__global__ void __launch_bounds__(1024)
+ps_sweep_kernel(T* grid, uint8_t* mask, uint8_t* border, int gx, int gy, long pitch, int k,
+                double half_power) {
+  IPA_NO_FMA
+  extern __shared__ int ps_prog[];
+  volatile int* prog = ps_prog;
+  for (int r = threadIdx.x; r < gx; r += 1024) ps_prog[r] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const volatile uint8_t* vmask = mask;
+  const volatile T* vgrid = grid;
+  for (int i = wave; i < gx; i += 16) {
+    for (int j0 = 0; j0 < gy; j0 += 64) {
+      const int jl = j0 + lane;
+      unsigned long long bits = __builtin_amdgcn_ballot_w64(jl < gy && border[(long)i * gy + jl] != 0);
+      while (bits) {
+        const int q = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int j = j0 + q;
+        const int xmn = i - k < 0 ? 0 : i - k, xmx = i + k > gx ? gx : i + k;
+        const int ymn = j - k < 0 ? 0 : j - k;
+        int ymx = j + k;
+        if (ymx > gx) ymx = gy;   // (as written: the column limit against the ROW count)
+        if (ymx > gy) ymx = gy;   // (out of bounds in the source)
+        // the rows above inside the window: finished left of the window's end + 1
+        const int need = ymx + 1 < gy ? ymx + 1 : gy;
+        for (int r0 = i - 1; r0 >= 0 && r0 >= i - k; r0 -= 64) {
+          const int r = r0 - lane;
+          for (;;) {
+            const bool ok = r < 0 || r < i - k || prog[r] >= need;
+            if (__builtin_amdgcn_ballot_w64(!ok) == 0) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        double sw = 0.0, sv = 0.0;
+        for (int xi = xmn; xi < xmx; xi++) {
+          const double dx2 = (double)((xi - i) * (xi - i));
+          for (int yi = ymn + lane; yi < ymx; yi += 64) {
+            if ((xi != i || yi != j) && vmask[(long)xi * gy + yi] == 0) {
+              const double wi = inv_dist_pow<PW>(dx2 + (double)((yi - j) * (yi - j)), half_power);
+              sw += wi;
+              sv += wi * (double)vgrid[(long)xi * pitch + yi];
+            }
+          }
+        }
+        sw = wsum(sw);
+        sv = wsum(sv);
+        if (sw != 0.0) {
+          if (lane == 0) {
+            grid[(long)i * pitch + j] = (T)(sv / sw);
+            border[(long)i * gy + j] = 0;
+            mask[(long)i * gy + j] = 0;
+          }
+          __threadfence();   // the fill is visible before the progress says so
+        }
+        if (lane == 0) prog[i] = j + 1;
+      }
+      if (lane == 0) prog[i] = j0 + 64 < gy ? j0 + 64 : gy;
+    }
+    if (lane == 0) prog[i] = gy;
+  }
+}
+
 }  // namespace ipa
 
 using namespace ipa;
@@ -507,6 +617,65 @@ int ipa_cross_avg_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask,
   if (rc) return rc;
   rc = ipa_cross_avg_fill_dev(ctx, dg, dtype, dm, h, w, w, ksize, power);
   if (rc) return rc;
+  return fill_back(ctx, grid, dg, gb);
+}
+
+int ipa_point_spread_idw_dev(ipa_ctx* ctx, void* d_grid, int dtype, uint8_t* d_mask, int h, int w,
+                             long pitch, int ksize, double power, long max_iter) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_grid && d_mask, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0 && pitch >= w && ksize >= 0, "bad shape/ksize");
+  IPA_REQUIRE(ctx, h <= 16000, "point spread IDW keeps one progress word per row in LDS: at most 16000 rows");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "point_spread_idw supports float32/float64 grids (got dtype %d)", dtype);
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t bb = up((size_t)h * w);
+  int rc = ipa_plan_reserve(ctx, bb + 256);
+  if (rc) return rc;
+  uint8_t* border = (uint8_t*)ctx->plan;
+  unsigned* any = (unsigned*)((char*)ctx->plan + bb);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  IPA_HIP(ctx, hipMemsetAsync(border, 0, bb + 256, ctx->stream));
+  const unsigned nb = (unsigned)(((long)h * w + 255) / 256);
+  const double hp = 0.5 * power;
+  const size_t lds = (size_t)h * sizeof(int);
+  for (long n = 0;; n++) {
+    // _createBorder; its return value decides whether another sweep runs
+    hipLaunchKernelGGL(ps_border_kernel, dim3(nb), dim3(256), 0, ctx->stream, d_mask, border, h, w, any);
+    unsigned found = 0;
+    IPA_HIP(ctx, hipMemcpyAsync(&found, any, sizeof(found), hipMemcpyDeviceToHost, ctx->stream));
+    IPA_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (!found || n >= max_iter) break;
+    IPA_HIP(ctx, hipMemsetAsync(any, 0, sizeof(unsigned), ctx->stream));
+#define IPA_PS_LAUNCH(T, PW)                                                                     \
+  hipLaunchKernelGGL((ps_sweep_kernel<T, PW>), dim3(1), dim3(1024), lds, ctx->stream, (T*)d_grid, \
+                     d_mask, border, h, w, pitch, ksize, hp)
+    if (dtype == IPA_F32) {
+      if (power == 2.0) IPA_PS_LAUNCH(float, 2);
+      else if (power == 1.0) IPA_PS_LAUNCH(float, 1);
+      else IPA_PS_LAUNCH(float, 0);
+    } else {
+      if (power == 2.0) IPA_PS_LAUNCH(double, 2);
+      else if (power == 1.0) IPA_PS_LAUNCH(double, 1);
+      else IPA_PS_LAUNCH(double, 0);
+    }
+#undef IPA_PS_LAUNCH
+  }
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+int ipa_point_spread_idw(ipa_ctx* ctx, void* grid, int dtype, uint8_t* mask, int h, int w,
+                         int ksize, double power, long max_iter) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, mask, "null mask");
+  char* dg; uint8_t* dm; size_t gb;
+  int rc = fill_host(ctx, grid, dtype, mask, h, w, &dg, &dm, &gb);
+  if (rc) return rc;
+  rc = ipa_point_spread_idw_dev(ctx, dg, dtype, dm, h, w, w, ksize, power, max_iter);
+  if (rc) return rc;
+  // the mask is modified too (filled pixels are unmasked)
+  IPA_HIP(ctx, hipMemcpyAsync(mask, dm, (size_t)h * w, hipMemcpyDeviceToHost, ctx->stream));
   return fill_back(ctx, grid, dg, gb);
 }
 

@@ -4,3 +4,4 @@ from .interpolate2dStructuredFastIDW import interpolate2dStructuredFastIDW  # no
 from .interpolate2dUnstructuredIDW import interpolate2dUnstructuredIDW  # noqa: F401
 from .interpolateCircular2dStructuredIDW import interpolateCircular2dStructuredIDW  # noqa: F401
 from .interpolate2dStructuredCrossAvg import interpolate2dStructuredCrossAvg  # noqa: F401
+from .interpolate2dStructuredPointSpreadIDW import interpolate2dStructuredPointSpreadIDW  # noqa: F401

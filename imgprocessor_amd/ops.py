@@ -784,6 +784,30 @@ def cross_avg_fill(grid, mask, ksize, power=2, ctx=None):
     return grid
 
 
+def point_spread_idw(grid, mask, ksize, power=2, max_iter=1e5, ctx=None):
+    """in-place point-spread IDW fill (interpolate2dStructuredPointSpreadIDW): grid AND mask are
+    modified - filled pixels are unmasked"""
+    ctx = _ctx_of(grid, mask, ctx=ctx)
+    it = int(min(max_iter, 2 ** 62))
+    if _is_dev(grid):
+        if not _is_dev(mask):
+            raise TypeError('device grid needs a device mask')
+        h, w = grid.shape
+        ctx._check(ctx._lib.ipa_point_spread_idw_dev(ctx.handle, grid.ptr, dtype_id(grid.dtype),
+                                                     mask.ptr, h, w, w, int(ksize), float(power), it),
+                   'point_spread_idw')
+        return grid
+    h, w = _fill_grid(grid)
+    if not (isinstance(mask, np.ndarray) and mask.flags.c_contiguous and mask.shape == grid.shape and
+            mask.dtype in (np.bool_, np.uint8)):
+        raise ValueError('mask must be a C-contiguous bool / uint8 array of the grid\'s shape '
+                         '(it is modified in place)')
+    ctx._check(ctx._lib.ipa_point_spread_idw(ctx.handle, _p(grid), dtype_id(grid.dtype),
+                                             _p(mask.view(np.uint8)), h, w, int(ksize), float(power),
+                                             it), 'point_spread_idw')
+    return grid
+
+
 # ------------------------------------------------------- fastFilter / fastMean --
 RESIZE_INTERP = {'linear': 1, 'cubic': 2, 'area': 3, 'lanczos4': 4, 1: 1, 2: 2, 3: 3, 4: 4}
 FAST_FILTER_FN = {'median': 0, 'nanmedian': 1, 'mean': 2, 'nanmean': 3}

@@ -388,6 +388,18 @@ int ipa_cross_avg_fill_dev(ipa_ctx* ctx, void* d_grid, int dtype, const uint8_t*
 int ipa_cross_avg_fill(ipa_ctx* ctx, void* grid, int dtype, const uint8_t* mask, int h, int w,
                        int ksize, double power);
 
+/* replaces interpolate/interpolate2dStructuredPointSpreadIDW.py:7-141 as written: sweeps over the
+ * border pixels of the masked areas (_createBorder :31-63: row and column scans that carry their
+ * previous value across row / column ends - index -1 marks the last pixel of the row / column),
+ * each filled in raster order from the unmasked pixels within [i-k, i+k) x [j-k, j+k) with weights
+ * 1 / distance^power and unmasked at once, so later pixels of the sweep see it (:75-135); repeated
+ * until a border pass finds no transition or max_iter sweeps have run.  In place on grid (F32 or
+ * F64) AND mask (filled pixels become 0). */
+int ipa_point_spread_idw_dev(ipa_ctx* ctx, void* d_grid, int dtype, uint8_t* d_mask, int h, int w,
+                             long pitch, int ksize, double power, long max_iter);
+int ipa_point_spread_idw(ipa_ctx* ctx, void* grid, int dtype, uint8_t* mask, int h, int w,
+                         int ksize, double power, long max_iter);
+
 /* ---------------------------------------------------------------- filters: fast* */
 /* replaces cv2.resize(img, (dw, dh), interpolation=...) at filters/fastFilter.py:47-48
  * (INTER_LANCZOS4 on the float64 grid of statistics) and filters/fastMean.py:14-19 (INTER_AREA

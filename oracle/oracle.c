@@ -23,6 +23,7 @@
  *                                                              -> orc_pos_to_intensity_unc
  *   - imgProcessor/interpolate/interpolate2dStructuredIDW.py:26-65      -> orc_idw
  *   - imgProcessor/interpolate/interpolate2dStructuredFastIDW.py:29-63  -> orc_fast_idw
+ *   - imgProcessor/interpolate/interpolate2dStructuredPointSpreadIDW.py:31-141 -> orc_point_spread_idw
  *   - imgProcessor/camera/LensDistortion.py:316-330,342-358 (cv2.remap,
  *     cv2.initUndistortRectifyMap)                             -> orc_remap, orc_build_undistort_map
  *   - imgProcessor/camera/PerspectiveCorrection.py:374-406 (cv2.warpPerspective)
@@ -1234,6 +1235,80 @@ static double cross_local_avg(const void* in, int dt, const uint8_t* mask, long 
         n++;
       }
   return val / (double)n;
+}
+
+/* interpolate/interpolate2dStructuredPointSpreadIDW.py:31-63 (_createBorder) and :65-141 (_calc),
+ * as written.  _createBorder: a row-major scan, then a column-major scan, each carrying its
+ * "previous value" ACROSS the ends of rows / columns; a masked pixel that follows an unmasked one
+ * becomes border, an unmasked pixel that follows a masked one marks ITS PREDECESSOR IN THE SAME
+ * ROW / COLUMN - index j - 1 (i - 1), which for j = 0 (i = 0) is numpy's -1: the last pixel of
+ * the row (column).  Flags are only ever set here.  _calc: sweeps over the border pixels in
+ * raster order, each filled from the unmasked pixels of its window [i-k, i+k) x [j-k, j+k) - the
+ * mask as the sweep has left it so far -, then unmasked itself; a sweep ends with a new border
+ * pass; the loop ends when a border pass finds no transition or after maxIter sweeps.  The
+ * column limit is clamped to gy only when it exceeds the ROW count gx (:89-90); where it would
+ * leave the array (gy < gx) it is clamped to the array here.  mask is modified. */
+static int ps_create_border(const uint8_t* mask, uint8_t* border, long gx, long gy) {
+  int any = 0;
+  uint8_t last = mask[0];
+  for (long i = 0; i < gx; i++)
+    for (long j = 0; j < gy; j++) {
+      uint8_t val = mask[i * gy + j];
+      if (val != last) {
+        if (val) border[i * gy + j] = 1;
+        else border[i * gy + (j > 0 ? j - 1 : gy - 1)] = 1;
+        any = 1;
+      }
+      last = val;
+    }
+  last = mask[0];
+  for (long j = 0; j < gy; j++)
+    for (long i = 0; i < gx; i++) {
+      uint8_t val = mask[i * gy + j];
+      if (val != last) {
+        if (val) border[i * gy + j] = 1;
+        else border[(i > 0 ? i - 1 : gx - 1) * gy + j] = 1;
+        any = 1;
+      }
+      last = val;
+    }
+  return any;
+}
+
+int orc_point_spread_idw(void* grid, int dt, uint8_t* mask, long gx, long gy, long kernel,
+                         double power, long max_iter) {
+  uint8_t* border = (uint8_t*)calloc((size_t)gx * gy, 1);
+  if (!border) return -1;
+  int any = ps_create_border(mask, border, gx, gy);
+  long n = 0;
+  while (n < max_iter && any) {
+    for (long i = 0; i < gx; i++)
+      for (long j = 0; j < gy; j++) {
+        if (!border[i * gy + j]) continue;
+        long xmn = i - kernel < 0 ? 0 : i - kernel, xmx = i + kernel > gx ? gx : i + kernel;
+        long ymn = j - kernel < 0 ? 0 : j - kernel, ymx = j + kernel;
+        if (ymx > gx) ymx = gy;
+        if (ymx > gy) ymx = gy; /* (out of bounds in the source) */
+        double sumWi = 0.0, value = 0.0;
+        for (long xi = xmn; xi < xmx; xi++)
+          for (long yi = ymn; yi < ymx; yi++)
+            if (!(xi == i && yi == j) && !mask[xi * gy + yi]) {
+              double d2 = (double)((xi - i) * (xi - i) + (yi - j) * (yi - j));
+              double wi = 1.0 / pow(d2, 0.5 * power);
+              sumWi += wi;
+              value += wi * load_px(grid, dt, xi * gy + yi);
+            }
+        if (sumWi != 0.0) {
+          store_px(grid, dt, i * gy + j, value / sumWi);
+          border[i * gy + j] = 0;
+          mask[i * gy + j] = 0;
+        }
+      }
+    any = ps_create_border(mask, border, gx, gy);
+    n++;
+  }
+  free(border);
+  return 0;
 }
 
 int orc_cross_avg(void* grid, int dt, const uint8_t* mask, long gx, long gy, long kernel,

@@ -420,6 +420,20 @@ def interpolateCircular2dStructuredIDW(grid, mask, kernel=15, power=2, fr=1, fph
     return grid
 
 
+def interpolate2dStructuredPointSpreadIDW(grid, mask, kernel=15, power=2, maxIter=1e5, copy=True):
+    """interpolate/interpolate2dStructuredPointSpreadIDW.py:7-141 (copy=False: grid and mask are
+    modified in place, as there)"""
+    assert grid.shape == mask.shape, 'grid and mask shape are different'
+    if copy:
+        grid, mask = grid.copy(), mask.copy()
+    assert grid.flags.c_contiguous and mask.flags.c_contiguous and mask.dtype == np.bool_
+    m = mask.view(np.uint8)
+    _chk(lib().orc_point_spread_idw(_p(grid), _dt(grid), _p(m), C.c_long(grid.shape[0]),
+                                    C.c_long(grid.shape[1]), C.c_long(kernel), C.c_double(power),
+                                    C.c_long(int(min(maxIter, 2 ** 62)))), 'point_spread_idw')
+    return grid
+
+
 def interpolate2dStructuredCrossAvg(grid, mask, kernel=15, power=2):
     """interpolate/interpolate2dStructuredCrossAvg.py:7-115 (in place, returns grid)"""
     assert grid.flags.c_contiguous

@@ -35,12 +35,19 @@ def install_shim():
     os.makedirs(os.path.join(d, 'numba'))
     with open(os.path.join(d, 'numba', '__init__.py'), 'w') as f:
         f.write(
+            "import types\n"
             "def _ident(*a, **k):\n"
-            "    if len(a) == 1 and callable(a[0]) and not k:\n"
+            "    if len(a) == 1 and isinstance(a[0], types.FunctionType) and not k:\n"
             "        return a[0]\n"
             "    return lambda fn: fn\n"
             "jit = njit = vectorize = guvectorize = _ident\n"
-            "boolean = bool\n")
+            "class _Sig(object):\n"
+            "    # a type name of a numba signature: boolean(boolean[:, :], boolean[:, :])\n"
+            "    def __getitem__(self, k):\n"
+            "        return self\n"
+            "    def __call__(self, *a, **k):\n"
+            "        return self\n"
+            "boolean = _Sig()\n")
     sys.path.insert(0, d)
     sys.path.insert(1, REF)
 
@@ -1039,8 +1046,53 @@ def gen_interp_more():
     np.savez_compressed(os.path.join(HERE, 'interp_more.npz'), **out)
 
 
+def gen_point_spread():
+    """point_spread.npz: interpolate2dStructuredPointSpreadIDW run from the reference's own source
+    (numba identity shim).  Its wrapper asks for ``np.bool``, which numpy >= 1.24 no longer has:
+    the alias is restored for the call, nothing else is touched.  Grids: square, and more columns
+    than rows (``if ymx > gx: ymx = gy`` compares the column limit with the ROW count: with
+    gy > gx the window then runs to the end of the row - defined behaviour; with gy < gx it could
+    leave the array - no such case here)."""
+    if not hasattr(np, 'bool'):
+        np.bool = bool
+    from imgProcessor.interpolate.interpolate2dStructuredPointSpreadIDW import \
+        interpolate2dStructuredPointSpreadIDW
+    out = {}
+    rng = np.random.default_rng(33)
+    for name, shape in (('sq', (48, 48)), ('wide', (40, 56))):
+        g = synth(shape, 12, np.float64) + np.linspace(0, 2, shape[1])[None, :]
+        m = rng.random(shape) < 0.3
+        m[14:30, 10:26] = True            # a bigger connected area: several sweeps
+        m[0, 0] = False
+        out['ps_grid_' + name] = g
+        out['ps_mask_' + name] = m
+        for kern, power in ((5, 2), (3, 1), (8, 3)):
+            out['ps_%s_k%d_p%d' % (name, kern, power)] = interpolate2dStructuredPointSpreadIDW(
+                g, m, kern, power)
+    # a mask that starts and ends rows on masked pixels: the scan's carry across row / column ends
+    # marks the LAST pixel of a row / column (border[i, -1]) - unmasked pixels get recomputed
+    g = synth((32, 32), 13, np.float64)
+    m = np.zeros((32, 32), bool)
+    m[5:9, 0:6] = True
+    m[12:20, 26:32] = True
+    m[0:4, 10:14] = True
+    m[28:32, 18:25] = True
+    out.update(ps_grid_edge=g, ps_mask_edge=m)
+    out['ps_edge_k4_p2'] = interpolate2dStructuredPointSpreadIDW(g, m, 4, 2)
+    g32 = out['ps_grid_sq'].astype(np.float32)
+    out['ps32_sq_k5_p2'] = interpolate2dStructuredPointSpreadIDW(g32, out['ps_mask_sq'], 5, 2)
+    # copy=False: grid and mask are modified in place
+    g, m = out['ps_grid_sq'].copy(), out['ps_mask_sq'].copy()
+    r = interpolate2dStructuredPointSpreadIDW(g, m, 5, 2, copy=False)
+    assert r is g and not m.any()
+    np.savez_compressed(os.path.join(HERE, 'point_spread.npz'), **out)
+
+
 if __name__ == '__main__':
     install_shim()
+    if sys.argv[1:] == ['point_spread']:
+        gen_point_spread()
+        sys.exit(0)
     if sys.argv[1:] == ['interp_more']:
         gen_interp_more()
         sys.exit(0)
@@ -1052,6 +1104,7 @@ if __name__ == '__main__':
         sys.exit(0)
     gen_stencils()
     gen_interp_more()
+    gen_point_spread()
     gen_fast_filter()
     gen_cv_resize()
     gen_remap_scipy()

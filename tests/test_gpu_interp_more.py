@@ -196,3 +196,55 @@ def test_vignetting_random_steps_warps(ia, oracle):
     ref = oracle.warp_perspective(src, np.eye(3), (8, 8), q5, oracle.CONSTANT, 0.0)
     assert np.array_equal(np.isnan(out), np.isnan(ref))
     assert np.isnan(out[3, 4]) and np.isnan(out[3, 3]) and np.isnan(out[2, 4])
+
+
+def test_point_spread_idw_golden_and_oracle(ia, oracle):
+    """interpolate2dStructuredPointSpreadIDW: against the reference's own output (point_spread.npz)
+    and, on larger grids with big holes, masked rims and more rows than 16 waves, against the oracle;
+    the sums run over the lanes of a wave instead of raster order: float64 within a few ulps, the
+    values a sweep leaves feed the next"""
+    from imgprocessor_amd.interpolate import interpolate2dStructuredPointSpreadIDW as psidw
+    g = load_golden('point_spread.npz')
+    for name in ('sq', 'wide'):
+        grid, mask = g['ps_grid_' + name], g['ps_mask_' + name]
+        for kern, power in ((5, 2), (3, 1), (8, 3)):
+            got = psidw(grid, mask, kern, power)
+            assert_close(got, g['ps_%s_k%d_p%d' % (name, kern, power)], 1e-11, 0,
+                         'golden %s k%d p%d' % (name, kern, power))
+        assert mask.any()
+    got = psidw(g['ps_grid_edge'], g['ps_mask_edge'], 4, 2)
+    assert_close(got, g['ps_edge_k4_p2'], 1e-11, 0, 'golden edge')
+    got = psidw(g['ps_grid_sq'].astype(np.float32), g['ps_mask_sq'], 5, 2)
+    assert got.dtype == np.float32
+    assert_close(got, g['ps32_sq_k5_p2'], 2e-6, 0, 'golden float32')
+    gr, m = g['ps_grid_sq'].copy(), g['ps_mask_sq'].copy()
+    r = psidw(gr, m, 5, 2, copy=False)
+    assert r is gr and not m.any()
+    assert_close(gr, g['ps_sq_k5_p2'], 1e-11, 0, 'in place')
+    rng = np.random.default_rng(4)
+    for (h, w, k, power, dens) in ((150, 210, 15, 2, 0.2), (96, 96, 4, 1, 0.6), (70, 300, 70, 3, 0.1),
+                                   (40, 64, 2, 2.5, 0.9)):
+        grid = rng.random((h, w)) + np.linspace(5, 10, w)[None, :]
+        mask = rng.random((h, w)) < dens
+        mask[h // 4:3 * h // 4, w // 4:3 * w // 4] = True
+        mask[0, 0] = False
+        mask[:, -1] |= rng.random(h) < 0.5     # rows that end masked / unmasked: the -1 quirk
+        mask[-1, :] |= rng.random(w) < 0.5
+        for dt, tol in ((np.float64, 1e-10), (np.float32, 3e-6)):
+            got = psidw(grid.astype(dt), mask, k, power)
+            want = oracle.interpolate2dStructuredPointSpreadIDW(grid.astype(dt), mask, k, power)
+            assert_close(got, want, tol, 0, 'point spread %s %s' % ((h, w, k, power), dt.__name__))
+    # device arrays, limited sweeps: the mask that is left matches the oracle's
+    ctx = ia.default_context(0)
+    grid = rng.random((120, 160))
+    mask = np.zeros((120, 160), bool)
+    mask[30:90, 40:120] = True
+    dg, dm = ctx.to_device(grid), ctx.to_device(mask.view(np.uint8))
+    out = psidw(dg, dm, 6, 2, maxIter=3, copy=False)
+    wg, wm = grid.copy(), mask.copy()
+    oracle.interpolate2dStructuredPointSpreadIDW(wg, wm, 6, 2, maxIter=3, copy=False)
+    assert out is dg and np.array_equal(dm.get().astype(bool), wm) and wm.any()
+    assert_close(dg.get(), wg, 1e-10, 0, 'three sweeps')
+    # nothing masked / everything masked: nothing happens
+    assert np.array_equal(psidw(grid, np.zeros_like(mask), 5, 2), grid)
+    assert np.array_equal(psidw(grid, np.ones_like(mask), 5, 2), grid)
