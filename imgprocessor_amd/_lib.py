@@ -71,6 +71,7 @@ PROTOTYPES = {
     'ipa_closest_distance_dev': [_vp, _vp, _i, _i, _l, _i, _vp, _i, _l],
     'ipa_pos_intensity_unc_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _d, _d, _i, _vp, _l],
     'ipa_median_threshold_dev': [_vp, _vp, _i, _i, _i, _l, _d, _i, _vp, _l, _vp, _l],
+    'ipa_median_threshold_size_dev': [_vp, _vp, _i, _i, _i, _l, _i, _d, _i, _vp, _l, _vp, _l],
     'ipa_calib_prefilter_dev': [_vp, _vp, _i, _vp, _vp, _i, _i, _l, _l, _l, _d, _vp, _l],
     'ipa_remap_conv2d_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _vp, _l, _dp, _i, _i, _vp, _i, _i,
                              _i, _l, _i, _l, _l, _i, _i, _d, _i, _i],

@@ -795,6 +795,57 @@ median_threshold_kernel(const T* __restrict__ img, const T* __restrict__ bg,
   if (indices) indices[(long)y * ipitch + x] = hit ? 1 : 0;
 }
 
+// filters/medianThreshold.py:7-30 with ANY size (round 4): scipy.ndimage.median_filter(img,
+// size) = the element of rank size*size / 2 of the size x size window at offsets -size/2 ..
+// size - 1 - size/2, edge pixels repeated ('reflect').  A block of 64 x 4 outputs stages its
+// window tile in LDS once; every lane then finds ITS window's rank element by counting: the
+// candidate v is the answer when (values < v) <= rank < (values <= v) - what sorting would put at
+// that rank, for any size, without a size-specific selection network (3x3 keeps its own).
+template <typename T>
+__global__ void __launch_bounds__(256)
+median_threshold_any_kernel(const T* __restrict__ img, int h, int w, long pitch, int size,
+                            double threshold, int cond_less, T* __restrict__ out, long opitch,
+                            unsigned char* __restrict__ indices, long ipitch) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char mt_lds[];
+  T* tile = reinterpret_cast<T*>(mt_lds);
+  const int lo = size / 2, TW = 64 + size - 1, TH = 4 + size - 1, TP = TW | 1;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int e = tid; e < TW * TH; e += 256) {
+    const int ty = e / TW, tx = e - ty * TW;
+    const int yy = resolve_idx(y0 + ty - lo, h, IPA_BORDER_REFLECT);
+    const int xx = resolve_idx(x0 + tx - lo, w, IPA_BORDER_REFLECT);
+    tile[ty * TP + tx] = img[(long)yy * pitch + xx];
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x, y = y0 + threadIdx.y;
+  if (x >= w || y >= h) return;
+  const T* win = tile + threadIdx.y * TP + threadIdx.x;   // window origin of this pixel
+  const T a = win[lo * TP + lo];
+  const int rank = (size * size) / 2;
+  T blur = a;
+  bool found = false;
+  for (int cy = 0; cy < size && !found; cy++)
+    for (int cx = 0; cx < size && !found; cx++) {
+      const T v = win[cy * TP + cx];
+      int less = 0, leq = 0;
+      for (int by = 0; by < size; by++)
+        for (int bx = 0; bx < size; bx++) {
+          const T u = win[by * TP + bx];
+          less += u < v ? 1 : 0;
+          leq += u <= v ? 1 : 0;
+        }
+      if (less <= rank && rank < leq) {
+        blur = v;
+        found = true;
+      }
+    }
+  const double rel = fabs(((double)a - (double)blur) / (double)blur);
+  const bool hit = cond_less ? rel < threshold : rel > threshold;
+  out[(long)y * opitch + x] = hit ? blur : a;
+  if (indices) indices[(long)y * ipitch + x] = hit ? 1 : 0;
+}
+
 }  // namespace ipa
 
 using namespace ipa;
@@ -841,6 +892,41 @@ int ipa_median_threshold_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, 
   IPA_REQUIRE(ctx, threshold > 0, "threshold must be > 0 (the reference returns the input as is)");
   return median_threshold_launch(ctx, d_img, dtype, nullptr, nullptr, false, h, w, pitch, 0, 0,
                                  threshold, cond_less, d_out, out_pitch, d_indices, idx_pitch);
+}
+
+int ipa_median_threshold_size_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w,
+                                  long pitch, int size, double threshold, int cond_less,
+                                  void* d_out, long out_pitch, unsigned char* d_indices,
+                                  long idx_pitch) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, threshold > 0, "threshold must be > 0 (the reference returns the input as is)");
+  IPA_REQUIRE(ctx, size >= 1, "size must be >= 1");
+  if (size == 3)
+    return median_threshold_launch(ctx, d_img, dtype, nullptr, nullptr, false, h, w, pitch, 0, 0,
+                                   threshold, cond_less, d_out, out_pitch, d_indices, idx_pitch);
+  IPA_REQUIRE(ctx, d_img && d_out, "null pointer");
+  IPA_REQUIRE(ctx, h > 0 && w > 0, "empty image");
+  IPA_REQUIRE(ctx, pitch >= w && out_pitch >= w && (!d_indices || idx_pitch >= w),
+              "pitch smaller than width");
+  IPA_REQUIRE(ctx, d_img != d_out, "the median cannot run in place");
+  if (dtype != IPA_F32 && dtype != IPA_F64)
+    IPA_UNSUPPORTED(ctx, "median threshold supports float32/float64 (got dtype %d)", dtype);
+  const size_t es = dtype == IPA_F32 ? 4 : 8;
+  const size_t lds = (size_t)(4 + size - 1) * ((64 + size - 1) | 1) * es;
+  if (lds > 64 * 1024)
+    IPA_UNSUPPORTED(ctx, "median threshold: a %dx%d window does not fit the LDS tile", size, size);
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(64, 4);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  if (dtype == IPA_F32)
+    hipLaunchKernelGGL((median_threshold_any_kernel<float>), grid, block, lds, ctx->stream,
+                       (const float*)d_img, h, w, pitch, size, threshold, cond_less, (float*)d_out,
+                       out_pitch, d_indices, idx_pitch);
+  else
+    hipLaunchKernelGGL((median_threshold_any_kernel<double>), grid, block, lds, ctx->stream,
+                       (const double*)d_img, h, w, pitch, size, threshold, cond_less,
+                       (double*)d_out, out_pitch, d_indices, idx_pitch);
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
 }
 
 int ipa_calib_prefilter_dev(ipa_ctx* ctx, const void* d_img, int dtype, const void* d_bg,

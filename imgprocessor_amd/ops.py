@@ -475,8 +475,8 @@ def pos_intensity_unc(image, sx, sy, ksize, ctx=None):
     return d_out if dev else d_out.get()
 
 
-def median_threshold(img, threshold=0.1, condition='>', want_indices=True, ctx=None):
-    """filters/medianThreshold.py:7-30 (size=3): -> (out, indices) new arrays"""
+def median_threshold(img, threshold=0.1, condition='>', want_indices=True, ctx=None, size=3):
+    """filters/medianThreshold.py:7-30: -> (out, indices) new arrays"""
     if condition not in ('>', '<'):
         raise ValueError("condition must be '>' or '<'")
     dev = _is_dev(img)
@@ -487,8 +487,11 @@ def median_threshold(img, threshold=0.1, condition='>', want_indices=True, ctx=N
     h, w = d_img.shape
     d_out = DeviceArray(ctx, (h, w), d_img.dtype)
     d_idx = DeviceArray(ctx, (h, w), np.uint8) if want_indices else None
-    ctx._check(ctx._lib.ipa_median_threshold_dev(
-        ctx.handle, d_img.ptr, dtype_id(d_img.dtype), h, w, w, float(threshold),
+    size = int(size)
+    if size < 1:
+        raise ValueError('size must be >= 1')
+    ctx._check(ctx._lib.ipa_median_threshold_size_dev(
+        ctx.handle, d_img.ptr, dtype_id(d_img.dtype), h, w, w, size, float(threshold),
         int(condition == '<'), d_out.ptr, w, d_idx.ptr if want_indices else None, w),
         'median_threshold')
     if dev:

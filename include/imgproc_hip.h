@@ -262,6 +262,13 @@ int ipa_pos_intensity_unc_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h,
 int ipa_median_threshold_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w, long pitch,
                              double threshold, int cond_less, void* d_out, long out_pitch,
                              unsigned char* d_indices, long idx_pitch);
+/* the same for any window size (filters/medianThreshold.py:7-30 passes `size` to
+ * scipy.ndimage.median_filter): blur = the element of rank size*size/2 of the size x size window
+ * at offsets -size/2 .. size-1-size/2, edge pixels repeated; size = 3 takes the kernel above. */
+int ipa_median_threshold_size_dev(ipa_ctx* ctx, const void* d_img, int dtype, int h, int w,
+                                  long pitch, int size, double threshold, int cond_less,
+                                  void* d_out, long out_pitch, unsigned char* d_indices,
+                                  long idx_pitch);
 
 /* replaces stages 2-4 of CameraCalibration.correct (camera/CameraCalibration.py:416-437) in one
  * pass over the frame:

@@ -1012,23 +1012,49 @@ static double median3x3(const void* img, int dt, long h, long w, long y, long x)
   return v[4];
 }
 
-/* filters/medianThreshold.py:7-30 with size=3: blur = float64(median3x3); indices =
+/* scipy.ndimage.median_filter(img, size=n): the element of rank n*n/2 of the n x n window at
+ * offsets -n/2 .. n-1-n/2 (scipy's origin rule for even sizes), edge pixels repeated */
+static double median_nxn(const void* img, int dt, long h, long w, long y, long x, int n, double* v) {
+  int c = 0;
+  const long lo = n / 2;
+  for (long dy = -lo; dy < n - lo; dy++)
+    for (long dx = -lo; dx < n - lo; dx++)
+      v[c++] = load_px(img, dt, resolve_idx(y + dy, h, ORC_REFLECT) * w +
+                                    resolve_idx(x + dx, w, ORC_REFLECT));
+  for (int i = 1; i < c; i++) { /* insertion sort */
+    double t = v[i];
+    int j = i - 1;
+    while (j >= 0 && v[j] > t) { v[j + 1] = v[j]; j--; }
+    v[j + 1] = t;
+  }
+  return v[c / 2];
+}
+
+/* filters/medianThreshold.py:7-30: blur = float64(median_filter(img, size)); indices =
  * |(img - blur) / blur| > threshold ('<' when cond_less); out = indices ? blur : img.
  * IEEE semantics as numpy under errstate(ignore): blur == 0 gives inf (replaced for '>') or
  * NaN (0/0: comparison false, kept).  indices may be NULL. */
-int orc_median_threshold(const void* img, int dt, long h, long w, double threshold, int cond_less,
-                         void* out, uint8_t* indices) {
+int orc_median_threshold_size(const void* img, int dt, long h, long w, int size, double threshold,
+                              int cond_less, void* out, uint8_t* indices) {
   if (dt != ORC_F32 && dt != ORC_F64) return -2;
+  if (size < 1 || size > 64) return -3;
 #pragma omp parallel for num_threads(g_threads) schedule(static)
-  for (long y = 0; y < h; y++)
+  for (long y = 0; y < h; y++) {
+    double v[64 * 64];
     for (long x = 0; x < w; x++) {
-      double a = load_px(img, dt, y * w + x), blur = median3x3(img, dt, h, w, y, x);
+      double a = load_px(img, dt, y * w + x);
+      double blur = size == 3 ? median3x3(img, dt, h, w, y, x) : median_nxn(img, dt, h, w, y, x, size, v);
       double rel = fabs((a - blur) / blur);
       int hit = cond_less ? rel < threshold : rel > threshold;
       if (indices) indices[y * w + x] = (uint8_t)hit;
       store_px(out, dt, y * w + x, hit ? blur : a);
     }
+  }
   return 0;
+}
+int orc_median_threshold(const void* img, int dt, long h, long w, double threshold, int cond_less,
+                         void* out, uint8_t* indices) {
+  return orc_median_threshold_size(img, dt, h, w, 3, threshold, cond_less, out, indices);
 }
 
 /* camera/CameraCalibration.py:416-437 (stages 2-4 of correct()): image -= bg (:505);

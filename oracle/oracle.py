@@ -49,7 +49,7 @@ def lib():
                      'orc_conv_ydep', 'orc_std2d', 'orc_idw', 'orc_fast_idw',
                      'orc_remap_conv2d', 'orc_masked_mean', 'orc_nan_max',
                      'orc_masked_median',
-                     'orc_median_threshold', 'orc_calib_prefilter', 'orc_closest_distance',
+                     'orc_median_threshold', 'orc_median_threshold_size', 'orc_calib_prefilter', 'orc_closest_distance',
                      'orc_pos_to_intensity_unc'):
             getattr(_LIB, name).restype = C.c_int
     return _LIB
@@ -294,17 +294,16 @@ def nan_maximum_filter(arr, ksize):
 
 
 def medianThreshold(img, threshold=0.1, size=3, condition='>', copy=True):
-    """filters/medianThreshold.py:7-30 (size=3 only) -> (img, indices)"""
-    assert size == 3
+    """filters/medianThreshold.py:7-30 -> (img, indices)"""
     if not threshold > 0:
         return img, None
     src = np.ascontiguousarray(img)
     out = np.empty_like(src)
     idx = np.empty(src.shape, np.uint8)
-    _chk(lib().orc_median_threshold(_p(src), _dt(src), C.c_long(src.shape[0]),
-                                    C.c_long(src.shape[1]), C.c_double(threshold),
-                                    C.c_int(condition != '>'), _p(out), _p(idx)),
-         'median_threshold')
+    _chk(lib().orc_median_threshold_size(_p(src), _dt(src), C.c_long(src.shape[0]),
+                                         C.c_long(src.shape[1]), C.c_int(int(size)),
+                                         C.c_double(threshold), C.c_int(condition != '>'), _p(out),
+                                         _p(idx)), 'median_threshold')
     if copy:
         return out, idx.astype(bool)
     img[...] = out

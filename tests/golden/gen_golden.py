@@ -256,6 +256,10 @@ def gen_stencils():
     z[21, 31] = 1.0
     out['img_zero'] = z
     out['out_zero'], out['ind_zero'] = medianThreshold(z, 0.1)
+    # other window sizes (round 4): odd, even (scipy shifts the window's origin), larger
+    for size in (5, 4, 2, 7, 9):
+        out['out_s%d' % size], out['ind_s%d' % size] = medianThreshold(a, 0.1, size=size)
+    out['out32_s5'], out['ind32_s5'] = medianThreshold(a32, 0.1, size=5)
     # CameraCalibration.correct stages 2-4 as written at camera/CameraCalibration.py:505
     # (image -= bg), :527-528 (image[i] /= d[i], i = d != 0), :566-567 (nan_to_num, then the
     # reference's medianThreshold in place).  The module itself needs cv2 to import, so the three

@@ -433,8 +433,16 @@ def test_median_threshold_golden(ia, oracle):
     assert medianThreshold(img, 0.1, copy=False)[0] is img
     assert np.array_equal(img, g['out_thr0p1_gt'])
     assert medianThreshold(img, 0.0) == (img, None)
+    # any window size (round 4): odd, even (scipy's shifted origin), larger - the reference's output
+    for size in (5, 4, 2, 7, 9):
+        out, ind = medianThreshold(g['img'], 0.1, size=size)
+        assert np.array_equal(out, g['out_s%d' % size]), size
+        assert np.array_equal(ind, g['ind_s%d' % size]), size
+    out, ind = medianThreshold(g['img'].astype(np.float32), 0.1, size=5)
+    assert out.dtype == np.float32 and np.array_equal(out, g['out32_s5'])
+    assert np.array_equal(ind, g['ind32_s5'])
     with pytest.raises(NotImplementedError):
-        medianThreshold(img, 0.1, size=5)
+        medianThreshold(img, 0.1, size=(3, 5))
     # ragged sizes (tile edges in both directions) against the oracle, device arrays
     big = 0.2 + synth((203, 391), 5, np.float64)
     big[::7, ::11] *= 4
@@ -442,6 +450,10 @@ def test_median_threshold_golden(ia, oracle):
     dout, dind = medianThreshold(d, 0.2)
     want, wind = oracle.medianThreshold(big, 0.2)
     assert np.array_equal(dout.get(), want) and np.array_equal(dind.get().astype(bool), wind)
+    for size in (5, 6, 11):
+        dout, dind = medianThreshold(d, 0.2, size=size)
+        want, wind = oracle.medianThreshold(big, 0.2, size=size)
+        assert np.array_equal(dout.get(), want) and np.array_equal(dind.get().astype(bool), wind), size
     one = synth((1, 5), 1, np.float32) + 0.5  # single row: every vertical neighbour is the row
     assert np.array_equal(medianThreshold(one, 0.01)[0], oracle.medianThreshold(one, 0.01)[0])
 

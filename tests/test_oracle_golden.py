@@ -124,6 +124,11 @@ def test_median_threshold_and_calibration_stages(oracle):
     assert oracle.medianThreshold(img, 0.1, copy=False)[0] is img
     assert np.array_equal(img, g['out_thr0p1_gt'])
     assert oracle.medianThreshold(img, 0.0) == (img, None)
+    for size in (5, 4, 2, 7, 9):   # other window sizes, even ones with scipy's shifted origin
+        out, ind = oracle.medianThreshold(g['img'], 0.1, size=size)
+        assert np.array_equal(out, g['out_s%d' % size]) and np.array_equal(ind, g['ind_s%d' % size])
+    out, ind = oracle.medianThreshold(g['img'].astype(np.float32), 0.1, size=5)
+    assert np.array_equal(out, g['out32_s5']) and np.array_equal(ind, g['ind32_s5'])
     for thr, key in ((0.1, 'cal_out_thr0p1'), (0.0, 'cal_out_thr0p0')):
         got = oracle.calib_prefilter(g['cal_raw'], g['cal_bg'], g['cal_ff'], thr)
         assert np.array_equal(got, g[key], equal_nan=True), key
