@@ -25,6 +25,7 @@ _dp = C.POINTER(C.c_double)
 PROTOTYPES = {
     'ipa_version': [],
     'ipa_device_count': [C.POINTER(_i)],
+    'ipa_device_pci_bus_id': [_i, C.c_char_p, C.c_size_t],
     'ipa_ctx_create': [_i, C.POINTER(_vp)],
     'ipa_ctx_destroy': [_vp],
     'ipa_ctx_synchronize': [_vp],

@@ -355,6 +355,13 @@ int ipa_resize_dev(ipa_ctx* ctx, const void* d_src, int dtype, int sh, int sw, l
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   IPA_HIP(ctx, hipSetDevice(ctx->device));
   dim3 block(256), grid((unsigned)((dw + 255) / 256), (unsigned)dh);
+  // OpenCV's rule (resize.cpp): INTER_LINEAR at an exact 2 x 2 reduction IS the area average
+  // ("interpolation == INTER_LINEAR && is_area_fast && iscale_x == 2 && iscale_y == 2")
+  if (interp == IPA_RESIZE_LINEAR && sw == 2 * dw && sh == 2 * dh) interp = IPA_RESIZE_AREA;
+  if (interp != IPA_RESIZE_LINEAR && interp != IPA_RESIZE_CUBIC && interp != IPA_RESIZE_AREA &&
+      interp != IPA_RESIZE_LANCZOS4)
+    IPA_UNSUPPORTED(ctx, "resize: interpolation %d is not built (linear 1, cubic 2, area 3, "
+                         "lanczos4 4; INTER_NEAREST and the exact / bit-exact variants are not)", interp);
   if (interp == IPA_RESIZE_AREA) {
     if (!(scale_x >= 1 && scale_y >= 1))
       IPA_UNSUPPORTED(ctx, "INTER_AREA is built for downscaling (OpenCV switches to a bilinear "

@@ -173,6 +173,12 @@ int ipa_ctx_synchronize(ipa_ctx* c) {
   return IPA_OK;
 }
 
+int ipa_device_pci_bus_id(int device_id, char* buf, size_t len) {
+  if (!buf || len < 16) return IPA_ERR_BAD_ARG;
+  if (hipDeviceGetPCIBusId(buf, (int)len, device_id) != hipSuccess) return IPA_ERR_HIP;
+  return IPA_OK;
+}
+
 int ipa_ctx_device_info(ipa_ctx* c, char* name, size_t name_len, int* cu_count,
                         size_t* total_mem) {
   if (!c) return IPA_ERR_BAD_ARG;

@@ -3,9 +3,12 @@
 "For bigger ksizes it is often faster to resize an image rather than blur it": the image is
 shrunk to ``round(shape / f)`` with ``cv2.resize(..., INTER_AREA)`` and enlarged back with
 ``INTER_LINEAR``.  Both resizes are OpenCV's published algorithm on the GPU (`ops.resize`,
-cv2-unpinned) for float32 / float64 images; integer images take the reference's
-``toFloatArray`` rule (uint8 / uint16 -> float32) first - cv2's 8-bit fixed-point resize differs
-between OpenCV versions and is not restated.  ``inplace=True`` writes the result into ``img``.
+cv2-unpinned) for float32 / float64 images.  Integer images (the reference's demo feeds a uint8
+one) keep their dtype like ``cv2.resize`` does: they are resized in float32 (``toFloatArray``'s
+rule for uint8 / uint16; cv2's 8-bit fixed-point arithmetic differs between OpenCV versions and is
+not restated) and the result is rounded half-to-even and saturated to the dtype's range -
+``cv::saturate_cast`` - for the returned array and for the in-place write alike.
+``inplace=True`` writes the result into ``img``.
 """
 import numpy as np
 
@@ -23,6 +26,9 @@ def fastMean(img, f=10, inplace=False, ctx=None):
     ss1 = int(round(s1 / f))
     small = ops.resize(src, (ss0, ss1), 'area', ctx=ctx)
     big = ops.resize(small, (s0, s1), 'linear', ctx=ctx)
+    if src.dtype.kind in 'ui':
+        info = np.iinfo(src.dtype)
+        big = np.clip(np.rint(big), info.min, info.max).astype(src.dtype)
     if inplace:
         img[...] = big
         return img

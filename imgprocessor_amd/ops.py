@@ -820,6 +820,10 @@ def resize(img, dsize_hw, interpolation='linear', out=None, ctx=None, src_shape=
     """cv2.resize(img, (w, h), interpolation=...) for 2-D float32 / float64 images;
     dsize_hw = (rows, columns) of the result.  ``src_shape`` (device arrays): resize only the
     top-left (rows, columns) of ``img`` - fastFilter's cropped grid, without a copy"""
+    if interpolation not in RESIZE_INTERP:
+        raise ValueError('resize: interpolation %r is not built (linear / 1, cubic / 2, area / 3, '
+                         'lanczos4 / 4; cv2.INTER_NEAREST = 0 and the exact variants are not)'
+                         % (interpolation,))
     interp = RESIZE_INTERP[interpolation]
     dh, dw = int(dsize_hw[0]), int(dsize_hw[1])
     if _is_dev(img):

@@ -132,12 +132,18 @@ class FramePipeline(object):
 
 
 def numa_cpus_of_device(device=0):
-    """host CPUs of the NUMA node GPU `device` is attached to, from sysfs (the render nodes'
-    PCI devices in bus order); None when the platform does not say"""
+    """host CPUs of the NUMA node GPU `device` is attached to: the device's PCI address as HIP
+    numbers it in THIS process (so HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES are honoured and
+    other render nodes do not shift the count), then /sys/bus/pci/devices/<address>/numa_node;
+    None when the platform does not say"""
+    import ctypes as C
+    from . import _lib as L
     try:
-        base = '/sys/class/drm'
-        cards = sorted(d for d in os.listdir(base) if d.startswith('renderD'))
-        node = int(open(os.path.join(base, cards[device], 'device', 'numa_node')).read())
+        buf = C.create_string_buffer(64)
+        if L.lib().ipa_device_pci_bus_id(int(device), buf, 64) != 0:
+            return None
+        bdf = buf.value.decode().strip().lower()
+        node = int(open('/sys/bus/pci/devices/%s/numa_node' % bdf).read())
         if node < 0:
             return None
         spec = open('/sys/devices/system/node/node%d/cpulist' % node).read().strip()

@@ -74,6 +74,10 @@ const char* ipa_status_string(int status);
 /* last error text of this context (or of the calling thread when ctx==NULL) */
 const char* ipa_last_error(const ipa_ctx* ctx);
 int ipa_device_count(int* count);
+/* PCI address "dddd:bb:dd.f" of HIP device `device_id` as this process numbers it (honours
+ * HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) - for host-side placement of the feeding threads
+ * (sharding.numa_cpus_of_device reads /sys/bus/pci/devices/<address>/numa_node).  len >= 16. */
+int ipa_device_pci_bus_id(int device_id, char* buf, size_t len);
 int ipa_ctx_create(int device_id, ipa_ctx** ctx);
 int ipa_ctx_destroy(ipa_ctx* ctx);
 int ipa_ctx_synchronize(ipa_ctx* ctx);

@@ -1607,6 +1607,9 @@ int orc_resize(const void* src, int dt, long sh, long sw, void* dst, long dh, lo
   if (dt != ORC_F32 && dt != ORC_F64) return -1;
   if (sh < 1 || sw < 1 || dh < 1 || dw < 1) return -1;
   const double scale_x = 1.0 / ((double)dw / (double)sw), scale_y = 1.0 / ((double)dh / (double)sh);
+  /* resize.cpp: INTER_LINEAR at an exact 2 x 2 reduction is computed as INTER_AREA */
+  if (interp == 1 && sw == 2 * dw && sh == 2 * dh) interp = 3;
+  if (interp < 1 || interp > 4) return -3;
   int ks = interp == 1 ? 2 : (interp == 2 ? 4 : 8);
   int isx = (int)nearbyint(scale_x), isy = (int)nearbyint(scale_y);
   int area_fast = 0;

@@ -121,8 +121,21 @@ def test_fast_filter_and_fast_mean_end_to_end(ia, oracle):
             got = fastMean(a, fac)
             assert got.dtype == dt
             assert np.array_equal(got, oracle.fastMean(a, fac)), (dt.__name__, fac)
-    u8 = (rng.random((100, 70)) * 255).astype(np.uint8)      # toFloatArray rule: float32
-    assert fastMean(u8, 20).dtype == np.float32
+    # integer images keep their dtype like cv2.resize: float32 arithmetic, round half to even, saturate
+    for dt in (np.uint8, np.uint16):
+        ui = (rng.random((100, 70)) * np.iinfo(dt).max).astype(dt)
+        want = np.clip(np.rint(oracle.fastMean(ui.astype(np.float32), 20)), 0, np.iinfo(dt).max).astype(dt)
+        got = fastMean(ui, 20)
+        assert got.dtype == dt and np.array_equal(got, want)
+        ci = ui.copy()
+        assert fastMean(ci, 20, inplace=True) is ci and np.array_equal(ci, want)
+    # an exact 2 x 2 reduction with INTER_LINEAR is the area average (OpenCV's rule)
+    from imgprocessor_amd import ops
+    sq = rng.random((64, 96)).astype(np.float32)
+    assert np.array_equal(ops.resize(sq, (32, 48), 'linear'), ops.resize(sq, (32, 48), 'area'))
+    assert np.array_equal(ops.resize(sq, (32, 48), 'linear'), oracle.resize(sq, (32, 48), oracle.RESIZE_LINEAR))
+    with pytest.raises(ValueError):
+        ops.resize(sq, (32, 48), 0)
     c = a.copy()
     assert fastMean(c, 10, inplace=True) is c and np.array_equal(c, oracle.fastMean(a, 10))
     # device arrays stay on the device
