@@ -115,6 +115,24 @@ def main():
         if not np.array_equal(np.asarray(i1), np.asarray(j1)):
             fails += 1
             print('MISMATCH medianThreshold indices %s' % info, flush=True)
+        msz = int(rng.choice([2, 4, 5, 7, 8, 11]))
+        if msz < min(h, w):
+            g2, i2 = filters.medianThreshold(np.abs(img) + 0.1, thr, size=msz, condition=cond)
+            o2, j2 = oracle.medianThreshold(np.abs(img) + 0.1, thr, size=msz, condition=cond)
+            check('medianThreshold size %d' % msz, g2, o2, 0, 0, info + ' thr %g %s' % (thr, cond))
+            if not np.array_equal(np.asarray(i2), np.asarray(j2)):
+                fails += 1
+                print('MISMATCH medianThreshold size %d indices %s' % (msz, info), flush=True)
+        # point-spread IDW (sweeps with in-order dependence; more columns than rows or square:
+        # where the source's window is defined)
+        if w >= h:
+            from imgprocessor_amd.interpolate import interpolate2dStructuredPointSpreadIDW as psidw
+            pm = rng.random((h, w)) < rng.choice([0.1, 0.5, 0.9])
+            pm[h // 3:2 * h // 3, w // 3:2 * w // 3] = True
+            pm[0, 0] = False
+            pk, pp = int(rng.choice([2, 5, 15])), float(rng.choice([1, 2, 3.5]))
+            check('pointSpreadIDW', psidw(img, pm, pk, pp), oracle.interpolate2dStructuredPointSpreadIDW(img, pm, pk, pp),
+                  3e-5 if dt == np.float32 else 1e-9, 0, info + ' kernel %d power %g' % (pk, pp))
         b = rng.random((h, w)) < 0.02
         ck = int(rng.choice([3, 10, 30]))
         check('closestDirectDistance', closestDirectDistance(b, ck), oracle.closestDirectDistance(b, ck), 0, 0,
