@@ -150,6 +150,18 @@ def timed(ctx, fn, steps, warmup):
     return e0.elapsed_ms(e1) / steps
 
 
+def timed_settled(ctx, fn, steps, warmup, settle_s=0.2):
+    """`timed` after `settle_s` seconds of the same launches: every configuration below builds
+    its frames on the host first, the GPU idles meanwhile and its clocks take ~100 ms of load to
+    come back - three warm-up launches of a 1 ms kernel are inside that ramp"""
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < settle_s:
+        for _ in range(8):
+            fn()
+        ctx.synchronize()
+    return timed(ctx, fn, steps, warmup)
+
+
 def other_configs(ctx, ia, ops, budget_launches=60):
     """BASELINE.json configurations C2..C5, kernel-only on device-resident data (C4 also
     PCIe-inclusive), each with its COMPULSORY HBM bytes: every input element read once, every
@@ -192,7 +204,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     src = ctx.to_device(synth_frames(B, h, w, 200))
     dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
     dst = placed((B, h, w), np.float32, lambda d: ops.remap_conv2d(src, dmx, dmy, k5, out=d))
-    ms = timed(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst), budget_launches, 5)
+    ms = timed_settled(ctx, lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst), budget_launches, 5)
     entry('C2 1080p f32, LensDistortion undistort (maps) + 5x5 Gaussian, %d frames/launch' % B,
           B, h, w, ms, (8 * B + 8) * h * w, 1)
     del src, dst, dmx, dmy
@@ -207,7 +219,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     dst = placed((B, h, w), np.float32,
                  lambda d: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, 'linear', out=d))
     for interp in ('linear', 'cubic'):
-        ms = timed(ctx, lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, interp,
+        ms = timed_settled(ctx, lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, interp,
                                                                out=dst), budget_launches, 5)
         two = interp != 'linear'
         entry('C3 4K f32, PerspectiveCorrection warp (%s) + separable 9+9, %d frames/launch'
@@ -218,7 +230,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
     # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
     # uint8 frames (OpenCV's 8U short-weight arithmetic, bit-exact against the oracle)
-    ms = timed(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
+    ms = timed_settled(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
                budget_launches, 5)
     entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
           8 * B * h * w, 3, 'planning pass (first call) + ring kernel + gather kernel on the rim; '
@@ -226,7 +238,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
           bound='lds', work=64 * 4 * B * h * w)
     u8 = ctx.to_device(np.round(synth_frames(B, h, w, 310) * 255).astype(np.uint8))
     d8 = ctx.empty((B, h, w), np.uint8)
-    ms = timed(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
+    ms = timed_settled(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),
                budget_launches // 2, 3)
     entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
           ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weight table resident in LDS (integer-exact); "
@@ -247,7 +259,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
                       [0, 0, 1.0]])
         P = np.array([[1, 0, 0], [0, 1, 0], [2e-6, 1e-6, 1.0]])
         return P @ R
-    ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
+    ms = timed_settled(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
                                                         'cubic', out=dst), budget_launches, 5)
     entry('C5-like 4K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
           8 * B * h * w, 2, 'two launches through the workspace; the 11x11 filter is fma-bound',
@@ -257,7 +269,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     h, w, B = 4320, 7680, 4
     src = ctx.to_device(synth_frames(B, h, w, 500))
     dst = ctx.empty((B, h, w), np.float32)
-    ms = timed(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
+    ms = timed_settled(ctx, lambda: ops.warp_perspective_conv2d(src, rot_persp(h, w), (h, w), k11,
                                                         'cubic', out=dst), budget_launches // 2, 3)
     entry('C5 8K f32, bicubic warp + dense 11x11, %d frames/launch' % B, B, h, w, ms,
           8 * B * h * w, 2, 'two launches through the workspace; the 11x11 filter is fma-bound',
@@ -273,7 +285,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     u16 = ctx.to_device(np.concatenate([np.roll(f16, 29 * i, axis=1) for i in range(B // 16)]))
     dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
     dst = placed((B, h, w), np.float32, lambda d: ops.remap_conv2d(u16, dmx, dmy, k7, out=d))
-    ms = timed(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst), budget_launches // 2, 3)
+    ms = timed_settled(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst), budget_launches // 2, 3)
     entry('C4 4K uint16 -> float32, undistort (maps) + dense 7x7, %d frames/launch (kernel only)'
           % B, B, h, w, ms, (6 * B + 8) * h * w, 1)
     del u16, dst
@@ -556,7 +568,7 @@ def main():
                 B2 = 128
                 s2 = ctx.to_device(synth_frames(B2, h, w, seed0=7))
                 o2 = ctx.empty((B2, h, w), np.float32)
-                ms2 = timed(ctx, lambda: ops.remap_conv2d(s2, dmx, dmy, k5, out=o2), 40, 5)
+                ms2 = timed_settled(ctx, lambda: ops.remap_conv2d(s2, dmx, dmy, k5, out=o2), 40, 5)
                 c2 = (8 * B2 + 8) * h * w
                 extra.append({'workload': 'headline at %d frames/launch' % B2, 'frames': B2,
                               'ms': round(ms2, 4), 'Mpix_s': round(B2 * h * w / ms2 / 1e3, 1),
