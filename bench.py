@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 H4K, W4K = 2160, 3840
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 VALU_PEAK_FLOPS = 157.3e12  # fp32 vector peak (MI355X_MICROARCH.md)
+VALU_ISSUE_PEAK = 256 * 64 * 2.4e9   # vector lane-instructions per second, every SIMD issuing
 LDS_PEAK_BPS = 150e12       # aggregate ds_read_b64/b128 rate, every CU streaming (same guide)
 
 
@@ -188,6 +189,11 @@ def other_configs(ctx, ia, ops, budget_launches=60):
         if bound == 'lds' and work:
             e['lds_bytes'] = int(work)
             e['frac_lds'] = round(work / (ms * 1e-3) / LDS_PEAK_BPS, 4)
+        if bound == 'valu_issue' and work:
+            # integer work: vector instructions x lanes against what the SIMDs can issue
+            # (256 CUs x 64 lanes per clock at the guide's 2.4 GHz)
+            e['vector_lane_instructions'] = int(work)
+            e['frac_valu_issue'] = round(work / (ms * 1e-3) / VALU_ISSUE_PEAK, 4)
         if note:
             e['note'] = note
         out.append(e)
@@ -242,8 +248,11 @@ def other_configs(ctx, ia, ops, budget_launches=60):
                budget_launches // 2, 3)
     entry('PerspectiveCorrection default 4K uint8, Lanczos4 warp, %d frames/launch' % B, B, h, w,
           ms, 2 * B * h * w, 1, "OpenCV's 8U fixed-point weight table resident in LDS (integer-exact); "
-          'bound by the integer VALU / texture addresser, an HBM fraction is the wrong roofline',
-          bound='valu')
+          'bound by integer vector work, an HBM fraction is the wrong roofline: per sample 32 '
+          'v_dot2_i32_i16 (the 64 taps), 32 v_perm_b32 (bytes out of the aligned tap dwords), ~40 for '
+          'the homography, the 1/32-px fractions, the table and tap addresses and the rounding = ~104 '
+          'vector instructions per lane (counted in the source, not from the ISA)',
+          bound='valu_issue', work=104 * B * h * w)
     del u8, d8
 
     # C5: bicubic (a=-0.5) warp under rotation + perspective, dense 11x11 - on 4K frames here
