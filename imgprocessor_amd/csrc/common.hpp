@@ -41,6 +41,8 @@ struct ipa_tuning {
   int u8_lz_lds = 1;      // uint8 Lanczos4: OpenCV's 128 KB weight table in LDS (0: weights formed per sample)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
+  int tile_warp = 2;      // perspective warps of float32 frames with the tile's source box in LDS (tile_warp.hpp):
+                          // 0 never, 1 where it pays, 2 whenever the homography is covered
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates
                           // are evaluated ONCE into the plan buffer and the gather kernel reads them (0: never)
@@ -73,6 +75,10 @@ struct ipa_ctx {
   // ipa_plan_reserve() clears it, the user that wants reuse sets it after filling the buffer.
   double plan_key[40];
   int plan_key_n = 0;
+  // the LDS box of the tile warp kernel (tile_warp.hpp) for the last homography + geometry: a
+  // host-side walk over the tiles that a repeated call does not pay again (0.4 ms per 4K call)
+  double tile_warp_key[14];
+  int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0;
   // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
   // and the source + geometry it belongs to: ring_plan_prepare's hint
   unsigned* ring_hint = nullptr;

@@ -20,6 +20,7 @@
 #include "sampler.hpp"
 #include "ring_remap.hpp"
 #include "stored_coords.hpp"
+#include "tile_warp.hpp"
 
 namespace ipa {
 
@@ -465,6 +466,51 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
   return 0;
 }
 
+// float32 perspective warps on the tile kernel (tile_warp.hpp); 1: not covered
+template <int INTERP>
+static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const HomographyCoord& coord,
+                            int n_frames) {
+  TileWarpArgs t;
+  {
+    double key[14] = {(double)INTERP, (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
+    for (int k = 0; k < 9; k++) key[5 + k] = coord.m[k];
+    if (!ctx->tile_warp_valid || memcmp(key, ctx->tile_warp_key, sizeof key) != 0) {
+      int pitch = 0, rows = 0;
+      const bool ok = tile_warp_box<ntaps<INTERP>::value>(coord.m, p.dh, p.dw, p.sh, p.sw, &pitch, &rows);
+      ctx->tile_warp_ok = ok ? 1 : 0;
+      ctx->tile_warp_rows = rows;
+      ctx->tile_warp_pitch = ok ? tile_warp_pitch(coord.m, p.dh, p.dw, pitch, rows) : 0;
+      memcpy(ctx->tile_warp_key, key, sizeof key);
+      ctx->tile_warp_valid = 1;
+    }
+    if (!ctx->tile_warp_ok) return 1;
+    t.pitch = ctx->tile_warp_pitch;
+    t.rows = ctx->tile_warp_rows;
+  }
+  t.dst = p.dst; t.dst_frame_elems = p.dst_frame_elems; t.dpitch = p.dpitch;
+  t.src = p.src; t.src_frame_bytes = p.src_frame_bytes; t.src_bytes = p.src_bytes;
+  t.sh = p.sh; t.sw = p.sw; t.spitch = p.spitch; t.dh = p.dh; t.dw = p.dw;
+  t.n_frames = n_frames;
+  t.border = p.border; t.q5 = p.q5; t.cubic_a = p.cubic_a; t.lanczos = p.lanczos;
+  t.cval = (float)p.cval;
+  t.tiles_x = (p.dw + kWarpTileW - 1) / kWarpTileW;
+  t.tiles = t.tiles_x * ((p.dh + kWarpTileH - 1) / kWarpTileH);
+  // frames a workgroup walks through with one evaluation of its tile's coordinates: as many as
+  // still leave the launch four rounds of workgroups (4 per CU)
+  t.frames_wg = 8;
+  while (t.frames_wg > 1 && (long)t.tiles * ((n_frames + t.frames_wg - 1) / t.frames_wg) < 4096) t.frames_wg >>= 1;
+  if (t.frames_wg > n_frames) t.frames_wg = n_frames;
+  const size_t dbytes = ((size_t)(p.dh - 1) * p.dpitch + p.dw) * sizeof(float);
+  if (dbytes >= (1ull << 31)) return 1;
+  t.dst_bytes = (unsigned)dbytes;
+  t.inv_pitch = 1.0f / (float)t.pitch;
+  const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
+  const size_t lds = (size_t)t.pitch * t.rows * sizeof(float);
+  hipLaunchKernelGGL((tile_warp_kernel<INTERP>), dim3((unsigned)t.tiles * groups), dim3(256), lds,
+                     ctx->stream, t, coord);
+  return 0;
+}
+
 template <typename Coord>
 static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, int map_vec) {
   if (!ctx) return IPA_ERR_BAD_ARG;
@@ -550,6 +596,18 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   // the lens model and the homography read the coordinates the planning pass stored; the
   // homography's are doubles, 16 B per pixel and frame.  ring_remap = 2: every covered case)
   constexpr bool kHom = std::is_same<Coord, HomographyCoord>::value;
+  if constexpr (kHom) {
+    if (ctx->tune.tile_warp && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
+        base != IPA_INTER_NEAREST && (unsigned long)p.tiles * a.n_frames < (1ul << 30)) {
+      int trc = base == IPA_INTER_LINEAR ? tile_warp_launch<kLinear>(ctx, p, coord, a.n_frames)
+                : base == IPA_INTER_LANCZOS4 ? tile_warp_launch<kLanczos4>(ctx, p, coord, a.n_frames)
+                                             : tile_warp_launch<kCubic>(ctx, p, coord, a.n_frames);
+      if (trc == 0) {
+        IPA_HIP(ctx, hipGetLastError());
+        return IPA_OK;
+      }
+    }
+  }
   // ... and from which batch size (4K frames, ring against gather kernel, profiles/r03_micro.txt):
   // a map pair is planned anew on every call (its contents may have changed) - ~50 us that 2
   // bilinear frames do not earn back (79 against 30 us; level at 16) -, a source given by value

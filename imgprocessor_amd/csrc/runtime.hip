@@ -65,6 +65,7 @@ const TuneName kTuneNames[] = {
     {"ring_min", "IPA_RING_MIN", &ipa_tuning::ring_min},
     {"ring_remap", "IPA_RING_REMAP", &ipa_tuning::ring_remap},
     {"stored_coords", "IPA_STORED_COORDS", &ipa_tuning::stored_coords},
+    {"tile_warp", "IPA_TILE_WARP", &ipa_tuning::tile_warp},
     {"lens_cache", "IPA_LENS_CACHE", &ipa_tuning::lens_cache},
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
@@ -79,6 +80,7 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "stream_k") == 0) return v >= 7 && v <= 99;
   if (strcmp(name, "ring_min") == 0) return v >= 1;
   if (strcmp(name, "ring_remap") == 0) return v >= 0 && v <= 2;
+  if (strcmp(name, "tile_warp") == 0) return v >= 0 && v <= 2;
   if (strcmp(name, "stored_coords") == 0) return v >= 0;
   return v == 0 || v == 1;
 }

@@ -1,0 +1,446 @@
+// tile_warp.hpp — cv2.warpPerspective (camera/PerspectiveCorrection.py:377-378, 401-405) for
+// homographies that ROTATE the picture: the source box of an output tile staged in LDS.
+//
+// The gather kernel (remap_impl.hpp) and the ring kernel (ring_remap.hpp) both assume that an
+// output row walks along a source row: a wave's gather then touches 2-3 cache lines and a strip's
+// footprints advance row by row.  Under a rotation of a few degrees neither holds - a gather of 64
+// lanes crosses a source row every 1 / sin(angle) pixels and pays the texture addresser per line
+// touched, the ring's strips stop being "clean" - and the time of a warp doubles to triples
+// (tools/angle_sweep.py, profiles/r04_micro.txt).  Here a workgroup owns a 64 x 32 output tile:
+//   * the tile's corners through the homography give the bounding box of its footprints in the
+//     source (a projective map takes the tile to a convex quadrilateral: the extremes are at the
+//     corners);
+//   * the box is read row by row with coalesced dword loads - every cell through the border mode,
+//     so the samples below need no border logic - into LDS;
+//   * every pixel's NT x NT taps come from LDS: the weights of axis_split(), the products and sums
+//     of sample() in its order - results identical to remap_kernel;
+//   * footprints the box does not hold (outside the source altogether, not finite, or a box
+//     clipped to the LDS the launch reserved) go through sample() itself.
+// The coordinates (a double division per pixel) are evaluated once per tile and kept in registers
+// for the frames_wg frames the workgroup walks through.
+#pragma once
+
+#include "sampler.hpp"
+
+namespace ipa {
+
+constexpr int kWarpTileW = 64, kWarpTileH = 32;
+constexpr int kWarpTilePx = kWarpTileH / 4;      // pixels per thread: lane = column, rows wave + 4 j
+constexpr int kWarpTileLdsBytes = 40960;  // the box of one tile (4 workgroups per CU at the most)
+
+struct TileWarpArgs {
+  char* dst;
+  long dst_frame_elems, dpitch;
+  const char* src;
+  long src_frame_bytes;
+  unsigned src_bytes, dst_bytes;   // of one frame (descriptor ranges)
+  int sh, sw, spitch, dh, dw;
+  int n_frames, frames_wg;
+  int border, q5;
+  float cubic_a;
+  const float* lanczos;
+  float cval;
+  int tiles_x, tiles;
+  int pitch, rows;   // the LDS box: floats per row (odd: rotated reads spread over the banks), rows
+  float inv_pitch;
+};
+
+// first and last source index the footprints of coordinates in [lo, hi] can touch, clipped to what
+// a footprint with at least one tap inside [0, n) reaches.  (1/32-px rounding moves a coordinate
+// by up to 1/64: 0.02 covers it and the rounding of the corner arithmetic.)
+template <int NT>
+__host__ __device__ inline void tile_axis_box(double lo, double hi, int n, int& first, int& count) {
+  const double lim = 1.0e6;
+  lo = lo < -lim ? -lim : (lo > lim ? lim : lo);
+  hi = hi < -lim ? -lim : (hi > lim ? lim : hi);
+  int a = (int)floor(lo - 0.02) - (NT / 2 - 1);
+  int b = (int)floor(hi + 0.02) + NT / 2;
+  if (a < -(NT - 1)) a = -(NT - 1);
+  if (b > n + NT - 2) b = n + NT - 2;
+  first = a;
+  count = b - a + 1 > 0 ? b - a + 1 : 0;
+}
+
+// sample() of sampler.hpp tap by tap (rolled loops, a handful of registers): the same weights,
+// products and sums in the same order - for the few footprints a tile's box does not hold
+template <int INTERP>
+__device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, double sy, float cval) {
+  constexpr int NT = ntaps<INTERP>::value;
+  if (!(sx > (double)-kCoordLimit && sx < (double)kCoordLimit && sy > (double)-kCoordLimit &&
+        sy < (double)kCoordLimit)) {
+    if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cval;
+    sx = sx < (double)-kCoordLimit ? (double)-kCoordLimit : (sx > (double)kCoordLimit ? (double)kCoordLimit : sx);
+    sy = sy < (double)-kCoordLimit ? (double)-kCoordLimit : (sy > (double)kCoordLimit ? (double)kCoordLimit : sy);
+  }
+  int ix0, iy0;
+  float wxs[4], wys[4];   // bilinear / bicubic weights (indexed with constants only)
+  const float *wxr = s.lanczos, *wyr = s.lanczos;   // Lanczos4: rows of the table (the LDS copy)
+  if constexpr (INTERP == kLanczos4) {
+    const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+    ix0 = (qx >> 5) - 3;
+    iy0 = (qy >> 5) - 3;
+    wxr += (qx & 31) * 8;
+    wyr += (qy & 31) * 8;
+  } else {
+    float wx[NT], wy[NT];
+    axis_split<INTERP, float, double>(s, sx, ix0, wx);
+    axis_split<INTERP, float, double>(s, sy, iy0, wy);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      wxs[k] = wx[k % NT];
+      wys[k] = wy[k % NT];
+    }
+  }
+  if (s.border == IPA_BORDER_CONSTANT &&
+      (ix0 >= s.w || ix0 + NT <= 0 || iy0 >= s.h || iy0 + NT <= 0))
+    return cval;
+  auto weight = [](const float* row, const float (&w)[4], int k) {
+    if constexpr (INTERP == kLanczos4) return row[k];
+    else return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+  };
+  float out = 0.f;
+#pragma unroll 1
+  for (int r = 0; r < NT; r++) {
+    const int yy = resolve_idx(iy0 + r, s.h, s.border);
+    float rs = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < NT; c++) {
+      const int xx = resolve_idx(ix0 + c, s.w, s.border);
+      const float v = (yy < 0 || xx < 0)
+                          ? cval
+                          : u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, (yy * s.pitch + xx) << 2, 0, 0));
+      const float w = weight(wxr, wxs, c);
+      rs = c == 0 ? w * v : ipa_fma(w, v, rs);
+    }
+    const float w = weight(wyr, wys, r);
+    out = r == 0 ? w * rs : ipa_fma(w, rs, out);
+  }
+  return out;
+}
+
+template <int INTERP>
+__global__ void __launch_bounds__(256)
+tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
+  constexpr int NT = ntaps<INTERP>::value;
+  constexpr bool kLz = INTERP == kLanczos4;
+  extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+  __shared__ double corner[8];
+  __shared__ __attribute__((aligned(16))) float lz[kLz ? 256 : 4];
+  const unsigned tid = threadIdx.x, lane = tid & 63u;
+  const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (kLz) lz[tid] = a.lanczos[tid];
+
+  const unsigned groups = ((unsigned)a.n_frames + a.frames_wg - 1) / (unsigned)a.frames_wg;
+  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
+  const unsigned grp = b % groups, tile = b / groups;
+  const int tyi = (int)(tile / (unsigned)a.tiles_x), txi = (int)tile - tyi * a.tiles_x;
+  const int x0 = txi * kWarpTileW, y0 = tyi * kWarpTileH;
+  const int x1 = x0 + kWarpTileW - 1 < a.dw ? x0 + kWarpTileW - 1 : a.dw - 1;
+  const int y1 = y0 + kWarpTileH - 1 < a.dh ? y0 + kWarpTileH - 1 : a.dh - 1;
+  if (tid < 4u) {
+    double sx, sy;
+    coord.get((tid & 1u) ? x1 : x0, (tid & 2u) ? y1 : y0, sx, sy);
+    corner[2 * tid] = sx;
+    corner[2 * tid + 1] = sy;
+  }
+  __syncthreads();
+  int bx0, by0, bw, bh;
+  {
+    double lox = corner[0], hix = corner[0], loy = corner[1], hiy = corner[1];
+    bool fin = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double cx = corner[2 * k], cy = corner[2 * k + 1];
+      fin = fin && ipa_abs(cx) < 1.0e6 && ipa_abs(cy) < 1.0e6;   // false for NaN
+      lox = cx < lox ? cx : lox; hix = cx > hix ? cx : hix;
+      loy = cy < loy ? cy : loy; hiy = cy > hiy ? cy : hiy;
+    }
+    tile_axis_box<NT>(lox, hix, a.sw, bx0, bw);
+    tile_axis_box<NT>(loy, hiy, a.sh, by0, bh);
+    if (!fin) bw = bh = 0;
+    bw = bw < a.pitch ? bw : a.pitch;
+    bh = bh < a.rows ? bh : a.rows;
+    bx0 = __builtin_amdgcn_readfirstlane(bx0); by0 = __builtin_amdgcn_readfirstlane(by0);
+    bw = __builtin_amdgcn_readfirstlane(bw); bh = __builtin_amdgcn_readfirstlane(bh);
+  }
+  const bool inside = bx0 >= 0 && by0 >= 0 && bx0 + bw <= a.sw && by0 + bh <= a.sh;
+
+  // the tile's footprints, once: LDS index of the first tap (-1: through sample()), fractions
+  SrcView s;
+  s.h = a.sh; s.w = a.sw; s.pitch = a.spitch;
+  s.border = a.border; s.q5 = a.q5; s.cubic_a = a.cubic_a;
+  s.lanczos = lz;
+  int ad[kWarpTilePx];
+  float tx[kWarpTilePx], ty[kWarpTilePx];   // Lanczos4: the table rows' float offsets, as ints
+  const int x = x0 + (int)lane;
+  unsigned slow = 0;
+#pragma unroll
+  for (int j = 0; j < kWarpTilePx; j++) {
+    const int y = y0 + (int)wave + 4 * j;
+    double sx, sy;
+    coord.get(x < a.dw ? x : a.dw - 1, y < a.dh ? y : a.dh - 1, sx, sy);
+    const bool ok = ipa_abs(sx) < (double)kCoordLimit && ipa_abs(sy) < (double)kCoordLimit;
+    if (!ok) sx = sy = 0.0;
+    int ix0, iy0;
+    if constexpr (kLz) {
+      const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+      ix0 = (qx >> 5) - 3;
+      iy0 = (qy >> 5) - 3;
+      tx[j] = __int_as_float((qx & 31) << 3);
+      ty[j] = __int_as_float((qy & 31) << 3);
+    } else {
+      axis_frac<INTERP, float, double>(s, sx, ix0, tx[j]);
+      axis_frac<INTERP, float, double>(s, sy, iy0, ty[j]);
+    }
+    const int cx = ix0 - bx0, cy = iy0 - by0;
+    const bool in = ok && cx >= 0 && cy >= 0 && cx + NT <= bw && cy + NT <= bh;
+    ad[j] = in ? __mul24(cy, a.pitch) + cx : -1;
+    slow |= in ? 0u : 1u << j;
+  }
+
+  float* dst0 = reinterpret_cast<float*>(a.dst);
+  const int cells = bw * bh;
+  const float inv_bw = 1.0f / (float)(bw > 0 ? bw : 1);
+  const unsigned f0 = grp * (unsigned)a.frames_wg;
+  const unsigned f1 = f0 + (unsigned)a.frames_wg < (unsigned)a.n_frames ? f0 + (unsigned)a.frames_wg
+                                                                        : (unsigned)a.n_frames;
+
+  // The box of a tile INSIDE the source: wave w takes rows w, w + 4, ..., lane l column l - the row
+  // offset is a scalar, nothing but the LDS address is computed per load; the columns past 64 go
+  // 64 >> esh rows per load (lane = row : column, esh bits of column).  The first kRowsFly rows
+  // of a wave and its first 4 loads of the far columns are REQUESTED while the previous frame is
+  // being sampled and written to LDS after it (box_issue / box_commit): the ~1 us of an HBM
+  // round trip is then behind the samples and stores of a frame, not in front of them.
+  constexpr int kRowsFly = 12;
+  const int voff = (int)lane << 2;
+  const bool c0 = (int)lane < bw;
+  const int e = bw - 64;
+  const int esh = e <= 4 ? 2 : (e <= 8 ? 3 : (e <= 16 ? 4 : (e <= 32 ? 5 : 6)));
+  const int rstep = 64 >> esh;   // rows per load of the far columns
+  const int lr = (int)lane >> esh, lc = 64 + ((int)lane & ((1 << esh) - 1));
+  const bool cl = lc < bw;
+  const int soff0 = (__mul24(by0, a.spitch) + bx0) << 2;
+  float v0[kRowsFly], v1[4];
+  auto box_issue = [&](const __amdgpu_buffer_rsrc_t& rs) {
+#pragma unroll
+    for (int u = 0; u < kRowsFly; u++) {
+      const int r = (int)wave + 4 * u < bh ? (int)wave + 4 * u : bh - 1;
+      v0[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
+    }
+    if (e > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = ((int)wave + 4 * u) * rstep + lr;
+        const bool live = cl && r < bh;
+        v1[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, live ? (__mul24(r, a.spitch) + lc) << 2 : 0, soff0, 0));
+      }
+    }
+  };
+  auto box_commit = [&]() {
+#pragma unroll
+    for (int u = 0; u < kRowsFly; u++) {
+      const int r = (int)wave + 4 * u;
+      if (r < bh && c0) tile_lds[__mul24(r, a.pitch) + (int)lane] = v0[u];
+    }
+    if (e > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int r = ((int)wave + 4 * u) * rstep + lr;
+        if (cl && r < bh) tile_lds[__mul24(r, a.pitch) + lc] = v1[u];
+      }
+    }
+  };
+  // (boxes taller than 4 kRowsFly rows - Lanczos4 under a rotation of 30 degrees and more - or
+  // with many far columns: the rest, read when the frame's turn has come)
+  auto box_rest = [&](const __amdgpu_buffer_rsrc_t& rs) {
+#pragma unroll 1
+    for (int r = (int)wave + 4 * kRowsFly; r < bh; r += 4) {
+      const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
+      if (c0) tile_lds[__mul24(r, a.pitch) + (int)lane] = t;
+    }
+    if (e > 0) {
+#pragma unroll 1
+      for (int r0 = ((int)wave + 16) * rstep; r0 < bh; r0 += 4 * rstep) {
+        const int r = r0 + lr;
+        const bool live = cl && r < bh;
+        const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, live ? (__mul24(r, a.spitch) + lc) << 2 : 0, soff0, 0));
+        if (live) tile_lds[__mul24(r, a.pitch) + lc] = t;
+      }
+    }
+  };
+  s.rsrc = make_rsrc(a.src + (long)f0 * a.src_frame_bytes, a.src_bytes);
+  if (inside && f0 < f1) box_issue(s.rsrc);
+#pragma unroll 1
+  for (unsigned f = f0; f < f1; f++) {
+    s.rsrc = make_rsrc(a.src + (long)f * a.src_frame_bytes, a.src_bytes);
+    __syncthreads();   // the previous frame's taps are read (first pass: the Lanczos table is written)
+    // 1. the box
+    if (inside) {
+      box_commit();
+      box_rest(s.rsrc);
+    } else {
+      // on the rim of the source: cell by cell (i = row i / bw, column i % bw) through the border mode
+#pragma unroll 1
+      for (int i = (int)tid; i < cells; i += 256) {
+        const int row = (int)(((float)i + 0.5f) * inv_bw), col = i - row * bw;
+        const int yy = resolve_idx(by0 + row, a.sh, a.border);
+        const int xx = resolve_idx(bx0 + col, a.sw, a.border);
+        const bool live = yy >= 0 && xx >= 0;
+        const int off = live ? (__mul24(yy, a.spitch) + xx) << 2 : 0;
+        const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0));
+        tile_lds[__mul24(row, a.pitch) + col] = live ? t : a.cval;
+      }
+    }
+    __syncthreads();
+    if (inside && f + 1 < f1)
+      box_issue(make_rsrc(a.src + (long)(f + 1) * a.src_frame_bytes, a.src_bytes));
+    // 2. the samples, kGroup at a time (their taps in flight together)
+    const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
+    constexpr int kGroup = INTERP == kLinear ? 4 : (INTERP == kCubic ? 2 : 1);
+#pragma unroll
+    for (int j0 = 0; j0 < kWarpTilePx; j0 += kGroup) {
+#pragma unroll
+      for (int j = j0; j < j0 + kGroup; j++) {
+        const int y = y0 + (int)wave + 4 * j;
+        float wx[NT], wy[NT];
+        if constexpr (kLz) {
+          const float4* rx = reinterpret_cast<const float4*>(lz + __float_as_int(tx[j]));
+          const float4* ry = reinterpret_cast<const float4*>(lz + __float_as_int(ty[j]));
+          const float4 p0 = rx[0], p1 = rx[1], q0 = ry[0], q1 = ry[1];
+          wx[0] = p0.x; wx[1] = p0.y; wx[2 % NT] = p0.z; wx[3 % NT] = p0.w;
+          wx[4 % NT] = p1.x; wx[5 % NT] = p1.y; wx[6 % NT] = p1.z; wx[7 % NT] = p1.w;
+          wy[0] = q0.x; wy[1] = q0.y; wy[2 % NT] = q0.z; wy[3 % NT] = q0.w;
+          wy[4 % NT] = q1.x; wy[5 % NT] = q1.y; wy[6 % NT] = q1.z; wy[7 % NT] = q1.w;
+        } else {
+          weights_from_frac<INTERP, float>(s, tx[j], wx);
+          weights_from_frac<INTERP, float>(s, ty[j], wy);
+        }
+        const float* tp = tile_lds + (ad[j] < 0 ? 0 : ad[j]);
+        float o = 0.f;
+#pragma unroll
+        for (int r = 0; r < NT; r++) {
+          const float* tr = tp + r * a.pitch;
+          float rs = wx[0] * tr[0];
+#pragma unroll
+          for (int c = 1; c < NT; c++) rs = ipa_fma(wx[c], tr[c], rs);
+          o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+        }
+        if (ad[j] >= 0 && x < a.dw && y < a.dh)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << 2, (int)((long)y * a.dpitch) << 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // 3. rare: footprints the box does not hold, through the gather kernel's sample()
+    if (slow) {
+#pragma unroll 1
+      for (int j = 0; j < kWarpTilePx; j++) {
+        if (!((slow >> j) & 1u)) continue;
+        const int y = y0 + (int)wave + 4 * j;
+        if (x >= a.dw || y >= a.dh) continue;
+        double sx, sy;
+        coord.get(x, y, sx, sy);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tile_slow_sample<INTERP>(s, sx, sy, a.cval)), drs,
+                                              x << 2, (int)((long)y * a.dpitch) << 2, 0);
+      }
+    }
+  }
+}
+
+// The LDS box a launch needs: the largest source box over all tiles.  Returns false when the
+// warp is not one for this kernel (the plane's horizon crosses the picture, or a tile's box
+// exceeds the budget: strong minification).
+template <int NT>
+static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int* pitch,
+                                 int* rows) {
+  // w = m6 u + m7 v + m8 keeps one sign over the picture when it does at the four corners
+  const double wc[4] = {m[8], m[6] * (dw - 1) + m[8], m[7] * (dh - 1) + m[8],
+                        m[6] * (dw - 1) + m[7] * (dh - 1) + m[8]};
+  for (int k = 0; k < 4; k++)
+    if (!(wc[k] * wc[0] > 0.0) || !(fabs(wc[k]) > 1e-12)) return false;
+  auto at = [&](int u, int v, double& sx, double& sy) {
+    const double du = u, dv = v;
+    const double X = m[0] * du + m[1] * dv + m[2], Y = m[3] * du + m[4] * dv + m[5];
+    const double W = m[6] * du + m[7] * dv + m[8], iw = 1.0 / W;
+    sx = X * iw;
+    sy = Y * iw;
+  };
+  int mw = 0, mh = 0;
+  for (int y0 = 0; y0 < dh; y0 += kWarpTileH)
+    for (int x0 = 0; x0 < dw; x0 += kWarpTileW) {
+      const int x1 = x0 + kWarpTileW - 1 < dw ? x0 + kWarpTileW - 1 : dw - 1;
+      const int y1 = y0 + kWarpTileH - 1 < dh ? y0 + kWarpTileH - 1 : dh - 1;
+      double lox = 0, hix = 0, loy = 0, hiy = 0;
+      for (int k = 0; k < 4; k++) {
+        double cx, cy;
+        at((k & 1) ? x1 : x0, (k & 2) ? y1 : y0, cx, cy);
+        if (!(fabs(cx) < 1.0e6) || !(fabs(cy) < 1.0e6)) return false;
+        if (k == 0) { lox = hix = cx; loy = hiy = cy; }
+        lox = cx < lox ? cx : lox; hix = cx > hix ? cx : hix;
+        loy = cy < loy ? cy : loy; hiy = cy > hiy ? cy : hiy;
+      }
+      int f, bw, bh;
+      tile_axis_box<NT>(lox, hix, sw, f, bw);
+      tile_axis_box<NT>(loy, hiy, sh, f, bh);
+      mw = bw > mw ? bw : mw;
+      mh = bh > mh ? bh : mh;
+    }
+  if (mw < NT || mh < NT) return false;   // nothing of the source in sight: the gather kernel's cval fill
+  mw |= 1;
+  if ((long)mw * mh * 4 > kWarpTileLdsBytes) return false;
+  *pitch = mw;
+  *rows = mh;
+  return true;
+}
+
+// The LDS row pitch: the tap reads of a wave are 64 lanes walking along the output row, i.e. along
+// a slanted line of the box - lane l at row floor(y + l dy), column floor(x + l dx) - and
+// ds_read_b32 / ds_read2_b32 serve 32 lanes per cycle from 32 banks.  Some residues of the pitch
+// mod 32 put every row step of that line back on the banks just used (Lanczos4, 16 x 4K: 1.0 ->
+// 7.7 ms at 45 degrees with pitch = 31 mod 32, profiles/r04_micro.txt).  Counted here on the
+// lines of a few output rows for the odd pitches from the box width up; the cheapest wins.
+static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch, int rows) {
+  auto at = [&](double u, double v, double& sx, double& sy) {
+    const double W = m[6] * u + m[7] * v + m[8], iw = W != 0.0 ? 1.0 / W : 0.0;
+    sx = (m[0] * u + m[1] * v + m[2]) * iw;
+    sy = (m[3] * u + m[4] * v + m[5]) * iw;
+  };
+  int best = min_pitch | 1;
+  long best_cost = -1;
+  for (int P = min_pitch | 1; P < (min_pitch | 1) + 32; P += 2) {
+    if ((long)P * rows * 4 > kWarpTileLdsBytes) break;
+    long cost = 0;
+    for (int py = 0; py < 3; py++)
+      for (int px = 0; px < 3; px++)
+        for (int sub = 0; sub < 4; sub++) {
+          const double u0 = (dw - 64) * (0.1 + 0.4 * px), v0 = (dh - 1) * (0.1 + 0.4 * py) + sub;
+          double ox, oy;
+          at(u0, v0, ox, oy);
+          for (int g = 0; g < 64; g += 32) {
+            long addr[32];
+            int n = 0;
+            for (int l = g; l < g + 32; l++) {
+              double sx, sy;
+              at(u0 + l, v0, sx, sy);
+              const long aa = (long)floor(sy - oy + 0.37 * sub + 1024.0) * P +
+                              (long)floor(sx - ox + 0.21 * sub + 1024.0);
+              bool dup = false;
+              for (int k = 0; k < n; k++) dup = dup || addr[k] == aa;
+              if (!dup) addr[n++] = aa;
+            }
+            int cnt[32] = {0}, worst = 0;
+            for (int k = 0; k < n; k++) {
+              const int b = (int)(addr[k] & 31);
+              worst = ++cnt[b] > worst ? cnt[b] : worst;
+            }
+            cost += worst;
+          }
+        }
+    if (best_cost < 0 || cost < best_cost) {
+      best_cost = cost;
+      best = P;
+    }
+  }
+  return best;
+}
+
+}  // namespace ipa

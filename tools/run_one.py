@@ -1,6 +1,6 @@
 """Run the 4K fused headline a few times with given context knobs (for rocprofv3 passes).
 
-    python3 tools/run_one.py [--batch 16] [--steps 3] [--analytic] knob=value ...
+    python3 tools/run_one.py [--batch 16] [--steps 3] [--analytic] [--case cubic_maps|cubic_h|lanczos_h] knob=value ...
 """
 import os
 import sys
@@ -14,7 +14,7 @@ from imgprocessor_amd import ops  # noqa: E402
 
 def main():
     args = sys.argv[1:]
-    batch, steps, analytic, knobs = 16, 3, False, {}
+    batch, steps, analytic, knobs, case = 16, 3, False, {}, ''
     i = 0
     while i < len(args):
         a = args[i]
@@ -22,6 +22,8 @@ def main():
             batch = int(args[i + 1]); i += 1
         elif a == '--steps':
             steps = int(args[i + 1]); i += 1
+        elif a == '--case':
+            case = args[i + 1]; i += 1
         elif a == '--analytic':
             analytic = True
         elif '=' in a:
@@ -39,8 +41,21 @@ def main():
     dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
     src = ctx.to_device(np.random.default_rng(0).random((batch, h, w), dtype=np.float32))
     dst = ctx.empty((batch, h, w), np.float32)
+    H = np.array([[1.02, 0.03, -40.0], [-0.02, 0.98, 30.0], [4e-6, -3e-6, 1.0]])
+    if case.startswith('rot'):   # rot<deg>_<interp>: the homography of tools/angle_sweep.py
+        from angle_sweep import rot_persp
+        deg, interp = case[3:].split('_', 1)
+        H = rot_persp(h, w, float(deg))
     for _ in range(steps):
-        if analytic:
+        if case == 'cubic_maps':
+            ops.remap(src, dmx, dmy, interpolation='cubic', out=dst)
+        elif case == 'cubic_h':
+            ops.warp_perspective(src, H, (h, w), interpolation='cubic', out=dst)
+        elif case.startswith('rot'):
+            ops.warp_perspective(src, H, (h, w), interpolation=interp, out=dst)
+        elif case == 'lanczos_h':
+            ops.warp_perspective(src, H, (h, w), interpolation='lanczos4', out=dst)
+        elif analytic:
             ops.undistort_conv2d(src, K, dist, K, k5, out=dst)
         else:
             ops.remap_conv2d(src, dmx, dmy, k5, out=dst)
