@@ -41,7 +41,7 @@ struct ipa_tuning {
   int u8_lz_lds = 1;      // uint8 Lanczos4: OpenCV's 128 KB weight table in LDS (0: weights formed per sample)
   int lens_cache = 1;     // fused undistort + filter: lens model evaluated once per (K, dist, newK, size)
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
-  int tile_warp = 2;      // perspective warps of float32 frames with the tile's source box in LDS (tile_warp.hpp):
+  int tile_warp = 1;      // perspective warps of float32 frames with the tile's source box in LDS (tile_warp.hpp):
                           // 0 never, 1 where it pays, 2 whenever the homography is covered
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates
@@ -79,6 +79,7 @@ struct ipa_ctx {
   // host-side walk over the tiles that a repeated call does not pay again (0.4 ms per 4K call)
   double tile_warp_key[14];
   int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0;
+  double tile_warp_drift = 0, tile_warp_step = 0, tile_warp_fetch = 0;   // see tile_warp_pays()
   // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
   // and the source + geometry it belongs to: ring_plan_prepare's hint
   unsigned* ring_hint = nullptr;

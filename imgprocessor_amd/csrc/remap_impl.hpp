@@ -466,10 +466,28 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
   return 0;
 }
 
-// float32 perspective warps on the tile kernel (tile_warp.hpp); 1: not covered
+// float32 perspective warps on the tile kernel (tile_warp.hpp); 1: not covered / does not pay.
+// Where it pays (tile_warp = 1), measured against the ring + gather kernels on 480p ... 8K frames,
+// batches of 1 ... 16, rotations, perspective quadrilaterals and zooms (profiles/r04_micro.txt):
+//   bilinear  batches of 8+ frames and 64+ Mpx (4+ frames from 100 Mpx) whose boxes stay small
+//             (fetch <= 1.35) or whose rows drift (0.1+ rows per pixel - the gathers then pay per
+//             cache line) while the boxes stay moderate (fetch <= 2.6);
+//   bicubic   batches of 4+ frames with 48+ Mpx or a drift of 0.05+, boxes up to fetch 3;
+//   Lanczos4  any batch once the rows drift (0.03+) or the picture shrinks (step 1.2+): at a mild
+//             perspective the ring kernel's 8-byte LDS reads keep it ahead.
+static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, long px) {
+  const double d = ctx->tile_warp_drift, st = ctx->tile_warp_step, g = ctx->tile_warp_fetch;
+  const double work = (double)n_frames * (double)px;
+  if (base == IPA_INTER_LINEAR)
+    return ((n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6)) &&
+           (g <= 1.35 || (d >= 0.1 && g <= 2.6));
+  if (base == IPA_INTER_LANCZOS4) return d >= 0.03 || st >= 1.2;
+  return n_frames >= 4 && (work >= 48e6 || d >= 0.05) && g <= 3.0;
+}
+
 template <int INTERP>
 static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const HomographyCoord& coord,
-                            int n_frames) {
+                            int n_frames, int base) {
   TileWarpArgs t;
   {
     double key[14] = {(double)INTERP, (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
@@ -480,10 +498,14 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
       ctx->tile_warp_ok = ok ? 1 : 0;
       ctx->tile_warp_rows = rows;
       ctx->tile_warp_pitch = ok ? tile_warp_pitch(coord.m, p.dh, p.dw, pitch, rows) : 0;
+      if (ok)
+        tile_warp_measure(coord.m, p.dh, p.dw, pitch, rows, &ctx->tile_warp_drift, &ctx->tile_warp_step,
+                          &ctx->tile_warp_fetch);
       memcpy(ctx->tile_warp_key, key, sizeof key);
       ctx->tile_warp_valid = 1;
     }
     if (!ctx->tile_warp_ok) return 1;
+    if (ctx->tune.tile_warp < 2 && !tile_warp_pays(ctx, base, n_frames, (long)p.dh * p.dw)) return 1;
     t.pitch = ctx->tile_warp_pitch;
     t.rows = ctx->tile_warp_rows;
   }
@@ -599,9 +621,9 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   if constexpr (kHom) {
     if (ctx->tune.tile_warp && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
         base != IPA_INTER_NEAREST && (unsigned long)p.tiles * a.n_frames < (1ul << 30)) {
-      int trc = base == IPA_INTER_LINEAR ? tile_warp_launch<kLinear>(ctx, p, coord, a.n_frames)
-                : base == IPA_INTER_LANCZOS4 ? tile_warp_launch<kLanczos4>(ctx, p, coord, a.n_frames)
-                                             : tile_warp_launch<kCubic>(ctx, p, coord, a.n_frames);
+      int trc = base == IPA_INTER_LINEAR ? tile_warp_launch<kLinear>(ctx, p, coord, a.n_frames, base)
+                : base == IPA_INTER_LANCZOS4 ? tile_warp_launch<kLanczos4>(ctx, p, coord, a.n_frames, base)
+                                             : tile_warp_launch<kCubic>(ctx, p, coord, a.n_frames, base);
       if (trc == 0) {
         IPA_HIP(ctx, hipGetLastError());
         return IPA_OK;

@@ -119,7 +119,7 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, d
 }
 
 template <int INTERP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic ? 4 : 3, 8)))
 tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
@@ -186,8 +186,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
       ix0 = (qx >> 5) - 3;
       iy0 = (qy >> 5) - 3;
-      tx[j] = __int_as_float((qx & 31) << 3);
-      ty[j] = __int_as_float((qy & 31) << 3);
+      tx[j] = __int_as_float(((qx & 31) << 3) | ((qy & 31) << 19));   // float offsets of both table rows
+      ty[j] = 0.f;
     } else {
       axis_frac<INTERP, float, double>(s, sx, ix0, tx[j]);
       axis_frac<INTERP, float, double>(s, sy, iy0, ty[j]);
@@ -196,6 +196,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     const bool in = ok && cx >= 0 && cy >= 0 && cx + NT <= bw && cy + NT <= bh;
     ad[j] = in ? __mul24(cy, a.pitch) + cx : -1;
     slow |= in ? 0u : 1u << j;
+    __builtin_amdgcn_sched_barrier(0);   // one pixel's double arithmetic at a time (registers)
   }
 
   float* dst0 = reinterpret_cast<float*>(a.dst);
@@ -211,7 +212,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   // of a wave and its first 4 loads of the far columns are REQUESTED while the previous frame is
   // being sampled and written to LDS after it (box_issue / box_commit): the ~1 us of an HBM
   // round trip is then behind the samples and stores of a frame, not in front of them.
-  constexpr int kRowsFly = 12;
+  constexpr int kRowsFly = INTERP == kCubic ? 10 : 12;   // (a box of 35 / 37 / 41 rows at no rotation)
   const int voff = (int)lane << 2;
   const bool c0 = (int)lane < bw;
   const int e = bw - 64;
@@ -221,6 +222,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   const bool cl = lc < bw;
   const int soff0 = (__mul24(by0, a.spitch) + bx0) << 2;
   float v0[kRowsFly], v1[4];
+  // (addresses stepped from one value the compiler cannot carry across the frame loop: held as
+  // loop invariants they are 40 registers)
   auto box_issue = [&](const __amdgpu_buffer_rsrc_t& rs) {
 #pragma unroll
     for (int u = 0; u < kRowsFly; u++) {
@@ -228,35 +231,55 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       v0[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
     }
     if (e > 0) {
+      int r = (int)wave * rstep + lr;
+      asm volatile("" : "+v"(r));
+      int off = (__mul24(r, a.spitch) + lc) << 2;
+      const int ostep = __mul24(4 * rstep, a.spitch) << 2;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = ((int)wave + 4 * u) * rstep + lr;
-        const bool live = cl && r < bh;
-        v1[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, live ? (__mul24(r, a.spitch) + lc) << 2 : 0, soff0, 0));
+        v1[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, cl && r < bh ? off : 0, soff0, 0));
+        r += 4 * rstep;
+        off += ostep;
       }
     }
   };
   auto box_commit = [&]() {
+    int la = __mul24((int)wave, a.pitch) + (int)lane;
+    asm volatile("" : "+v"(la));
+    const int lstep = 4 * a.pitch;
 #pragma unroll
     for (int u = 0; u < kRowsFly; u++) {
-      const int r = (int)wave + 4 * u;
-      if (r < bh && c0) tile_lds[__mul24(r, a.pitch) + (int)lane] = v0[u];
+      if ((int)wave + 4 * u < bh && c0) tile_lds[la] = v0[u];
+      la += lstep;
     }
     if (e > 0) {
+      int r = (int)wave * rstep + lr;
+      asm volatile("" : "+v"(r));
+      int lb = __mul24(r, a.pitch) + lc;
+      const int bstep = __mul24(4 * rstep, a.pitch);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        const int r = ((int)wave + 4 * u) * rstep + lr;
-        if (cl && r < bh) tile_lds[__mul24(r, a.pitch) + lc] = v1[u];
+        if (cl && r < bh) tile_lds[lb] = v1[u];
+        r += 4 * rstep;
+        lb += bstep;
       }
     }
   };
   // (boxes taller than 4 kRowsFly rows - Lanczos4 under a rotation of 30 degrees and more - or
   // with many far columns: the rest, read when the frame's turn has come)
   auto box_rest = [&](const __amdgpu_buffer_rsrc_t& rs) {
+    constexpr int kMore = 8;   // rows in flight
 #pragma unroll 1
-    for (int r = (int)wave + 4 * kRowsFly; r < bh; r += 4) {
-      const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
-      if (c0) tile_lds[__mul24(r, a.pitch) + (int)lane] = t;
+    for (int r0 = (int)wave + 4 * kRowsFly; r0 < bh; r0 += 4 * kMore) {
+      float t[kMore];
+#pragma unroll
+      for (int u = 0; u < kMore; u++) {
+        const int r = r0 + 4 * u < bh ? r0 + 4 * u : bh - 1;
+        t[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
+      }
+#pragma unroll
+      for (int u = 0; u < kMore; u++)
+        if (r0 + 4 * u < bh && c0) tile_lds[__mul24(r0 + 4 * u, a.pitch) + (int)lane] = t[u];
     }
     if (e > 0) {
 #pragma unroll 1
@@ -294,6 +317,12 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     __syncthreads();
     if (inside && f + 1 < f1)
       box_issue(make_rsrc(a.src + (long)(f + 1) * a.src_frame_bytes, a.src_bytes));
+    // (the weights are formed anew for every frame: kept across the frame loop they are 8 registers
+    // per pixel the compiler would hold - bicubic 178 registers, 2 workgroups per CU)
+    if constexpr (INTERP == kCubic) {
+#pragma unroll
+      for (int j = 0; j < kWarpTilePx; j++) asm volatile("" : "+v"(tx[j]), "+v"(ty[j]));
+    }
     // 2. the samples, kGroup at a time (their taps in flight together)
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
     constexpr int kGroup = INTERP == kLinear ? 4 : (INTERP == kCubic ? 2 : 1);
@@ -304,8 +333,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const int y = y0 + (int)wave + 4 * j;
         float wx[NT], wy[NT];
         if constexpr (kLz) {
-          const float4* rx = reinterpret_cast<const float4*>(lz + __float_as_int(tx[j]));
-          const float4* ry = reinterpret_cast<const float4*>(lz + __float_as_int(ty[j]));
+          const float4* rx = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) & 0xffff));
+          const float4* ry = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) >> 16));
           const float4 p0 = rx[0], p1 = rx[1], q0 = ry[0], q1 = ry[1];
           wx[0] = p0.x; wx[1] = p0.y; wx[2 % NT] = p0.z; wx[3 % NT] = p0.w;
           wx[4 % NT] = p1.x; wx[5 % NT] = p1.y; wx[6 % NT] = p1.z; wx[7 % NT] = p1.w;
@@ -347,8 +376,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 }
 
 // The LDS box a launch needs: the largest source box over all tiles.  Returns false when the
-// warp is not one for this kernel (the plane's horizon crosses the picture, or a tile's box
-// exceeds the budget: strong minification).
+// warp is not one for this kernel (the plane's horizon crosses the picture, or a tile's box is
+// wider than 128 columns or exceeds the LDS budget: strong minification).
 template <int NT>
 static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int* pitch,
                                  int* rows) {
@@ -385,11 +414,41 @@ static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw
       mh = bh > mh ? bh : mh;
     }
   if (mw < NT || mh < NT) return false;   // nothing of the source in sight: the gather kernel's cval fill
+  if (mw > 128) return false;   // the fill reads columns 0-63 and 64-127 of a box
   mw |= 1;
   if ((long)mw * mh * 4 > kWarpTileLdsBytes) return false;
   *pitch = mw;
   *rows = mh;
   return true;
+}
+
+// What decides between this kernel and the row-walking ones (remap_impl.hpp), from the homography:
+//   drift  rows of the source an output row crosses per pixel, |d sy / d u| (largest of 9 probes);
+//   step   source pixels per output pixel along either axis (> 1: the picture shrinks);
+//   fetch  cells of the largest box per pixel of a tile (what a tile reads over what it writes).
+static inline void tile_warp_measure(const double* m, int dh, int dw, int pitch, int rows,
+                                     double* drift, double* step, double* fetch) {
+  auto at = [&](double u, double v, double& sx, double& sy) {
+    const double W = m[6] * u + m[7] * v + m[8], iw = W != 0.0 ? 1.0 / W : 0.0;
+    sx = (m[0] * u + m[1] * v + m[2]) * iw;
+    sy = (m[3] * u + m[4] * v + m[5]) * iw;
+  };
+  double d = 0, st = 0;
+  for (int py = 0; py < 3; py++)
+    for (int px = 0; px < 3; px++) {
+      const double u = (dw - 2) * 0.5 * px, v = (dh - 2) * 0.5 * py;
+      double x0, y0, x1, y1, x2, y2;
+      at(u, v, x0, y0);
+      at(u + 1, v, x1, y1);
+      at(u, v + 1, x2, y2);
+      const double a = hypot(x1 - x0, y1 - y0), b = hypot(x2 - x0, y2 - y0);
+      d = fabs(y1 - y0) > d ? fabs(y1 - y0) : d;
+      st = a > st ? a : st;
+      st = b > st ? b : st;
+    }
+  *drift = d;
+  *step = st;
+  *fetch = (double)pitch * rows / (kWarpTileW * kWarpTileH);
 }
 
 // The LDS row pitch: the tap reads of a wave are 64 lanes walking along the output row, i.e. along

@@ -85,7 +85,8 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   "strip_h" (0 = by launch size), "frames_inner", "frames_wg", "frame_major", "big_wave",
  *   "big_fused", "stream_k", "pipe7", "ring_remap", "ring_min", "lens_cache", "u8_lz_lds",
  *   "stored_coords" (smallest batch whose homography / lens coordinates are evaluated once
- *   for all frames, 0 = never).
+ *   for all frames, 0 = never), "pipe", "tile_warp" (perspective warps of float32 frames with an
+ *   output tile's source box in LDS: 0 never, 1 where it pays, 2 whenever the homography fits).
  * Values are range-checked (IPA_ERR_BAD_ARG).  ipa_ctx_create reads the IPA_* environment
  * defaults once; no launch path consults the environment.  The reference has no counterpart
  * (its numba / cv2 calls take no launch parameters). */

@@ -1,0 +1,143 @@
+"""GPU: perspective warps on the tile kernel (csrc/tile_warp.hpp: the source box of a 64 x 32 output
+tile in LDS) - PerspectiveCorrection's cv2.warpPerspective (camera/PerspectiveCorrection.py:377-378,
+401-405) under rotations, where the row-walking kernels pay per cache line.  Against the oracle and,
+bit for bit, against the gather kernel over rotations, perspective, zooms, every interpolation and
+border mode, ragged sizes, batches that do not divide by the frames of a workgroup, coordinates
+outside the source and not finite.
+"""
+import numpy as np
+import pytest
+
+from .conftest import assert_close
+from .gpu_helpers import frames, same_bits
+
+pytestmark = pytest.mark.gpu
+
+INTERPS = ('linear', 'cubic', 'cubic_cv', 'linear_cv_q5', 'cubic_cv_q5', 'lanczos4')
+BORDERS = ('constant', 'replicate', 'reflect', 'wrap', 'reflect101')
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)
+    return imgprocessor_amd
+
+
+def rot_persp(h, w, deg, persp=(1e-4, 5e-5), shift=(0.0, 0.0), zoom=1.0):
+    a = np.deg2rad(deg)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    R = np.array([[zoom * np.cos(a), -zoom * np.sin(a), cx - zoom * (np.cos(a) * cx - np.sin(a) * cy) + shift[0]],
+                  [zoom * np.sin(a), zoom * np.cos(a), cy - zoom * (np.sin(a) * cx + np.cos(a) * cy) + shift[1]],
+                  [0, 0, 1.0]])
+    P = np.array([[1, 0, 0], [0, 1, 0], [persp[0], persp[1], 1.0]])
+    return P @ R
+
+
+def both(ia, src, M, shape, interp, border='constant', cval=0.25):
+    """the same warp on the gather / ring kernels (tile_warp = 0) and on the tile kernel (2)"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    d = ctx.to_device(src)
+    out = []
+    try:
+        for tw in (0, 2):
+            ctx.set_tuning(tile_warp=tw)
+            out.append(ops.warp_perspective(d, M, shape, interp, border, border_value=cval).get())
+    finally:
+        ctx.set_tuning(tile_warp=1)
+    return out
+
+
+@pytest.mark.parametrize('deg', [0, 3, 17, 45, 90, 133, 180, 271])
+@pytest.mark.parametrize('interp', INTERPS)
+def test_tile_kernel_has_the_gather_kernels_bits(ia, deg, interp):
+    h, w, n = 301, 517, 3
+    src = frames(n, h, w)
+    M = rot_persp(h, w, deg, shift=(40.0, -25.0) if deg == 17 else (0.0, 0.0))
+    for border in BORDERS:
+        for shape in ((h, w), (h + 13, w - 7)):
+            ref, got = both(ia, src, M, shape, interp, border)
+            same_bits(got, ref, '%s %s %d deg -> %s' % (interp, border, deg, shape))
+
+
+@pytest.mark.parametrize('interp', ['linear', 'cubic', 'lanczos4'])
+def test_tile_kernel_against_the_oracle(ia, oracle, interp):
+    h, w, n = 150, 260, 2
+    src = frames(n, h, w)
+    oi = {'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS, 'lanczos4': oracle.LANCZOS4}[interp]
+    for deg, zoom in ((28.0, 1.0), (-61.0, 0.8), (5.0, 1.3)):
+        M = rot_persp(h, w, deg, zoom=zoom)
+        _, got = both(ia, src, M, (h, w), interp, 'constant', 0.5)
+        for f in range(n):
+            want = oracle.warp_perspective(src[f], M, (h, w), oi, oracle.CONSTANT, 0.5)
+            assert_close(got[f], want, 1e-5, 1e-5 * np.abs(want).max(), '%s %g deg frame %d' % (interp, deg, f))
+
+
+@pytest.mark.parametrize('n', [1, 5, 8, 9, 19])
+def test_batches_that_do_not_divide_by_the_frames_of_a_workgroup(ia, n):
+    h, w = 130, 200
+    src = frames(n, h, w)
+    M = rot_persp(h, w, 23.0)
+    for interp in ('linear', 'cubic', 'lanczos4'):
+        ref, got = both(ia, src, M, (h, w), interp)
+        same_bits(got, ref, '%s, %d frames' % (interp, n))
+
+
+def test_sizes_around_the_tile(ia):
+    for (h, w) in ((1, 1), (2, 3), (31, 63), (32, 64), (33, 65), (64, 128), (70, 9), (9, 700)):
+        src = frames(2, h, w)
+        for deg in (0.0, 37.0):
+            M = rot_persp(h, w, deg, persp=(1e-3 / max(w, 8), 0.0))
+            for interp in ('linear', 'cubic_cv_q5', 'lanczos4'):
+                for border in ('constant', 'reflect'):
+                    ref, got = both(ia, src, M, (h, w), interp, border)
+                    same_bits(got, ref, '%dx%d %s %s %g deg' % (h, w, interp, border, deg))
+
+
+def test_coordinates_outside_the_source_and_not_finite(ia):
+    h, w = 120, 180
+    src = frames(2, h, w)
+    cases = {
+        'far outside': np.array([[1.0, 0, 5000.0], [0, 1.0, -3000.0], [0, 0, 1.0]]),
+        'half outside': np.array([[1.0, 0.2, -90.0], [-0.2, 1.0, 60.0], [0, 0, 1.0]]),
+        'horizon in the picture': np.array([[1.0, 0, 0], [0, 1.0, 0], [0.02, 0.0, -1.0]]),
+        'huge zoom out': np.array([[40.0, 0, 0], [0, 40.0, 0], [0, 0, 1.0]]),
+        # boxes of 120-135 columns: around the 128 the kernel's fill covers (found by tools/fuzz_paths.py)
+        'zoom out 1.85': np.array([[1.85, 0.03, -70.0], [-0.03, 1.85, -40.0], [0, 0, 1.0]]),
+        'zoom out 2': np.array([[1.99, -0.067, -80.0], [0.069, 1.999, -50.0], [0, 0, 1.0]]),
+        'degenerate': np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 0.0]]),
+    }
+    for name, M in cases.items():
+        for interp in ('linear', 'cubic', 'lanczos4'):
+            for border in ('constant', 'replicate', 'wrap'):
+                ref, got = both(ia, src, M, (h, w), interp, border)
+                same_bits(got, ref, '%s %s %s' % (name, interp, border))
+
+
+def test_default_policy_gives_the_same_bits(ia):
+    """tile_warp = 1 (where it pays) takes the tile kernel for some of these and not for others"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 240, 400, 8
+    src = frames(n, h, w)
+    d = ctx.to_device(src)
+    for deg in (0.5, 9.0, 60.0):
+        M = rot_persp(h, w, deg, persp=(2e-5, 1e-5))
+        for interp in ('linear', 'cubic', 'lanczos4'):
+            ref, _ = both(ia, src, M, (h, w), interp)
+            got = ops.warp_perspective(d, M, (h, w), interp, 'constant', border_value=0.25).get()
+            same_bits(got, ref, 'policy %s %g deg' % (interp, deg))
+
+
+def test_repeated_calls_with_changing_homographies(ia):
+    """the host-side box of the last homography is cached in the context: a new matrix, size or
+    interpolation must not reuse it"""
+    h, w = 160, 230
+    src = frames(4, h, w)
+    seq = [(rot_persp(h, w, 12.0), (h, w), 'lanczos4'), (rot_persp(h, w, 12.0), (h, w), 'cubic'),
+           (rot_persp(h, w, 70.0), (h, w), 'cubic'), (rot_persp(h, w, 70.0), (h - 20, w + 11), 'cubic'),
+           (rot_persp(h, w, 12.0), (h, w), 'lanczos4')]
+    for M, shape, interp in seq:
+        ref, got = both(ia, src, M, shape, interp)
+        same_bits(got, ref, 'sequence %s %s' % (interp, shape))

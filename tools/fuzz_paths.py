@@ -89,11 +89,13 @@ def main():
                                                             cval, cmode))
             if (dh, dw) == (h, w) else None,
         }
-        plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0, stored_coords=0, pipe=1)
+        plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0, stored_coords=0, pipe=1, tile_warp=0)
         alts = [dict(ring_remap=2), dict(lens_cache=1), dict(frames_wg=1),
                 dict(ring_remap=2, lens_cache=1, frames_wg=1),
                 dict(frames_wg=1, stored_coords=1),     # homography coordinates stored once per batch
-                dict(pipe=0)]                           # compiler-scheduled loops everywhere
+                dict(pipe=0),                           # compiler-scheduled loops everywhere
+                dict(tile_warp=2),                      # homography warps with the tile's box in LDS
+                dict(tile_warp=1, ring_remap=1, stored_coords=4)]   # the default policy
         for name, fn in calls.items():
             if fn is None:
                 continue
