@@ -118,7 +118,7 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
                             const double* kx, int nkx, void* d_dst, int dst_dtype, int dh, int dw,
                             long dst_pitch, int n_frames, long src_frame_stride,
                             long dst_frame_stride, int interp, int border_mode, double border_value,
-                            int cby, int cbx) {
+                            int cby, int cbx, bool prefer_two = false) {
   IPA_REQUIRE(ctx, ky && kx && nky > 0 && nkx > 0 && (nky & 1) && (nkx & 1),
               "ky / kx must be given with odd lengths");
   IPA_REQUIRE(ctx, dst_dtype == IPA_F32, "remap + separable filter writes float32");
@@ -126,7 +126,7 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   // bicubic: built and correct, but 16 taps per sample on the K-1 extra halo rows of every
   // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
   const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9) &&
-                          src_dtype == IPA_F32 && base == IPA_INTER_LINEAR;
+                          src_dtype == IPA_F32 && base == IPA_INTER_LINEAR && !prefer_two;
   if (!one_kernel) {
     IPA_REQUIRE(ctx, dh > 0 && dw > 0 && n_frames >= 1, "empty image");
     int rc = ipa_ws_reserve(ctx, (size_t)n_frames * dh * dw * 4);
@@ -146,6 +146,35 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   else ipa_fused_sep_launch_b(ctx, f, q);
   IPA_HIP(ctx, hipGetLastError());
   return IPA_OK;
+}
+
+// A homography whose output rows drift across source rows (a rotation of a few degrees) is where
+// the fused kernels lose: their gathers pay per cache line a wave touches (16 x 4K, perspective
+// warp + separable 9+9: 0.34 ms at no rotation, 0.72 at 7 degrees, 1.66 at 45).  For batches
+// the tile warp kernel takes (remap_impl.hpp: tile_warp_pays) the chain then runs as two
+// launches - tile warp into the workspace, filter - whose time hardly depends on the angle
+// (0.52 - 0.66 ms); same results (the fused kernels round the remapped rows to float32 too).
+static bool rotated_warp_in_two_launches(const ipa_ctx* ctx, const double* m, int src_dtype,
+                                         int dst_dtype, int interp, int dh, int dw, int n_frames) {
+  if (!ctx->tune.tile_warp || src_dtype != IPA_F32 || dst_dtype != IPA_F32) return false;
+  if ((interp & 0xff) != IPA_INTER_LINEAR) return false;
+  if (n_frames < 8 || (double)n_frames * dh * dw < 64e6) return false;
+  auto at = [&](double u, double v, double& sx, double& sy) {
+    const double W = m[6] * u + m[7] * v + m[8], iw = W != 0.0 ? 1.0 / W : 0.0;
+    sx = (m[0] * u + m[1] * v + m[2]) * iw;
+    sy = (m[3] * u + m[4] * v + m[5]) * iw;
+  };
+  double drift = 0;
+  for (int py = 0; py < 3; py++)
+    for (int px = 0; px < 3; px++) {
+      const double u = (dw - 2) * 0.5 * px, v = (dh - 2) * 0.5 * py;
+      double x0, y0, x1, y1;
+      at(u, v, x0, y0);
+      at(u + 1, v, x1, y1);
+      if (!(fabs(y1 - y0) < 1e6)) return false;
+      drift = fabs(y1 - y0) > drift ? fabs(y1 - y0) : drift;
+    }
+  return drift >= (ctx->tune.tile_warp > 1 ? 0.0 : 0.045);
 }
 
 extern "C" {
@@ -226,10 +255,12 @@ int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_
                                     dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,
                                     border_mode, border_value);
   };
+  const bool rotated = dh > 0 && dw > 0 &&
+                       rotated_warp_in_two_launches(ctx, M, src_dtype, dst_dtype, interp, dh, dw, n_frames);
   return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
                           dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
                           dst_frame_stride, interp, border_mode, border_value, conv_border_y,
-                          conv_border_x);
+                          conv_border_x, rotated);
 }
 
 int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw,
@@ -353,6 +384,13 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
   void* tmp = nullptr;
   int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;
+  if (big != 0 && kernel && dh > 0 && dw > 0 &&
+      rotated_warp_in_two_launches(ctx, M, src_dtype, dst_dtype, interp, dh, dw, n_frames)) {
+    int rc = ipa_ws_reserve(ctx, (size_t)n_frames * dh * dw * 4);
+    if (rc) return rc;
+    tmp = ctx->ws;
+    big = 0;
+  }
   if (big == 0) {
     int rc = ipa_warp_perspective_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, tmp, IPA_F32, dh,
                                       dw, dw, n_frames, src_frame_stride, (long)dh * dw, interp,

@@ -141,3 +141,28 @@ def test_repeated_calls_with_changing_homographies(ia):
     for M, shape, interp in seq:
         ref, got = both(ia, src, M, shape, interp)
         same_bits(got, ref, 'sequence %s %s' % (interp, shape))
+
+
+def test_rotated_fused_chains_in_two_launches_have_the_same_bits(ia):
+    """warp + filter of a batch the tile kernel takes, under a rotation: tile warp into the
+    workspace, then the filter (fused.hip: rotated_warp_in_two_launches) - the bits of the one
+    fused kernel"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    n, h, w = 8, 2160, 3840
+    rng = np.random.default_rng(3)
+    d = ctx.to_device(rng.random((n, h, w), dtype=np.float32))
+    M = rot_persp(h, w, 5.0, persp=(2e-6, 1e-6))
+    g9 = ops.gaussian_kernel1d(1.0)
+    k5 = np.outer(g9[2:7], g9[2:7])
+    k5 /= k5.sum()
+    out = {}
+    try:
+        for tw in (0, 1):
+            ctx.set_tuning(tile_warp=tw)
+            out[tw] = (ops.warp_perspective_sepconv2d(d, M, (h, w), g9, g9).get(),
+                       ops.warp_perspective_conv2d(d, M, (h, w), k5).get())
+    finally:
+        ctx.set_tuning(tile_warp=1)
+    same_bits(out[1][0], out[0][0], 'warp + separable 9+9')
+    same_bits(out[1][1], out[0][1], 'warp + dense 5x5')
