@@ -21,6 +21,7 @@
 #pragma once
 
 #include "sampler.hpp"
+#include "ring_remap.hpp"   // pk_fma_half / pk_mul_half, lds_read_b64, lds_wait_all
 
 namespace ipa {
 
@@ -123,6 +124,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP
 tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
+  // LDS index of box cell (row r, column c).  Lanczos4 keeps the rows in interleaved pairs - pair
+  // p = {row 2p, row 2p + 1}, column c of both at float 2c - so that ONE aligned ds_read_b64
+  // (256 B/clk, twice ds_read2_b32) fetches two tap rows of a column: a footprint is 5 pairs x 8
+  // columns = 40 reads instead of 64 dwords in 32 (the scheme of ring_remap.hpp's Lanczos4 ring)
+  auto cell = [&](int r, int c) {
+    if constexpr (kLz) return __mul24(r >> 1, 2 * a.pitch) + 2 * c + (r & 1);
+    else return __mul24(r, a.pitch) + c;
+  };
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   __shared__ double corner[8];
   __shared__ __attribute__((aligned(16))) float lz[kLz ? 256 : 4];
@@ -194,7 +203,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     }
     const int cx = ix0 - bx0, cy = iy0 - by0;
     const bool in = ok && cx >= 0 && cy >= 0 && cx + NT <= bw && cy + NT <= bh;
-    ad[j] = in ? __mul24(cy, a.pitch) + cx : -1;
+    // (Lanczos4: first pair and column of the footprint in front, its row parity in bit 0)
+    ad[j] = !in ? -1 : (kLz ? ((__mul24(cy >> 1, 2 * a.pitch) + 2 * cx) << 1) | (cy & 1) : __mul24(cy, a.pitch) + cx);
     slow |= in ? 0u : 1u << j;
     __builtin_amdgcn_sched_barrier(0);   // one pixel's double arithmetic at a time (registers)
   }
@@ -244,7 +254,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     }
   };
   auto box_commit = [&]() {
-    int la = __mul24((int)wave, a.pitch) + (int)lane;
+    int la = cell((int)wave, (int)lane);   // rows wave + 4 u: 4 rows = 2 pairs further each
     asm volatile("" : "+v"(la));
     const int lstep = 4 * a.pitch;
 #pragma unroll
@@ -255,13 +265,10 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     if (e > 0) {
       int r = (int)wave * rstep + lr;
       asm volatile("" : "+v"(r));
-      int lb = __mul24(r, a.pitch) + lc;
-      const int bstep = __mul24(4 * rstep, a.pitch);
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (cl && r < bh) tile_lds[lb] = v1[u];
+        if (cl && r < bh) tile_lds[cell(r, lc)] = v1[u];
         r += 4 * rstep;
-        lb += bstep;
       }
     }
   };
@@ -279,7 +286,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       }
 #pragma unroll
       for (int u = 0; u < kMore; u++)
-        if (r0 + 4 * u < bh && c0) tile_lds[__mul24(r0 + 4 * u, a.pitch) + (int)lane] = t[u];
+        if (r0 + 4 * u < bh && c0) tile_lds[cell(r0 + 4 * u, (int)lane)] = t[u];
     }
     if (e > 0) {
 #pragma unroll 1
@@ -287,7 +294,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const int r = r0 + lr;
         const bool live = cl && r < bh;
         const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, live ? (__mul24(r, a.spitch) + lc) << 2 : 0, soff0, 0));
-        if (live) tile_lds[__mul24(r, a.pitch) + lc] = t;
+        if (live) tile_lds[cell(r, lc)] = t;
       }
     }
   };
@@ -311,7 +318,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const bool live = yy >= 0 && xx >= 0;
         const int off = live ? (__mul24(yy, a.spitch) + xx) << 2 : 0;
         const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0));
-        tile_lds[__mul24(row, a.pitch) + col] = live ? t : a.cval;
+        tile_lds[cell(row, col)] = live ? t : a.cval;
       }
     }
     __syncthreads();
@@ -319,31 +326,83 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       box_issue(make_rsrc(a.src + (long)(f + 1) * a.src_frame_bytes, a.src_bytes));
     // (the weights are formed anew for every frame: kept across the frame loop they are 8 registers
     // per pixel the compiler would hold - bicubic 178 registers, 2 workgroups per CU)
-    if constexpr (INTERP == kCubic) {
+    if constexpr (INTERP != kLinear) {   // (Lanczos4: the table rows read anew - 16 registers per pixel)
 #pragma unroll
       for (int j = 0; j < kWarpTilePx; j++) asm volatile("" : "+v"(tx[j]), "+v"(ty[j]));
     }
     // 2. the samples, kGroup at a time (their taps in flight together)
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
     constexpr int kGroup = INTERP == kLinear ? 4 : (INTERP == kCubic ? 2 : 1);
+    if constexpr (kLz) {
+      const int lbase = lds_address(tile_lds);
+      const int pstep = a.pitch << 3;   // bytes from pair to pair
+#pragma unroll
+      for (int j = 0; j < kWarpTilePx; j++) {
+        const int y = y0 + (int)wave + 4 * j;
+        const float4* rx = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) & 0xffff));
+        const float4* ry = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) >> 16));
+        const float4 a0 = rx[0], a1 = rx[1], b0 = ry[0], b1 = ry[1];
+        const v2f wp[4] = {v2f{a0.x, a0.y}, v2f{a0.z, a0.w}, v2f{a1.x, a1.y}, v2f{a1.z, a1.w}};
+        const float uy[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        const bool odd = (ad[j] & 1) != 0;
+        int ra = lbase + ((ad[j] < 0 ? 0 : ad[j] >> 1) << 2);
+        // 5 pairs x 8 columns: rows 2 pb .. 2 pb + 9, of which the sample uses 8 from row `odd` on.
+        // Three pairs, then two (all 40 reads at once are 80 registers: 210 in all, 2 waves per SIMD)
+        float rsum[10];
+        auto pairs = [&](auto first_, auto count_) {
+          constexpr int first = decltype(first_)::value, count = decltype(count_)::value;
+          v2f t[count][8];
+          static_for<0, count>([&](auto pp_) {
+            constexpr int pp = decltype(pp_)::value;
+            static_for<0, 8>([&](auto cc) {
+              constexpr int c = decltype(cc)::value;
+              t[pp][c] = lds_read_b64<c * 8>(ra);
+            });
+            ra += pstep;
+          });
+          lds_wait_all();
+#pragma unroll
+          for (int pp = 0; pp < count; pp++)
+#pragma unroll
+            for (int c = 0; c < 8; c++) asm volatile("" : "+v"(t[pp][c]));
+#pragma unroll
+          for (int pp = 0; pp < count; pp++) {
+            v2f rs = pk_mul_half<0>(wp[0], t[pp][0]);
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+              if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[pp][c], rs);
+              else rs = pk_fma_half<0>(wp[c >> 1], t[pp][c], rs);
+            }
+            rsum[2 * (first + pp)] = rs.x;
+            rsum[2 * (first + pp) + 1] = rs.y;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+        pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+        // both column sums - from the even and from the odd row on - and one select: selecting the
+        // eight row sums by `odd` first is as many instructions, and the compiler turns that form
+        // into an array in scratch memory indexed by `odd`
+        float oe = uy[0] * rsum[0], oo = uy[0] * rsum[1];
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+          oe = ipa_fma(uy[r], rsum[r], oe);
+          oo = ipa_fma(uy[r], rsum[r + 1], oo);
+        }
+        const float o = odd ? oo : oe;
+        if (ad[j] >= 0 && x < a.dw && y < a.dh)
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << 2, (int)((long)y * a.dpitch) << 2, 0);
+        __builtin_amdgcn_sched_barrier(0);   // one sample's taps in flight
+      }
+    } else {
 #pragma unroll
     for (int j0 = 0; j0 < kWarpTilePx; j0 += kGroup) {
 #pragma unroll
       for (int j = j0; j < j0 + kGroup; j++) {
         const int y = y0 + (int)wave + 4 * j;
         float wx[NT], wy[NT];
-        if constexpr (kLz) {
-          const float4* rx = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) & 0xffff));
-          const float4* ry = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) >> 16));
-          const float4 p0 = rx[0], p1 = rx[1], q0 = ry[0], q1 = ry[1];
-          wx[0] = p0.x; wx[1] = p0.y; wx[2 % NT] = p0.z; wx[3 % NT] = p0.w;
-          wx[4 % NT] = p1.x; wx[5 % NT] = p1.y; wx[6 % NT] = p1.z; wx[7 % NT] = p1.w;
-          wy[0] = q0.x; wy[1] = q0.y; wy[2 % NT] = q0.z; wy[3 % NT] = q0.w;
-          wy[4 % NT] = q1.x; wy[5 % NT] = q1.y; wy[6 % NT] = q1.z; wy[7 % NT] = q1.w;
-        } else {
-          weights_from_frac<INTERP, float>(s, tx[j], wx);
-          weights_from_frac<INTERP, float>(s, ty[j], wy);
-        }
+        weights_from_frac<INTERP, float>(s, tx[j], wx);
+        weights_from_frac<INTERP, float>(s, ty[j], wy);
         const float* tp = tile_lds + (ad[j] < 0 ? 0 : ad[j]);
         float o = 0.f;
 #pragma unroll
@@ -358,6 +417,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << 2, (int)((long)y * a.dpitch) << 2, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // 3. rare: footprints the box does not hold, through the gather kernel's sample()
     if (slow) {
@@ -378,6 +438,12 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 // The LDS box a launch needs: the largest source box over all tiles.  Returns false when the
 // warp is not one for this kernel (the plane's horizon crosses the picture, or a tile's box is
 // wider than 128 columns or exceeds the LDS budget: strong minification).
+// LDS bytes of a box (Lanczos4: whole row pairs, and the fifth pair of a footprint in the last rows)
+template <int NT>
+static inline long tile_warp_lds_bytes(int pitch, int rows) {
+  return NT == 8 ? (long)((rows + 3) / 2) * 2 * pitch * 4 : (long)pitch * rows * 4;
+}
+
 template <int NT>
 static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int* pitch,
                                  int* rows) {
@@ -416,7 +482,7 @@ static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw
   if (mw < NT || mh < NT) return false;   // nothing of the source in sight: the gather kernel's cval fill
   if (mw > 128) return false;   // the fill reads columns 0-63 and 64-127 of a box
   mw |= 1;
-  if ((long)mw * mh * 4 > kWarpTileLdsBytes) return false;
+  if (tile_warp_lds_bytes<NT>(mw, mh) > kWarpTileLdsBytes) return false;
   *pitch = mw;
   *rows = mh;
   return true;
@@ -457,6 +523,7 @@ static inline void tile_warp_measure(const double* m, int dh, int dw, int pitch,
 // mod 32 put every row step of that line back on the banks just used (Lanczos4, 16 x 4K: 1.0 ->
 // 7.7 ms at 45 degrees with pitch = 31 mod 32, profiles/r04_micro.txt).  Counted here on the
 // lines of a few output rows for the odd pitches from the box width up; the cheapest wins.
+template <int NT>
 static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch, int rows) {
   auto at = [&](double u, double v, double& sx, double& sy) {
     const double W = m[6] * u + m[7] * v + m[8], iw = W != 0.0 ? 1.0 / W : 0.0;
@@ -466,7 +533,7 @@ static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch
   int best = min_pitch | 1;
   long best_cost = -1;
   for (int P = min_pitch | 1; P < (min_pitch | 1) + 32; P += 2) {
-    if ((long)P * rows * 4 > kWarpTileLdsBytes) break;
+    if (tile_warp_lds_bytes<NT>(P, rows) > kWarpTileLdsBytes) break;
     long cost = 0;
     for (int py = 0; py < 3; py++)
       for (int px = 0; px < 3; px++)
@@ -480,8 +547,9 @@ static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch
             for (int l = g; l < g + 32; l++) {
               double sx, sy;
               at(u0 + l, v0, sx, sy);
-              const long aa = (long)floor(sy - oy + 0.37 * sub + 1024.0) * P +
-                              (long)floor(sx - ox + 0.21 * sub + 1024.0);
+              // (Lanczos4: 8-byte reads of row pairs - the banks of a dword read at half the row)
+              const long row = (long)floor(sy - oy + 0.37 * sub + 1024.0);
+              const long aa = (NT == 8 ? row >> 1 : row) * P + (long)floor(sx - ox + 0.21 * sub + 1024.0);
               bool dup = false;
               for (int k = 0; k < n; k++) dup = dup || addr[k] == aa;
               if (!dup) addr[n++] = aa;
