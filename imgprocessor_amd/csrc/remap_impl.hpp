@@ -487,16 +487,17 @@ static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, lo
   return n_frames >= 4 && (work >= 48e6 || d >= 0.05) && g <= 3.0;
 }
 
-template <int INTERP>
+template <int INTERP, typename ST = float>
 static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const HomographyCoord& coord,
                             int n_frames, int base) {
+  constexpr bool kU16 = std::is_same<ST, uint16_t>::value;
   TileWarpArgs t;
   {
-    double key[14] = {(double)INTERP, (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
+    double key[14] = {(double)(INTERP + (kU16 ? 16 : 0)), (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
     for (int k = 0; k < 9; k++) key[5 + k] = coord.m[k];
     if (!ctx->tile_warp_valid || memcmp(key, ctx->tile_warp_key, sizeof key) != 0) {
       int pitch = 0, rows = 0;
-      const bool ok = tile_warp_box<ntaps<INTERP>::value>(coord.m, p.dh, p.dw, p.sh, p.sw, &pitch, &rows);
+      const bool ok = tile_warp_box<ntaps<INTERP>::value, kU16>(coord.m, p.dh, p.dw, p.sh, p.sw, &pitch, &rows);
       ctx->tile_warp_ok = ok ? 1 : 0;
       ctx->tile_warp_rows = rows;
       ctx->tile_warp_pitch = ok ? tile_warp_pitch<ntaps<INTERP>::value>(coord.m, p.dh, p.dw, pitch, rows) : 0;
@@ -507,7 +508,13 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
       ctx->tile_warp_valid = 1;
     }
     if (!ctx->tile_warp_ok) return 1;
-    if (ctx->tune.tile_warp < 2 && !tile_warp_pays(ctx, base, n_frames, (long)p.dh * p.dw)) return 1;
+    if constexpr (kU16) {
+      // the gather kernel's 16U arithmetic is 4 - 10 times slower than this kernel's on 4K frames
+      // (profiles/r04_micro.txt): every batch with some work in it
+      if (ctx->tune.tile_warp < 2 && (double)n_frames * p.dh * p.dw < 2e6) return 1;
+    } else {
+      if (ctx->tune.tile_warp < 2 && !tile_warp_pays(ctx, base, n_frames, (long)p.dh * p.dw)) return 1;
+    }
     t.pitch = ctx->tile_warp_pitch;
     t.rows = ctx->tile_warp_rows;
   }
@@ -524,13 +531,13 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
   t.frames_wg = 8;
   while (t.frames_wg > 1 && (long)t.tiles * ((n_frames + t.frames_wg - 1) / t.frames_wg) < 4096) t.frames_wg >>= 1;
   if (t.frames_wg > n_frames) t.frames_wg = n_frames;
-  const size_t dbytes = ((size_t)(p.dh - 1) * p.dpitch + p.dw) * sizeof(float);
+  const size_t dbytes = ((size_t)(p.dh - 1) * p.dpitch + p.dw) * sizeof(ST);
   if (dbytes >= (1ull << 31)) return 1;
   t.dst_bytes = (unsigned)dbytes;
   t.inv_pitch = 1.0f / (float)t.pitch;
   const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
   const size_t lds = (size_t)tile_warp_lds_bytes<ntaps<INTERP>::value>(t.pitch, t.rows);
-  hipLaunchKernelGGL((tile_warp_kernel<INTERP>), dim3((unsigned)t.tiles * groups), dim3(256), lds,
+  hipLaunchKernelGGL((tile_warp_kernel<INTERP, ST>), dim3((unsigned)t.tiles * groups), dim3(256), lds,
                      ctx->stream, t, coord);
   return 0;
 }
@@ -621,6 +628,19 @@ static int remap_dispatch(ipa_ctx* ctx, const RemapCall& a, const Coord& coord, 
   // homography's are doubles, 16 B per pixel and frame.  ring_remap = 2: every covered case)
   constexpr bool kHom = std::is_same<Coord, HomographyCoord>::value;
   if constexpr (kHom) {
+    // uint16 frames in a cv2 mode (bicubic / Lanczos4 at 1/32-px coordinates: what
+    // PerspectiveCorrection.correct does to the camera's frames)
+    if (ctx->tune.tile_warp && u16_cv && (base == IPA_INTER_LANCZOS4 || base == IPA_INTER_CUBIC_CV) &&
+        (unsigned long)p.tiles * a.n_frames < (1ul << 30)) {
+      int trc = base == IPA_INTER_LANCZOS4
+                    ? tile_warp_launch<kLanczos4, uint16_t>(ctx, p, coord, a.n_frames, base)
+                    : tile_warp_launch<kCubic, uint16_t>(ctx, p, coord, a.n_frames, base);
+      if (trc < 0) return trc;
+      if (trc == 0) {
+        IPA_HIP(ctx, hipGetLastError());
+        return IPA_OK;
+      }
+    }
     if (ctx->tune.tile_warp && a.src_dt == IPA_F32 && a.dst_dt == IPA_F32 &&
         base != IPA_INTER_NEAREST && (unsigned long)p.tiles * a.n_frames < (1ul << 30)) {
       int trc = base == IPA_INTER_LINEAR ? tile_warp_launch<kLinear>(ctx, p, coord, a.n_frames, base)

@@ -49,15 +49,17 @@ struct TileWarpArgs {
 // first and last source index the footprints of coordinates in [lo, hi] can touch, clipped to what
 // a footprint with at least one tap inside [0, n) reaches.  (1/32-px rounding moves a coordinate
 // by up to 1/64: 0.02 covers it and the rounding of the corner arithmetic.)
-template <int NT>
+// INSIDE: clipped to [0, n) instead - the uint16 kernel's fast path takes footprints that lie
+// inside the source only.
+template <int NT, bool INSIDE = false>
 __host__ __device__ inline void tile_axis_box(double lo, double hi, int n, int& first, int& count) {
   const double lim = 1.0e6;
   lo = lo < -lim ? -lim : (lo > lim ? lim : lo);
   hi = hi < -lim ? -lim : (hi > lim ? lim : hi);
   int a = (int)floor(lo - 0.02) - (NT / 2 - 1);
   int b = (int)floor(hi + 0.02) + NT / 2;
-  if (a < -(NT - 1)) a = -(NT - 1);
-  if (b > n + NT - 2) b = n + NT - 2;
+  if (a < (INSIDE ? 0 : -(NT - 1))) a = INSIDE ? 0 : -(NT - 1);
+  if (b > (INSIDE ? n - 1 : n + NT - 2)) b = INSIDE ? n - 1 : n + NT - 2;
   first = a;
   count = b - a + 1 > 0 ? b - a + 1 : 0;
 }
@@ -119,11 +121,16 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, d
   return out;
 }
 
-template <int INTERP>
+template <int INTERP, typename ST = float>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic ? 4 : 3, 8)))
 tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
+  // uint16 frames: OpenCV's 16U arithmetic (float32 table weights, no fma).  The box is clipped to
+  // the source: footprints inside it take the fast path, the ones on the border tile_slow_u16
+  constexpr bool kU16 = std::is_same<ST, uint16_t>::value;
+  static_assert(!kU16 || INTERP == kCubic || INTERP == kLanczos4, "uint16: bicubic and Lanczos4");
+  constexpr int kEsh = kU16 ? 1 : 2;   // log2 of the element size
   // LDS index of box cell (row r, column c).  Lanczos4 keeps the rows in interleaved pairs - pair
   // p = {row 2p, row 2p + 1}, column c of both at float 2c - so that ONE aligned ds_read_b64
   // (256 B/clk, twice ds_read2_b32) fetches two tap rows of a column: a footprint is 5 pairs x 8
@@ -134,10 +141,12 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   };
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   __shared__ double corner[8];
-  __shared__ __attribute__((aligned(16))) float lz[kLz ? 256 : 4];
+  __shared__ __attribute__((aligned(16))) float lz[kU16 ? 384 : (kLz ? 256 : 4)];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if constexpr (kLz) lz[tid] = a.lanczos[tid];
+  if constexpr (kLz || kU16) lz[tid] = a.lanczos[tid];
+  if constexpr (kU16)
+    if (tid < 128u) lz[256 + tid] = a.lanczos[256 + tid];
 
   const unsigned groups = ((unsigned)a.n_frames + a.frames_wg - 1) / (unsigned)a.frames_wg;
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -164,8 +173,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       lox = cx < lox ? cx : lox; hix = cx > hix ? cx : hix;
       loy = cy < loy ? cy : loy; hiy = cy > hiy ? cy : hiy;
     }
-    tile_axis_box<NT>(lox, hix, a.sw, bx0, bw);
-    tile_axis_box<NT>(loy, hiy, a.sh, by0, bh);
+    tile_axis_box<NT, kU16>(lox, hix, a.sw, bx0, bw);
+    tile_axis_box<NT, kU16>(loy, hiy, a.sh, by0, bh);
     if (!fin) bw = bh = 0;
     bw = bw < a.pitch ? bw : a.pitch;
     bh = bh < a.rows ? bh : a.rows;
@@ -197,6 +206,12 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       iy0 = (qy >> 5) - 3;
       tx[j] = __int_as_float(((qx & 31) << 3) | ((qy & 31) << 19));   // float offsets of both table rows
       ty[j] = 0.f;
+    } else if constexpr (kU16) {   // bicubic: rows of the float32 table at 256, 1/32-px coordinates
+      const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+      ix0 = (qx >> 5) - 1;
+      iy0 = (qy >> 5) - 1;
+      tx[j] = __int_as_float((256 + ((qx & 31) << 2)) | ((256 + ((qy & 31) << 2)) << 16));
+      ty[j] = 0.f;
     } else {
       axis_frac<INTERP, float, double>(s, sx, ix0, tx[j]);
       axis_frac<INTERP, float, double>(s, sy, iy0, ty[j]);
@@ -209,7 +224,12 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     __builtin_amdgcn_sched_barrier(0);   // one pixel's double arithmetic at a time (registers)
   }
 
-  float* dst0 = reinterpret_cast<float*>(a.dst);
+  ST* dst0 = reinterpret_cast<ST*>(a.dst);
+  // one source element at byte offset voffset + soffset of a frame's descriptor, as float
+  auto load_px = [&](const __amdgpu_buffer_rsrc_t& rs, int vo, int so) -> float {
+    if constexpr (kU16) return (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, vo, so, 0);
+    else return u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, vo, so, 0));
+  };
   const int cells = bw * bh;
   const float inv_bw = 1.0f / (float)(bw > 0 ? bw : 1);
   const unsigned f0 = grp * (unsigned)a.frames_wg;
@@ -223,14 +243,14 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   // being sampled and written to LDS after it (box_issue / box_commit): the ~1 us of an HBM
   // round trip is then behind the samples and stores of a frame, not in front of them.
   constexpr int kRowsFly = INTERP == kCubic ? 10 : 12;   // (a box of 35 / 37 / 41 rows at no rotation)
-  const int voff = (int)lane << 2;
+  const int voff = (int)lane << kEsh;
   const bool c0 = (int)lane < bw;
   const int e = bw - 64;
   const int esh = e <= 4 ? 2 : (e <= 8 ? 3 : (e <= 16 ? 4 : (e <= 32 ? 5 : 6)));
   const int rstep = 64 >> esh;   // rows per load of the far columns
   const int lr = (int)lane >> esh, lc = 64 + ((int)lane & ((1 << esh) - 1));
   const bool cl = lc < bw;
-  const int soff0 = (__mul24(by0, a.spitch) + bx0) << 2;
+  const int soff0 = (__mul24(by0, a.spitch) + bx0) << kEsh;
   float v0[kRowsFly], v1[4];
   // (addresses stepped from one value the compiler cannot carry across the frame loop: held as
   // loop invariants they are 40 registers)
@@ -238,16 +258,16 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 #pragma unroll
     for (int u = 0; u < kRowsFly; u++) {
       const int r = (int)wave + 4 * u < bh ? (int)wave + 4 * u : bh - 1;
-      v0[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
+      v0[u] = load_px(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << kEsh));
     }
     if (e > 0) {
       int r = (int)wave * rstep + lr;
       asm volatile("" : "+v"(r));
-      int off = (__mul24(r, a.spitch) + lc) << 2;
-      const int ostep = __mul24(4 * rstep, a.spitch) << 2;
+      int off = (__mul24(r, a.spitch) + lc) << kEsh;
+      const int ostep = __mul24(4 * rstep, a.spitch) << kEsh;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        v1[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, cl && r < bh ? off : 0, soff0, 0));
+        v1[u] = load_px(rs, cl && r < bh ? off : 0, soff0);
         r += 4 * rstep;
         off += ostep;
       }
@@ -282,7 +302,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 #pragma unroll
       for (int u = 0; u < kMore; u++) {
         const int r = r0 + 4 * u < bh ? r0 + 4 * u : bh - 1;
-        t[u] = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << 2), 0));
+        t[u] = load_px(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << kEsh));
       }
 #pragma unroll
       for (int u = 0; u < kMore; u++)
@@ -293,10 +313,70 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       for (int r0 = ((int)wave + 16) * rstep; r0 < bh; r0 += 4 * rstep) {
         const int r = r0 + lr;
         const bool live = cl && r < bh;
-        const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(rs, live ? (__mul24(r, a.spitch) + lc) << 2 : 0, soff0, 0));
+        const float t = load_px(rs, live ? (__mul24(r, a.spitch) + lc) << kEsh : 0, soff0);
         if (live) tile_lds[cell(r, lc)] = t;
       }
     }
+  };
+  // uint16: a footprint the box does not hold whole - on the border of the source, outside it, not
+  // finite - in the arithmetic of sampler.hpp::sample_u16_cv, tap by tap (rolled loops, a handful of
+  // registers); the taps that exist come from the box where it has them (it holds what lies inside
+  // the source of every footprint of the tile), from memory otherwise (wrap / reflect borders)
+  auto slow_u16 = [&](double sx, double sy) -> uint16_t {
+#pragma clang fp contract(off)
+    constexpr int ks = NT;
+    const double rv = rint((double)a.cval);
+    const uint16_t cv16 = (uint16_t)(rv > 0 ? (rv < 65535 ? rv : 65535) : 0);
+    if (!(sx > (double)-kCoordLimit && sx < (double)kCoordLimit && sy > (double)-kCoordLimit &&
+          sy < (double)kCoordLimit)) {
+      if (a.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cv16;
+      sx = sx < (double)-kCoordLimit ? (double)-kCoordLimit : (sx > (double)kCoordLimit ? (double)kCoordLimit : sx);
+      sy = sy < (double)-kCoordLimit ? (double)-kCoordLimit : (sy > (double)kCoordLimit ? (double)kCoordLimit : sy);
+    }
+    const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+    const int ix0 = (qx >> 5) - (ks / 2 - 1), iy0 = (qy >> 5) - (ks / 2 - 1);
+    if (a.border == IPA_BORDER_CONSTANT && (ix0 >= a.sw || ix0 + ks <= 0 || iy0 >= a.sh || iy0 + ks <= 0))
+      return cv16;
+    const float* wx = lz + (INTERP == kCubic ? 256 : 0) + (qx & 31) * ks;
+    const float* wy = lz + (INTERP == kCubic ? 256 : 0) + (qy & 31) * ks;
+    const float cv = (float)cv16;
+    const bool whole = ix0 >= 0 && iy0 >= 0 && ix0 + ks <= a.sw && iy0 + ks <= a.sh;
+    auto tap = [&](int yy, int xx) -> float {
+      const int r = yy - by0, c = xx - bx0;
+      if ((unsigned)r < (unsigned)bh && (unsigned)c < (unsigned)bw) return tile_lds[cell(r, c)];
+      return (float)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(s.rsrc, (__mul24(yy, a.spitch) + xx) << 1, 0, 0);
+    };
+    float sum;
+    if (whole) {
+      sum = 0.f;
+#pragma unroll 1
+      for (int r = 0; r < ks; r++) {
+        float rs = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < ks; c++) {
+          const float pr = tap(iy0 + r, ix0 + c) * (wy[r] * wx[c]);
+          if constexpr (INTERP == kCubic) sum = (r == 0 && c == 0) ? pr : sum + pr;
+          else rs = c == 0 ? pr : rs + pr;
+        }
+        if constexpr (INTERP != kCubic) sum = sum + rs;
+      }
+    } else {
+      sum = cv;
+#pragma unroll 1
+      for (int r = 0; r < ks; r++) {
+        const int yy = resolve_idx(iy0 + r, a.sh, a.border);
+        if (yy < 0) continue;
+#pragma unroll 1
+        for (int c = 0; c < ks; c++) {
+          const int xx = resolve_idx(ix0 + c, a.sw, a.border);
+          if (xx >= 0) sum = sum + (tap(yy, xx) - cv) * (wy[r] * wx[c]);
+        }
+      }
+    }
+    float q = rintf(sum);
+    q = q > 0.f ? q : 0.f;
+    q = q < 65535.f ? q : 65535.f;
+    return (uint16_t)q;
   };
   s.rsrc = make_rsrc(a.src + (long)f0 * a.src_frame_bytes, a.src_bytes);
   if (inside && f0 < f1) box_issue(s.rsrc);
@@ -316,8 +396,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const int yy = resolve_idx(by0 + row, a.sh, a.border);
         const int xx = resolve_idx(bx0 + col, a.sw, a.border);
         const bool live = yy >= 0 && xx >= 0;
-        const int off = live ? (__mul24(yy, a.spitch) + xx) << 2 : 0;
-        const float t = u2f(__builtin_amdgcn_raw_buffer_load_b32(s.rsrc, off, 0, 0));
+        const int off = live ? (__mul24(yy, a.spitch) + xx) << kEsh : 0;
+        const float t = load_px(s.rsrc, off, 0);
         tile_lds[cell(row, col)] = live ? t : a.cval;
       }
     }
@@ -332,6 +412,18 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     }
     // 2. the samples, kGroup at a time (their taps in flight together)
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
+    // (uint16: `o` is the float32 sum; cv::saturate_cast<ushort> = round half to even, clamp)
+    auto store_px = [&](float o, int y) {
+      const int so = (int)((long)y * a.dpitch) << kEsh;
+      if constexpr (kU16) {
+        float q = rintf(o);
+        q = q > 0.f ? q : 0.f;   // NaN -> 0
+        q = q < 65535.f ? q : 65535.f;
+        __builtin_amdgcn_raw_buffer_store_b16((short)(unsigned short)q, drs, x << kEsh, so, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << kEsh, so, 0);
+      }
+    };
     constexpr int kGroup = INTERP == kLinear ? 4 : (INTERP == kCubic ? 2 : 1);
     if constexpr (kLz) {
       const int lbase = lds_address(tile_lds);
@@ -347,8 +439,25 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const bool odd = (ad[j] & 1) != 0;
         int ra = lbase + ((ad[j] < 0 ? 0 : ad[j] >> 1) << 2);
         // 5 pairs x 8 columns: rows 2 pb .. 2 pb + 9, of which the sample uses 8 from row `odd` on.
-        // Three pairs, then two (all 40 reads at once are 80 registers: 210 in all, 2 waves per SIMD)
-        float rsum[10];
+        // A few pairs at a time (all 40 reads at once are 80 registers: 210 in all, 2 waves per
+        // SIMD), their row sums added as they come to BOTH column sums - the one from the even and
+        // the one from the odd row on; one select at the end.  (Selecting the eight row sums by
+        // `odd` first is as many instructions, and the compiler turns that form into an array in
+        // scratch memory indexed by `odd`.)
+        float oe = 0.f, oo = 0.f;
+        auto row_sum = [&](auto k_, float R) {   // row k of the 10: row k of the even, k - 1 of the odd footprint
+          constexpr int k = decltype(k_)::value;
+          if constexpr (kU16) {
+#pragma clang fp contract(off)
+            if constexpr (k < 8) oe = oe + R;         // sum = 0; sum = sum + row sum, top to bottom
+            if constexpr (k >= 1 && k <= 8) oo = oo + R;
+          } else {
+            if constexpr (k == 0) oe = uy[0] * R;
+            else if constexpr (k < 8) oe = ipa_fma(uy[k], R, oe);
+            if constexpr (k == 1) oo = uy[0] * R;
+            else if constexpr (k >= 2 && k <= 8) oo = ipa_fma(uy[k - 1], R, oo);
+          }
+        };
         auto pairs = [&](auto first_, auto count_) {
           constexpr int first = decltype(first_)::value, count = decltype(count_)::value;
           v2f t[count][8];
@@ -365,33 +474,49 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
           for (int pp = 0; pp < count; pp++)
 #pragma unroll
             for (int c = 0; c < 8; c++) asm volatile("" : "+v"(t[pp][c]));
+          static_for<0, count>([&](auto pp_) {
+            constexpr int pp = decltype(pp_)::value;
+            constexpr int k0 = 2 * (first + pp);   // rows k0, k0 + 1 of the 10
+            v2f rs;
+            if constexpr (kU16) {
+#pragma clang fp contract(off)
+              // tap * (wy[r] * wx[c]), the products of a row added left to right - two rows at a
+              // time in the halves of packed multiplies and adds (each half rounded on its own).
+              // The row weights against the rows of this pair: of the even or of the odd
+              // footprint (0 on a row that is not the footprint's: that sum is not used)
+              const float we0 = k0 < 8 ? uy[k0 % 8] : 0.f, wo0 = k0 >= 1 ? uy[(k0 + 7) % 8] : 0.f;
+              const float we1 = k0 + 1 < 8 ? uy[(k0 + 1) % 8] : 0.f, wo1 = uy[k0 % 8];
+              const v2f wyp = v2f{odd ? wo0 : we0, odd ? wo1 : we1};
 #pragma unroll
-          for (int pp = 0; pp < count; pp++) {
-            v2f rs = pk_mul_half<0>(wp[0], t[pp][0]);
+              for (int c = 0; c < 8; c++) {
+                const float wxc = c & 1 ? wp[c >> 1].y : wp[c >> 1].x;
+                const v2f pr = t[pp][c] * (wyp * v2f{wxc, wxc});
+                rs = c == 0 ? pr : rs + pr;
+              }
+            } else {
+              rs = pk_mul_half<0>(wp[0], t[pp][0]);
 #pragma unroll
-            for (int c = 1; c < 8; c++) {
-              if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[pp][c], rs);
-              else rs = pk_fma_half<0>(wp[c >> 1], t[pp][c], rs);
+              for (int c = 1; c < 8; c++) {
+                if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[pp][c], rs);
+                else rs = pk_fma_half<0>(wp[c >> 1], t[pp][c], rs);
+              }
             }
-            rsum[2 * (first + pp)] = rs.x;
-            rsum[2 * (first + pp) + 1] = rs.y;
-          }
+            row_sum(std::integral_constant<int, k0>{}, rs.x);
+            row_sum(std::integral_constant<int, k0 + 1>{}, rs.y);
+          });
           __builtin_amdgcn_sched_barrier(0);
         };
-        pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-        pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
-        // both column sums - from the even and from the odd row on - and one select: selecting the
-        // eight row sums by `odd` first is as many instructions, and the compiler turns that form
-        // into an array in scratch memory indexed by `odd`
-        float oe = uy[0] * rsum[0], oo = uy[0] * rsum[1];
-#pragma unroll
-        for (int r = 1; r < 8; r++) {
-          oe = ipa_fma(uy[r], rsum[r], oe);
-          oo = ipa_fma(uy[r], rsum[r + 1], oo);
+        if constexpr (kU16) {
+          pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
+          pairs(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+          pairs(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
+        } else {
+          pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
+          pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
         }
         const float o = odd ? oo : oe;
         if (ad[j] >= 0 && x < a.dw && y < a.dh)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << 2, (int)((long)y * a.dpitch) << 2, 0);
+          store_px(o, y);
         __builtin_amdgcn_sched_barrier(0);   // one sample's taps in flight
       }
     } else {
@@ -401,20 +526,39 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       for (int j = j0; j < j0 + kGroup; j++) {
         const int y = y0 + (int)wave + 4 * j;
         float wx[NT], wy[NT];
-        weights_from_frac<INTERP, float>(s, tx[j], wx);
-        weights_from_frac<INTERP, float>(s, ty[j], wy);
         const float* tp = tile_lds + (ad[j] < 0 ? 0 : ad[j]);
         float o = 0.f;
+        if constexpr (kU16) {
+#pragma clang fp contract(off)
+          // bicubic on uint16 frames: the rows of the float32 table, the 16 products tap *
+          // (wy[r] * wx[c]) added left to right in row-major order
+          const float4 p4 = *reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) & 0xffff));
+          const float4 q4 = *reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) >> 16));
+          wx[0] = p4.x; wx[1] = p4.y; wx[2 % NT] = p4.z; wx[3 % NT] = p4.w;
+          wy[0] = q4.x; wy[1] = q4.y; wy[2 % NT] = q4.z; wy[3 % NT] = q4.w;
 #pragma unroll
-        for (int r = 0; r < NT; r++) {
-          const float* tr = tp + r * a.pitch;
-          float rs = wx[0] * tr[0];
+          for (int r = 0; r < NT; r++) {
+            const float* tr = tp + r * a.pitch;
 #pragma unroll
-          for (int c = 1; c < NT; c++) rs = ipa_fma(wx[c], tr[c], rs);
-          o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+            for (int c = 0; c < NT; c++) {
+              const float pr = tr[c] * (wy[r] * wx[c]);
+              o = (r == 0 && c == 0) ? pr : o + pr;
+            }
+          }
+        } else {
+          weights_from_frac<INTERP, float>(s, tx[j], wx);
+          weights_from_frac<INTERP, float>(s, ty[j], wy);
+#pragma unroll
+          for (int r = 0; r < NT; r++) {
+            const float* tr = tp + r * a.pitch;
+            float rs = wx[0] * tr[0];
+#pragma unroll
+            for (int c = 1; c < NT; c++) rs = ipa_fma(wx[c], tr[c], rs);
+            o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+          }
         }
         if (ad[j] >= 0 && x < a.dw && y < a.dh)
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << 2, (int)((long)y * a.dpitch) << 2, 0);
+          store_px(o, y);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -428,8 +572,11 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         if (x >= a.dw || y >= a.dh) continue;
         double sx, sy;
         coord.get(x, y, sx, sy);
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(tile_slow_sample<INTERP>(s, sx, sy, a.cval)), drs,
-                                              x << 2, (int)((long)y * a.dpitch) << 2, 0);
+        if constexpr (kU16)
+          __builtin_amdgcn_raw_buffer_store_b16((short)slow_u16(sx, sy), drs, x << kEsh,
+                                                (int)((long)y * a.dpitch) << kEsh, 0);
+        else
+          store_px(tile_slow_sample<INTERP>(s, sx, sy, a.cval), y);
       }
     }
   }
@@ -444,7 +591,7 @@ static inline long tile_warp_lds_bytes(int pitch, int rows) {
   return NT == 8 ? (long)((rows + 3) / 2) * 2 * pitch * 4 : (long)pitch * rows * 4;
 }
 
-template <int NT>
+template <int NT, bool INSIDE = false>
 static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int* pitch,
                                  int* rows) {
   // w = m6 u + m7 v + m8 keeps one sign over the picture when it does at the four corners
@@ -474,8 +621,8 @@ static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw
         loy = cy < loy ? cy : loy; hiy = cy > hiy ? cy : hiy;
       }
       int f, bw, bh;
-      tile_axis_box<NT>(lox, hix, sw, f, bw);
-      tile_axis_box<NT>(loy, hiy, sh, f, bh);
+      tile_axis_box<NT, INSIDE>(lox, hix, sw, f, bw);
+      tile_axis_box<NT, INSIDE>(loy, hiy, sh, f, bh);
       mw = bw > mw ? bw : mw;
       mh = bh > mh ? bh : mh;
     }

@@ -166,3 +166,33 @@ def test_rotated_fused_chains_in_two_launches_have_the_same_bits(ia):
         ctx.set_tuning(tile_warp=1)
     same_bits(out[1][0], out[0][0], 'warp + separable 9+9')
     same_bits(out[1][1], out[0][1], 'warp + dense 5x5')
+
+
+@pytest.mark.parametrize('interp', ['cubic_cv_q5', 'lanczos4'])
+def test_uint16_frames_in_opencvs_16u_arithmetic(ia, oracle, interp):
+    """the camera's uint16 frames (PerspectiveCorrection.correct on CV_16U images): the tile kernel
+    with the box clipped to the source, border footprints tap by tap - the gather kernel's and
+    the oracle's values exactly"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(11)
+    oi = {'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5, 'lanczos4': oracle.LANCZOS4}[interp]
+    for (h, w, n) in ((150, 260, 2), (33, 200, 5), (301, 517, 3)):
+        src = rng.integers(0, 65536, (n, h, w)).astype(np.uint16)
+        d = ctx.to_device(src)
+        for deg, zoom in ((0.0, 1.0), (17.0, 1.0), (-61.0, 0.8), (90.0, 1.2), (133.0, 1.0)):
+            M = rot_persp(h, w, deg, zoom=zoom)
+            for border, ob in (('constant', oracle.CONSTANT), ('replicate', oracle.REPLICATE),
+                               ('reflect', oracle.REFLECT), ('wrap', oracle.WRAP)):
+                out = []
+                try:
+                    for tw in (0, 2):
+                        ctx.set_tuning(tile_warp=tw)
+                        out.append(ops.warp_perspective(d, M, (h + 5, w - 3), interp, border, border_value=1000).get())
+                finally:
+                    ctx.set_tuning(tile_warp=1)
+                assert np.array_equal(out[0], out[1]), '%s %s %g deg: tile kernel differs from the gather kernel' % (
+                    interp, border, deg)
+                if (h, w) == (150, 260) and border in ('constant', 'replicate'):
+                    want = oracle.warp_perspective(src[0], M, (h + 5, w - 3), oi, ob, 1000)
+                    assert np.array_equal(out[1][0], want), '%s %s %g deg vs oracle' % (interp, border, deg)

@@ -46,6 +46,10 @@ def main():
         from angle_sweep import rot_persp
         deg, interp = case[3:].split('_', 1)
         H = rot_persp(h, w, float(deg))
+        if interp.endswith('@u16'):   # uint16 frames
+            interp = interp[:-4]
+            src = ctx.to_device((src.get() * 65535).astype(np.uint16))
+            dst = ctx.empty((batch, h, w), np.uint16)
     for _ in range(steps):
         if case == 'cubic_maps':
             ops.remap(src, dmx, dmy, interpolation='cubic', out=dst)
