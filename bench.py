@@ -230,8 +230,8 @@ def other_configs(ctx, ia, ops, budget_launches=60):
         two = interp != 'linear'
         entry('C3 4K f32, PerspectiveCorrection warp (%s) + separable 9+9, %d frames/launch'
               % (interp, B), B, h, w, ms, 8 * B * h * w, 2 if two else 1,
-              'two launches through the workspace (16 B/px of traffic for an 8 B/px workload)'
-              if two else None)
+              'two launches through the workspace: tile warp, then the filter (16 B/px of traffic for '
+              'an 8 B/px workload)' if two else None)
 
     # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
     # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
@@ -239,9 +239,41 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     ms = timed_settled(ctx, lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
                budget_launches, 5)
     entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
-          8 * B * h * w, 3, 'planning pass (first call) + ring kernel + gather kernel on the rim; '
-          'bound by the LDS tap reads of the ring kernel: 64 taps x 4 B per sample through ds_read_b64',
-          bound='lds', work=64 * 4 * B * h * w)
+          8 * B * h * w, 1, 'tile kernel (csrc/tile_warp.hpp): the source box of a 64 x 32 output tile '
+          'in LDS, rows in interleaved pairs; 40 8-byte LDS reads per sample (5 row pairs x 8 columns)',
+          bound='lds', work=40 * 8 * B * h * w)
+
+    # the same three chains with the picture rotated by 15 degrees: the row-walking kernels pay per
+    # cache line a wave's gather touches (profiles/r04_micro.txt: up to 3x at 45 degrees); the tile
+    # kernel's time hardly depends on the angle
+    def rot15(h, w):
+        a = np.deg2rad(15.0)
+        cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+        R = np.array([[np.cos(a), -np.sin(a), cx - np.cos(a) * cx + np.sin(a) * cy],
+                      [np.sin(a), np.cos(a), cy - np.sin(a) * cx - np.cos(a) * cy],
+                      [0, 0, 1.0]])
+        return np.array([[1, 0, 0], [0, 1, 0], [2e-6, 1e-6, 1.0]]) @ R
+    Hr = rot15(h, w)
+    ms = timed_settled(ctx, lambda: ops.warp_perspective_sepconv2d(src, Hr, (h, w), g9, g9, 'linear', out=dst),
+                       budget_launches, 5)
+    entry('C3 rotated by 15 degrees: 4K f32, warp (linear) + separable 9+9, %d frames/launch' % B, B, h, w,
+          ms, 8 * B * h * w, 2, 'tile warp into the workspace, then the filter (16 B/px of traffic for '
+          'an 8 B/px workload); the one fused kernel takes 0.88 ms at this angle')
+    ms = timed_settled(ctx, lambda: ops.warp_perspective(src, Hr, (h, w), 'lanczos4', out=dst), budget_launches, 5)
+    entry('PerspectiveCorrection default rotated by 15 degrees: 4K f32, Lanczos4 warp, %d frames/launch' % B,
+          B, h, w, ms, 8 * B * h * w, 1, 'tile kernel; ring + gather kernels: 1.7 ms at this angle',
+          bound='lds', work=40 * 8 * B * h * w)
+    u16 = ctx.to_device(np.round(synth_frames(B, h, w, 320) * 65535).astype(np.uint16))
+    d16 = ctx.empty((B, h, w), np.uint16)
+    ms = timed_settled(ctx, lambda: ops.warp_perspective(u16, Hm, (h, w), 'lanczos4', out=d16),
+                       budget_launches // 2, 3)
+    entry('PerspectiveCorrection default 4K uint16, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
+          4 * B * h * w, 1, "OpenCV's 16U arithmetic (float32 table weights, every product and sum rounded, "
+          'no fma), bit-exact against the oracle; tile kernel with the box clipped to the source: per '
+          'sample 40 8-byte LDS reads and ~200 vector instructions (80 packed multiplies, 40 packed adds '
+          'for the 64 taps and their weights; counted by rocprofv3: SQ_INSTS_VALU per wave and sample)',
+          bound='valu_issue', work=200 * B * h * w)
+    del u16, d16
     u8 = ctx.to_device(np.round(synth_frames(B, h, w, 310) * 255).astype(np.uint8))
     d8 = ctx.empty((B, h, w), np.uint8)
     ms = timed_settled(ctx, lambda: ops.warp_perspective(u8, Hm, (h, w), 'lanczos4', out=d8),

@@ -12,6 +12,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/r04_fetch -o r04 --ou
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r04_write -o r04 --output-format csv -- python3 $R/bench.py --no-cpu --no-configs --steps 5 --warmup 2 > $R/gpurun_out/r04_write.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/r04_cfetch -o r04 --output-format csv -- python3 $R/bench.py --no-cpu --steps 5 --warmup 2 > $R/gpurun_out/r04_cfetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/r04_cwrite -o r04 --output-format csv -- python3 $R/bench.py --no-cpu --steps 5 --warmup 2 > $R/gpurun_out/r04_cwrite.log 2>&1
+python3 $R/tools/angle_sweep.py 0 0.5 1 2 4 7 15 30 45 90 > $R/gpurun_out/r04_angles.txt 2>&1
 head -c 600 $R/gpurun_out/r04_bench.json
 # the N > 1 launcher path on hardware: two ranks time-sharing this box's one GPU (no scaling claim)
 cd $R && python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 $R/bench.py --gpus 2 --steps 50 --warmup 5 > $R/gpurun_out/r04_bench_2ranks_one_gpu.json 2> $R/gpurun_out/r04_bench_2ranks.err
