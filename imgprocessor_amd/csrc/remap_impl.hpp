@@ -469,10 +469,12 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
 // float32 perspective warps on the tile kernel (tile_warp.hpp); 1: not covered / does not pay.
 // Where it pays (tile_warp = 1), measured against the ring + gather kernels on 480p ... 8K frames,
 // batches of 1 ... 16, rotations, perspective quadrilaterals and zooms (profiles/r04_micro.txt):
-//   bilinear  batches of 8+ frames and 64+ Mpx (4+ frames from 100 Mpx) whose boxes stay small
-//             (fetch <= 1.35) or whose rows drift (0.1+ rows per pixel - the gathers then pay per
-//             cache line) while the boxes stay moderate (fetch <= 2.6);
-//   bicubic   batches of 4+ frames with 48+ Mpx or a drift of 0.05+, boxes up to fetch 3;
+//   bilinear  batches of 8+ frames and 64+ Mpx (4+ frames from 100 Mpx) of a picture that is
+//             enlarged (fetch <= 1.05: small boxes) or whose rows drift (0.1+ rows per pixel - the
+//             gathers then pay per cache line) while the boxes stay moderate (fetch <= 2.6); at
+//             scale 1 without rotation the two are level;
+//   bicubic   batches of 4+ frames (up to 2x; a few mild cases on small frames lose 15 %), smaller
+//             ones from a drift of 0.3;
 //   Lanczos4  everything but small batches (under 100 Mpx) of a picture that is enlarged (step
 //             < 0.95) and hardly rotated (drift < 0.02): there the ring kernel, whose strips
 //             then advance through few source rows, is 5-10 % ahead; elsewhere the tile kernel
@@ -482,9 +484,9 @@ static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, lo
   const double work = (double)n_frames * (double)px;
   if (base == IPA_INTER_LINEAR)
     return ((n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6)) &&
-           (g <= 1.35 || (d >= 0.1 && g <= 2.6));
+           (g <= 1.05 || (d >= 0.1 && g <= 2.6));
   if (base == IPA_INTER_LANCZOS4) return d >= 0.02 || st >= 0.95 || work >= 100e6;
-  return n_frames >= 4 && (work >= 48e6 || d >= 0.05) && g <= 3.0;
+  return n_frames >= 4 || d >= 0.3;
 }
 
 template <int INTERP, typename ST = float>

@@ -410,6 +410,9 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 #pragma unroll
       for (int j = 0; j < kWarpTilePx; j++) asm volatile("" : "+v"(tx[j]), "+v"(ty[j]));
     }
+    // (... and what derives from a footprint's address - LDS byte addresses, the row parity)
+#pragma unroll
+    for (int j = 0; j < kWarpTilePx; j++) asm volatile("" : "+v"(ad[j]));
     // 2. the samples, kGroup at a time (their taps in flight together)
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
     // (uint16: `o` is the float32 sum; cv::saturate_cast<ushort> = round half to even, clamp)
