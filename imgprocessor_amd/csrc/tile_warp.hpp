@@ -122,7 +122,7 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, d
 }
 
 template <int INTERP, typename ST = float>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic ? 4 : 3, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic || (INTERP == kLanczos4 && sizeof(ST) == 4) ? 4 : 3, 8)))
 tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
@@ -442,8 +442,8 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         const bool odd = (ad[j] & 1) != 0;
         int ra = lbase + ((ad[j] < 0 ? 0 : ad[j] >> 1) << 2);
         // 5 pairs x 8 columns: rows 2 pb .. 2 pb + 9, of which the sample uses 8 from row `odd` on.
-        // A few pairs at a time (all 40 reads at once are 80 registers: 210 in all, 2 waves per
-        // SIMD), their row sums added as they come to BOTH column sums - the one from the even and
+        // A pair at a time (all 40 reads at once are 80 registers: 210 in all, 2 waves per SIMD),
+        // their row sums added as they come to BOTH column sums - the one from the even and
         // the one from the odd row on; one select at the end.  (Selecting the eight row sums by
         // `odd` first is as many instructions, and the compiler turns that form into an array in
         // scratch memory indexed by `odd`.)
@@ -461,62 +461,67 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
             else if constexpr (k >= 2 && k <= 8) oo = ipa_fma(uy[k - 1], R, oo);
           }
         };
-        auto pairs = [&](auto first_, auto count_) {
-          constexpr int first = decltype(first_)::value, count = decltype(count_)::value;
-          v2f t[count][8];
-          static_for<0, count>([&](auto pp_) {
-            constexpr int pp = decltype(pp_)::value;
-            static_for<0, 8>([&](auto cc) {
-              constexpr int c = decltype(cc)::value;
-              t[pp][c] = lds_read_b64<c * 8>(ra);
-            });
-            ra += pstep;
+        // The pairs go through two register sets: pair p + 1 is in flight while pair p is summed
+        // (counted s_waitcnt lgkmcnt(8): the 8 reads of the older pair have returned - LDS reads
+        // return in order, anything else in flight only makes the wait stricter).
+        auto issue = [&](v2f (&t)[8]) {
+          static_for<0, 8>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            t[c] = lds_read_b64<c * 8>(ra);
           });
-          lds_wait_all();
-#pragma unroll
-          for (int pp = 0; pp < count; pp++)
-#pragma unroll
-            for (int c = 0; c < 8; c++) asm volatile("" : "+v"(t[pp][c]));
-          static_for<0, count>([&](auto pp_) {
-            constexpr int pp = decltype(pp_)::value;
-            constexpr int k0 = 2 * (first + pp);   // rows k0, k0 + 1 of the 10
-            v2f rs;
-            if constexpr (kU16) {
-#pragma clang fp contract(off)
-              // tap * (wy[r] * wx[c]), the products of a row added left to right - two rows at a
-              // time in the halves of packed multiplies and adds (each half rounded on its own).
-              // The row weights against the rows of this pair: of the even or of the odd
-              // footprint (0 on a row that is not the footprint's: that sum is not used)
-              const float we0 = k0 < 8 ? uy[k0 % 8] : 0.f, wo0 = k0 >= 1 ? uy[(k0 + 7) % 8] : 0.f;
-              const float we1 = k0 + 1 < 8 ? uy[(k0 + 1) % 8] : 0.f, wo1 = uy[k0 % 8];
-              const v2f wyp = v2f{odd ? wo0 : we0, odd ? wo1 : we1};
-#pragma unroll
-              for (int c = 0; c < 8; c++) {
-                const float wxc = c & 1 ? wp[c >> 1].y : wp[c >> 1].x;
-                const v2f pr = t[pp][c] * (wyp * v2f{wxc, wxc});
-                rs = c == 0 ? pr : rs + pr;
-              }
-            } else {
-              rs = pk_mul_half<0>(wp[0], t[pp][0]);
-#pragma unroll
-              for (int c = 1; c < 8; c++) {
-                if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[pp][c], rs);
-                else rs = pk_fma_half<0>(wp[c >> 1], t[pp][c], rs);
-              }
-            }
-            row_sum(std::integral_constant<int, k0>{}, rs.x);
-            row_sum(std::integral_constant<int, k0 + 1>{}, rs.y);
-          });
-          __builtin_amdgcn_sched_barrier(0);
+          ra += pstep;
         };
-        if constexpr (kU16) {
-          pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{});
-          pairs(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-          pairs(std::integral_constant<int, 4>{}, std::integral_constant<int, 1>{});
-        } else {
-          pairs(std::integral_constant<int, 0>{}, std::integral_constant<int, 3>{});
-          pairs(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
-        }
+        auto sum_pair = [&](auto pp_, v2f (&t)[8]) {
+          constexpr int k0 = 2 * decltype(pp_)::value;   // rows k0, k0 + 1 of the 10
+#pragma unroll
+          for (int c = 0; c < 8; c++) asm volatile("" : "+v"(t[c]));
+          v2f rs;
+          if constexpr (kU16) {
+#pragma clang fp contract(off)
+            // tap * (wy[r] * wx[c]), the products of a row added left to right - two rows at a
+            // time in the halves of packed multiplies and adds (each half rounded on its own).
+            // The row weights against the rows of this pair: of the even or of the odd
+            // footprint (0 on a row that is not the footprint's: that sum is not used)
+            const float we0 = k0 < 8 ? uy[k0 % 8] : 0.f, wo0 = k0 >= 1 ? uy[(k0 + 7) % 8] : 0.f;
+            const float we1 = k0 + 1 < 8 ? uy[(k0 + 1) % 8] : 0.f, wo1 = uy[k0 % 8];
+            const v2f wyp = v2f{odd ? wo0 : we0, odd ? wo1 : we1};
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+              const float wxc = c & 1 ? wp[c >> 1].y : wp[c >> 1].x;
+              const v2f pr = t[c] * (wyp * v2f{wxc, wxc});
+              rs = c == 0 ? pr : rs + pr;
+            }
+          } else {
+            rs = pk_mul_half<0>(wp[0], t[0]);
+#pragma unroll
+            for (int c = 1; c < 8; c++) {
+              if (c & 1) rs = pk_fma_half<1>(wp[c >> 1], t[c], rs);
+              else rs = pk_fma_half<0>(wp[c >> 1], t[c], rs);
+            }
+          }
+          row_sum(std::integral_constant<int, k0>{}, rs.x);
+          row_sum(std::integral_constant<int, k0 + 1>{}, rs.y);
+        };
+        v2f ta[8], tb[8];
+        issue(ta);
+        issue(tb);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        sum_pair(std::integral_constant<int, 0>{}, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(ta);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        sum_pair(std::integral_constant<int, 1>{}, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(tb);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        sum_pair(std::integral_constant<int, 2>{}, ta);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(ta);
+        asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        sum_pair(std::integral_constant<int, 3>{}, tb);
+        __builtin_amdgcn_sched_barrier(0);
+        lds_wait_all();
+        sum_pair(std::integral_constant<int, 4>{}, ta);
         const float o = odd ? oo : oe;
         if (ad[j] >= 0 && x < a.dw && y < a.dh)
           store_px(o, y);
