@@ -426,12 +426,13 @@ def main():
     # WHERE a 2 GB batch buffer lands in physical memory moves this streaming kernel by up to 10 %
     # on this part (a property of the allocation: profiles/r04_micro.txt).  Since round 4 the
     # PRODUCT deals with it: the context's block pool chooses every block of 256 MiB and more
-    # among IMGPROC_HIP_PLACE candidate allocations (default 8) by a strip-shaped probe, once per
+    # among up to IMGPROC_HIP_PLACE candidate allocations (default 24; fewer once one of the fast
+    # class has shown up) by a strip-shaped probe, once per
     # block (device.py::_alloc_placed) - d_src / d_dst above were allocated that way, exactly as a
     # caller's arrays are, and `config.buffer_placement` is the pool's own log.  --placements N
     # overrides the candidate count for this run (1 = every allocation as it comes).
-    placement = {'by': 'Context block pool (product default: IMGPROC_HIP_PLACE=%d candidates per block '
-                       '>= 256 MiB, strip-shaped 3x3 probe)' % ctx._place_n,
+    placement = {'by': 'Context block pool (product default: up to IMGPROC_HIP_PLACE=%d candidates per block '
+                       '>= 256 MiB, strip-shaped 3x3 probe, drawing stops at the first of the fast class)' % ctx._place_n,
                  'candidates': ctx._place_n, 'blocks': list(ctx.placement_log)}
 
     px = B * h * w

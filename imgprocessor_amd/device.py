@@ -47,12 +47,16 @@ class Context(object):
         # of the allocation, not of the address inside it (profiles/r04_micro.txt: one offset is
         # as good as another within an allocation; a linear copy does not see it at all; a plain
         # 3x3 filter from one half of the block into the other does, and ranks the blocks like the
-        # fused kernel).  So a block of >= 256 MiB that the pool cannot serve is chosen among
-        # IMGPROC_HIP_PLACE candidate allocations (default 8, at most 24 GiB of candidates at a
-        # time; 1 = take the first) by that probe, ~1 ms per GiB and candidate, once per block -
-        # the pool hands it out again afterwards.
-        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '8')))
-        self._place_bytes = 24 << 30
+        # fused kernel).  The fresh 2 GiB allocations of a process fall into three classes by that
+        # probe (tools/placement_classes.py, 40 held at once: 8 at 0.377 ms, 8 at 0.391, 24 at 0.423;
+        # the headline launch on pairs of them 0.95 - 0.98 / 1.04 / 1.09 ms).  So a block of
+        # >= 256 MiB that the pool cannot serve is chosen among up to IMGPROC_HIP_PLACE candidate
+        # allocations (default 24, at most 64 GiB of candidates at a time; 1 = take the first) by
+        # that probe - ~3 ms per candidate of 2 GiB, once per block, the pool hands it out again
+        # afterwards - and the drawing stops early once a candidate of the fast class has shown up
+        # (>= 6 drawn and the best 9.5 % under their median).
+        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '24')))
+        self._place_bytes = 64 << 30
         self._place_min = 256 << 20
         self._place_max = 16 << 30
         self._placing = False
@@ -111,9 +115,9 @@ class Context(object):
         return p
 
     def _alloc_placed(self, nbytes):
-        """the best of up to `_place_n` allocations of `nbytes` by `_probe_block`; the others go
-        back to the driver (all candidates are held until the choice is made: a freed one would
-        be handed out again)"""
+        """the best of up to `_place_n` allocations of `nbytes` by `_probe_block` (fewer when one of
+        the fast class shows up early); the others go back to the driver (all candidates are
+        held until the choice is made: a freed one would be handed out again)"""
         self._placing = True
         try:
             cands, times = [], []
@@ -126,6 +130,8 @@ class Context(object):
                     break   # out of device memory: choose among what there is
                 cands.append(p)
                 times.append(self._probe_block(p, nbytes))
+                if len(times) >= 6 and min(times) <= 0.905 * float(np.median(times)):
+                    break   # one of the fast class is among them
             best = int(np.argmin(times))
             self.synchronize()
             for i, p in enumerate(cands):
