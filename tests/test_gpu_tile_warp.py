@@ -196,3 +196,41 @@ def test_uint16_frames_in_opencvs_16u_arithmetic(ia, oracle, interp):
                 if (h, w) == (150, 260) and border in ('constant', 'replicate'):
                     want = oracle.warp_perspective(src[0], M, (h + 5, w - 3), oi, ob, 1000)
                     assert np.array_equal(out[1][0], want), '%s %s %g deg vs oracle' % (interp, border, deg)
+
+
+@pytest.mark.parametrize('odd', [0, 1])
+@pytest.mark.parametrize('case', [('linear', np.float32), ('cubic', np.float32), ('lanczos4', np.float32),
+                                  ('cubic_cv_q5', np.uint16), ('lanczos4', np.uint16)])
+def test_tile_kernel_with_pitches_and_frame_strides(ia, case, odd):
+    """the C ABI on regions of larger device buffers (row pitch > width, frame stride > frame):
+    the bits of the same warp on contiguous arrays, nothing written outside the region"""
+    import ctypes as C
+    from imgprocessor_amd import ops
+    from imgprocessor_amd import _lib as L
+    from imgprocessor_amd.device import dtype_id
+    interp, dt = case
+    ctx = ia.default_context(0)
+    n, h, w, dh, dw = 5, 150, 333, 170, 301
+    rng = np.random.default_rng(5)
+    src = (rng.integers(0, 65536, (n, h, w)).astype(np.uint16) if dt == np.uint16
+           else rng.random((n, h, w), dtype=np.float32))
+    M = rot_persp(h, w, 21.0, zoom=0.9)
+    fill = dt(7)
+    old = ctx.set_tuning(tile_warp=2)
+    try:
+        want = ops.warp_perspective(ctx.to_device(src), M, (dh, dw), interp, 'reflect').get()
+        sp, dp = w + 24 + odd, dw + 8 + 3 * odd
+        sbig = np.full((n, h + 5, sp), fill, dt)
+        sbig[:, :h, :w] = src
+        d_s = ctx.to_device(sbig)
+        d_d = ctx.to_device(np.full((n, dh + 3, dp), dt(9), dt))
+        Mv = L.dbl(np.ravel(M), 9)
+        ctx._check(ctx._lib.ipa_warp_perspective_dev(
+            ctx.handle, d_s.ptr, dtype_id(dt), h, w, sp, Mv, d_d.ptr, dtype_id(dt), dh, dw, dp, n,
+            (h + 5) * sp, (dh + 3) * dp, ops.interp_id(interp), ops.border_id('reflect'), 0.0), 'warp')
+        got = d_d.get()
+    finally:
+        ctx.set_tuning(**old)
+    assert np.array_equal(np.ascontiguousarray(got[:, :dh, :dw]).view(np.uint8), want.view(np.uint8)), \
+        'pitched tile warp %s %s' % (interp, np.dtype(dt).name)
+    assert (got[:, dh:, :] == dt(9)).all() and (got[:, :, dw:] == dt(9)).all(), 'wrote outside the region'
