@@ -536,7 +536,6 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
   const size_t dbytes = ((size_t)(p.dh - 1) * p.dpitch + p.dw) * sizeof(ST);
   if (dbytes >= (1ull << 31)) return 1;
   t.dst_bytes = (unsigned)dbytes;
-  t.inv_pitch = 1.0f / (float)t.pitch;
   const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
   const size_t lds = (size_t)tile_warp_lds_bytes<ntaps<INTERP>::value>(t.pitch, t.rows);
   hipLaunchKernelGGL((tile_warp_kernel<INTERP, ST>), dim3((unsigned)t.tiles * groups), dim3(256), lds,

@@ -11,13 +11,17 @@
 //     source (a projective map takes the tile to a convex quadrilateral: the extremes are at the
 //     corners);
 //   * the box is read row by row with coalesced dword loads - every cell through the border mode,
-//     so the samples below need no border logic - into LDS;
+//     so the samples below need no border logic - into LDS; the next frame's box is requested
+//     while the current frame is being sampled;
 //   * every pixel's NT x NT taps come from LDS: the weights of axis_split(), the products and sums
 //     of sample() in its order - results identical to remap_kernel;
 //   * footprints the box does not hold (outside the source altogether, not finite, or a box
-//     clipped to the LDS the launch reserved) go through sample() itself.
+//     clipped to the LDS the launch reserved) go through a rolled-loop restatement of sample().
 // The coordinates (a double division per pixel) are evaluated once per tile and kept in registers
 // for the frames_wg frames the workgroup walks through.
+// uint16 frames (ST = uint16_t; bicubic and Lanczos4 at 1/32-px coordinates): OpenCV's 16U
+// arithmetic of sampler.hpp::sample_u16_cv - float32 table weights, tap * (wy * wx) products added
+// without fma -, the box clipped to the source, footprints on its border tap by tap (slow_u16).
 #pragma once
 
 #include "sampler.hpp"
@@ -42,8 +46,7 @@ struct TileWarpArgs {
   const float* lanczos;
   float cval;
   int tiles_x, tiles;
-  int pitch, rows;   // the LDS box: floats per row (odd: rotated reads spread over the banks), rows
-  float inv_pitch;
+  int pitch, rows;   // the LDS box: floats per row (chosen against bank conflicts: tile_warp_pitch), rows
 };
 
 // first and last source index the footprints of coordinates in [lo, hi] can touch, clipped to what
@@ -127,7 +130,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
   // uint16 frames: OpenCV's 16U arithmetic (float32 table weights, no fma).  The box is clipped to
-  // the source: footprints inside it take the fast path, the ones on the border tile_slow_u16
+  // the source: footprints inside it take the fast path, the ones on the border slow_u16 below
   constexpr bool kU16 = std::is_same<ST, uint16_t>::value;
   static_assert(!kU16 || INTERP == kCubic || INTERP == kLanczos4, "uint16: bicubic and Lanczos4");
   constexpr int kEsh = kU16 ? 1 : 2;   // log2 of the element size
