@@ -345,6 +345,59 @@ template <typename Src, int K, bool STREAM> struct geom_halo {
                                 pipe_capable<Src, K>::value && (IPA_HALO_SAMPLE != 0 || !Src::kHasQ5);
 };
 
+// ---- footprints on the border of the source, constant border mode (the reference's: cv2.remap
+// with BORDER_CONSTANT, camera/LensDistortion.py:323-326 - and with its getOptimalNewCameraMatrix
+// (alpha = 1) call every undistorted picture has such a rim).  sample() redoes them tap by tap
+// with dependent loads: a strip that has one in every row ran 25 - 50 % over the others (64 x 4K,
+// alpha = 1: 1.42 ms against 0.94).  Their taps are in the registers already - the gathers are
+// range-checked and never fault; a tap outside the source is just the wrong pixel - so: whoever
+// forms the records of a row marks, for every footprint that is not interior, which of its 4
+// taps lie inside the source (bits 8 + 4 k .. 11 + 4 k of the interior word; rows that have none
+// pay nothing), and the blend replaces the others by the border value: sample()'s arithmetic in
+// sample()'s order, no tap inside = the border value itself.
+// PACKED (uint16 frames: ONE dword at the byte offset of the left tap holds both taps of a row):
+// where that offset is negative - the left tap in column -1 of row 0 - the range check drops the
+// whole dword, the right tap with it: bit 31 sends such a lane through sample().
+constexpr unsigned kBorderSlow = 1u << 31;
+template <int NS, int QM, bool PACKED, typename C>
+__device__ __forceinline__ unsigned border_tap_bits(const SrcView& s, const C (&sx)[NS],
+                                                    const C (&sy)[NS], unsigned interior) {
+  unsigned vb = 0;
+#pragma unroll
+  for (int k = 0; k < NS; k++) {
+    if (!((interior >> k) & 1u)) {
+      const bool ok = ipa_abs(sx[k]) < (C)kCoordLimit && ipa_abs(sy[k]) < (C)kCoordLimit;
+      int ix0, iy0;
+      float t0, t1;
+      axis_frac<kLinear, float, C, QM>(s, ok ? sx[k] : (C)0, ix0, t0);
+      axis_frac<kLinear, float, C, QM>(s, ok ? sy[k] : (C)0, iy0, t1);
+      const bool x0 = (unsigned)ix0 < (unsigned)s.w, x1 = (unsigned)(ix0 + 1) < (unsigned)s.w;
+      const bool y0 = (unsigned)iy0 < (unsigned)s.h, y1 = (unsigned)(iy0 + 1) < (unsigned)s.h;
+      const unsigned b = ((y0 && x0) ? 1u : 0u) | ((y0 && x1) ? 2u : 0u) | ((y1 && x0) ? 4u : 0u) |
+                         ((y1 && x1) ? 8u : 0u);
+      vb |= (ok ? b : 0u) << (8 + 4 * k);
+      if constexpr (PACKED)
+        if (ok && ix0 == -1 && (iy0 == 0 || iy0 == -1) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
+    }
+  }
+  return vb;
+}
+__device__ __forceinline__ float border_blend(float v00, float v01, float v10, float v11, float tx,
+                                              float ty, unsigned vb, float cval) {
+  v00 = (vb & 1u) ? v00 : cval;
+  v01 = (vb & 2u) ? v01 : cval;
+  v10 = (vb & 4u) ? v10 : cval;
+  v11 = (vb & 8u) ? v11 : cval;
+  const float wx0 = 1.f - tx, wx1 = tx, wy0 = 1.f - ty, wy1 = ty;
+  float r0 = wx0 * v00;
+  r0 = ipa_fma(wx1, v01, r0);
+  float o = wy0 * r0;
+  float r1 = wx0 * v10;
+  r1 = ipa_fma(wx1, v11, r1);
+  o = ipa_fma(wy1, r1, o);
+  return vb ? o : cval;
+}
+
 template <int K, int QM, bool HALO, typename Coord>
 __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
                                                     const SampleRowSrc<float, kLinear, Coord>& src,
@@ -434,6 +487,8 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
     int e[NS];
     batch_footprint_linear<NS, QM>(s, sx, sy, tx, ty, e, interior);
     if constexpr (HALO) interior |= allin;
+    if (s.border == IPA_BORDER_CONSTANT && __builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u))
+      interior |= border_tap_bits<NS, QM, false, float>(s, sx, sy, interior);
 #pragma unroll
     for (int k = 0; k < NS; k++) off[k] = (unsigned)e[k] << 2;
   };
@@ -500,16 +555,28 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
       if (lane < 2u * G::H) xp[kRowPad - G::H + hcol] = cur[4];
     }
     if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
-      // footprints touching the source border (rare): redo them tap by tap, straight into the
-      // LDS row - ONE copy of the border-aware sampler per step (a loop, not unrolled)
+      if (s.border == IPA_BORDER_CONSTANT) {
+        // footprints touching the source border, constant border mode: the taps are here, the
+        // ones outside the source replaced by the border value (border_tap_bits / border_blend)
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+          if (!((interior >> k) & 1u))
+            xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
+                border_blend(top[2 * k], top[2 * k + 1], bot[2 * k], bot[2 * k + 1], tx[k], ty[k],
+                             (interior >> (8 + 4 * k)) & 15u, src.cval);
+        }
+      } else {
+        // the other border modes (rare): redo them tap by tap, straight into the LDS row - ONE
+        // copy of the border-aware sampler per step (a loop, not unrolled)
 #pragma unroll 1
-      for (int k = 0; k < NS; k++) {
-        if (!((interior >> k) & 1u)) {
-          const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
-          float sx, sy;
-          src.coord.get(col, yb + t, sx, sy);
-          xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
-              sample<float, kLinear, float>(s, sx, sy, src.cval);
+        for (int k = 0; k < NS; k++) {
+          if (!((interior >> k) & 1u)) {
+            const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
+            float sx, sy;
+            src.coord.get(col, yb + t, sx, sy);
+            xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
+                sample<float, kLinear, float>(s, sx, sy, src.cval);
+          }
         }
       }
     }
@@ -717,6 +784,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     unsigned interior;
     batch_footprint_linear<NS, QM>(s, sx, sy, tx, ty, e, interior);
     if constexpr (HALO) interior |= lane < 2u * G::H ? 0u : 0x10u;   // lanes without a halo pixel
+    if (s.border == IPA_BORDER_CONSTANT && __builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u))
+      interior |= border_tap_bits<NS, QM, NR == 1, C>(s, sx, sy, interior);
     float* slot = rlane + (unsigned)(r % R) * RR;
     *reinterpret_cast<v4i*>(slot) = v4i{e[0] << SH, e[1] << SH, e[2] << SH, e[3] << SH};
     *reinterpret_cast<v4f*>(slot + 256) = v4f{tx[0], tx[1], tx[2], tx[3]};
@@ -841,12 +910,33 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (HALO) {
       if (lane < 2u * G::H) xp[kRowPad - G::H + hcol] = cur[4];
     }
-    if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
-      // footprints touching the source border (rare): redo them tap by tap, straight into the
-      // LDS row - ONE copy of the border-aware sampler per step (a loop, not unrolled)
+    if (s.border == IPA_BORDER_CONSTANT) {
+      if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
+        // footprints touching the source border, constant border mode: the taps are here, the
+        // ones outside the source replaced by the border value (border_tap_bits / border_blend)
+#pragma unroll
+        for (int k = 0; k < NS; k++) {
+          if (!((interior >> k) & 1u) && !(interior & kBorderSlow)) {
+            float v00, v01, v10, v11;
+            taps_of(top, k, v00, v01);
+            taps_of(bot, k, v10, v11);
+            const float o = border_blend(v00, v01, v10, v11, tx[k], ty[k], (interior >> (8 + 4 * k)) & 15u,
+                                         src.cval);
+            bool keep = true;   // EDGE: positions the filter's constant border supplies stay
+            if constexpr (EDGE) keep = !(rowt < 0 || (k < 4 ? c.uq[k < 4 ? k : 0] : c.uh) < 0);
+            if (keep) xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] = o;
+          }
+        }
+      }
+    }
+    if (__builtin_amdgcn_ballot_w64(s.border == IPA_BORDER_CONSTANT ? (interior & kBorderSlow) != 0u
+                                                                     : interior != (1u << NS) - 1u)) {
+      // the other border modes, and the lanes border_tap_bits left to it (rare): redo them tap by
+      // tap, straight into the LDS row - ONE copy of the border-aware sampler per step (a loop,
+      // not unrolled)
 #pragma unroll 1
       for (int k = 0; k < NS; k++) {
-        if (!((interior >> k) & 1u)) {
+        if (!((interior >> k) & 1u) && (s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow))) {
           C sx, sy;
           // pixel column of sample k and its place in the LDS row
           const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;

@@ -292,3 +292,36 @@ def test_homography_coordinates_stored_once_per_batch(ia, n):
         for rep in range(2):
             for nm, fn in calls.items():
                 same_bits(fn().get(), ref[nm], 'stored coordinates: %s n=%d %r call %d' % (nm, n, (h, w), rep))
+
+
+@pytest.mark.parametrize('dtype', [np.float32, np.uint16])
+@pytest.mark.parametrize('n', [1, 3, 4, 8])
+def test_footprints_on_the_source_rim_in_every_row(ia, oracle, dtype, n):
+    """maps that leave the source along whole edges (what getOptimalNewCameraMatrix(alpha = 1) gives
+    every undistorted picture, camera/LensDistortion.py:350-357): constant border - the hand-
+    scheduled loops blend those footprints from the taps they hold (wave_pipe.hpp::border_blend),
+    uint16 frames send the corner where the packed tap dword starts before the frame through
+    sample() -, and the other border modes; against the oracle"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 97, 530
+    src = frames(n, h, w, dtype)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    cases = {
+        'half a pixel out at the top left': (xx - 0.5, yy - 0.5),
+        'out at the bottom right': (xx + 0.6, yy + 0.4),
+        'zoomed out 3 %': ((xx - w / 2) * 1.03 + w / 2, (yy - h / 2) * 1.03 + h / 2),
+        'far out on the left': (xx - 40.25, yy + 0.1),
+    }
+    for name, (mx, my) in cases.items():
+        mx, my = mx.astype(np.float32), my.astype(np.float32)
+        dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+        for K in (3, 5, 7):
+            k = kern(K)
+            for border, ob in (('constant', oracle.CONSTANT), ('replicate', oracle.REPLICATE)):
+                got = ops.remap_conv2d(ctx.to_device(src), dmx, dmy, k, 'linear', border, 0.25).get()
+                for f in range(n):
+                    want = oracle.conv2d(oracle.remap(src[f], mx, my, oracle.LINEAR, ob, 0.25,
+                                                      out_dtype=np.float32), k)
+                    assert_close(got[f], want, 1e-5, 1e-5 * np.abs(want).max(),
+                                 '%s, %dx%d, %s, frame %d of %d %s' % (name, K, K, border, f, n, np.dtype(dtype).name))
