@@ -385,6 +385,13 @@ __device__ __forceinline__ double sample_exact(const SrcView& s, C sx, C sy, dou
 // value is consumed; only then are they blended.  Footprints that touch the
 // image border (rare) are redone through sample().  Same arithmetic and
 // summation order as sample(): results are bit-identical.
+// Constant border mode (cv2.remap's default, and what the reference's alpha = 1 undistortion
+// leaves along the rim of every picture): a footprint that touches the border keeps the fast
+// path - its tap rows are loaded at their real offsets (range-checked: never a fault, a tap
+// outside the source is just the wrong pixel), the taps outside are replaced by the border value
+// in the blend, no tap inside gives the border value itself: sample()'s arithmetic in sample()'s
+// order.  Only a footprint whose row loads start before the frame or run past its end (the
+// range check may drop such a load whole) is redone through sample().
 template <typename ST, int INTERP, int N, typename C>
 __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N], const C (&sy)[N],
                                              typename compute_of<ST>::type cval,
@@ -392,7 +399,8 @@ __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N],
   using CT = typename compute_of<ST>::type;
   constexpr int NT = ntaps<INTERP>::value;
   int e[N];
-  bool interior[N];
+  bool interior[N], redo[N];
+  unsigned rmask[N], cmask[N];   // rows / columns of the footprint inside the source
   CT wx[N][NT], wy[N][NT];
 #pragma unroll
   for (int k = 0; k < N; k++) {
@@ -403,6 +411,30 @@ __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N],
     axis_split<INTERP, CT, C>(s, ok ? sy[k] : (C)0, iy0, wy[k]);
     interior[k] = ok && ix0 >= 0 && iy0 >= 0 && ix0 + NT <= s.w && iy0 + NT <= s.h;
     e[k] = interior[k] ? iy0 * s.pitch + ix0 : 0;
+    redo[k] = !interior[k];
+    rmask[k] = cmask[k] = (1u << NT) - 1u;
+    if (!interior[k] && s.border == IPA_BORDER_CONSTANT) {
+      rmask[k] = cmask[k] = 0u;
+      if (ok) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+          rmask[k] |= (unsigned)(iy0 + t) < (unsigned)s.h ? 1u << t : 0u;
+          cmask[k] |= (unsigned)(ix0 + t) < (unsigned)s.w ? 1u << t : 0u;
+        }
+      }
+      if (rmask[k] == 0u || cmask[k] == 0u) {
+        rmask[k] = cmask[k] = 0u;   // nothing of it inside: the border value
+        redo[k] = false;
+      } else {
+        // first and last row that exist: their loads must lie inside the frame
+        const int r0 = iy0 < 0 ? 0 : iy0, r1 = iy0 + NT - 1 < s.h - 1 ? iy0 + NT - 1 : s.h - 1;
+        const bool before = r0 == 0 && ix0 < 0, past = r1 == s.h - 1 && ix0 + NT > s.w;
+        if (!before && !past) {
+          e[k] = __mul24(iy0, s.pitch) + ix0;
+          redo[k] = false;
+        }
+      }
+    }
   }
   CT v[N][NT][NT];
 #pragma unroll
@@ -411,6 +443,13 @@ __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N],
     for (int r = 0; r < NT; r++) TapLoad<ST, CT>::template row<NT>(s, e[k] + r * s.pitch, v[k][r]);
 #pragma unroll
   for (int k = 0; k < N; k++) {
+    if (!interior[k] && !redo[k]) {   // (rare) taps outside the source: the border value
+#pragma unroll
+      for (int r = 0; r < NT; r++)
+#pragma unroll
+        for (int c = 0; c < NT; c++)
+          v[k][r][c] = ((rmask[k] >> r) & (cmask[k] >> c) & 1u) ? v[k][r][c] : cval;
+    }
     CT o = (CT)0;
 #pragma unroll
     for (int r = 0; r < NT; r++) {
@@ -419,11 +458,11 @@ __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N],
       for (int c = 1; c < NT; c++) rs = ipa_fma(wx[k][c], v[k][r][c], rs);
       o = r == 0 ? wy[k][0] * rs : ipa_fma(wy[k][r], rs, o);
     }
-    out[k] = o;
+    out[k] = (!interior[k] && !redo[k] && rmask[k] == 0u) ? cval : o;
   }
 #pragma unroll
   for (int k = 0; k < N; k++)
-    if (!interior[k]) out[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+    if (redo[k]) out[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
 }
 
 // ---- split form of sample_batch for software-pipelined callers (wave_stencil.hpp):
@@ -436,6 +475,11 @@ template <typename ST, int INTERP, int N> struct BatchTaps {
   CT v[N][NT][NT];
   CT tx[N], ty[N];
   unsigned interior;  // bit k: footprint k fully inside the source
+  // bilinear, constant border mode: which of the 4 taps of a footprint that is NOT interior lie
+  // inside the source (bits 4 k .. 4 k + 3: x0y0, x1y0, x0y1, x1y1) - batch_blend_border() blends
+  // it from the taps issued, the others replaced by the border value; bit 31: a footprint whose
+  // row loads start before the frame or run past its end (sample() redoes the lane's)
+  unsigned tapbits;
 };
 
 // QM selects the coordinate rule at compile time where the caller can (the per-strip loops
@@ -475,6 +519,7 @@ __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], 
   constexpr int NT = ntaps<INTERP>::value;
   static_assert(INTERP == kLinear || INTERP == kCubic, "split sampling: bilinear/bicubic only");
   b.interior = 0;
+  b.tapbits = 0;
   int e[N];
   const unsigned xlim = s.w - NT + 1 > 0 ? (unsigned)(s.w - NT + 1) : 0u;
   const unsigned ylim = s.h - NT + 1 > 0 ? (unsigned)(s.h - NT + 1) : 0u;
@@ -489,10 +534,22 @@ __device__ __forceinline__ void batch_issue(const SrcView& s, const C (&sx)[N], 
     axis_frac<INTERP, CT, C, QM>(s, ok ? sy[k] : (C)0, iy0, b.ty[k]);
     const bool in = ok && (unsigned)ix0 < xlim && (unsigned)iy0 < ylim;
     b.interior |= in ? (1u << k) : 0u;
+    if constexpr (INTERP == kLinear) {
+      if (!in && s.border == IPA_BORDER_CONSTANT) {   // (rare)
+        const bool x0 = (unsigned)ix0 < (unsigned)s.w, x1 = (unsigned)(ix0 + 1) < (unsigned)s.w;
+        const bool y0 = (unsigned)iy0 < (unsigned)s.h, y1 = (unsigned)(iy0 + 1) < (unsigned)s.h;
+        const unsigned tb = ((y0 && x0) ? 1u : 0u) | ((y0 && x1) ? 2u : 0u) | ((y1 && x0) ? 4u : 0u) |
+                            ((y1 && x1) ? 8u : 0u);
+        b.tapbits |= (ok ? tb : 0u) << (4 * k);
+        const bool before = ix0 < 0 && (iy0 == 0 || iy0 == -1);
+        const bool past = ix0 + 2 > s.w && (iy0 == s.h - 1 || iy0 == s.h - 2);
+        if (ok && tb && (before || past)) b.tapbits |= 1u << 31;
+      }
+    }
     // |iy0| <= kCoordLimit < 2^23 and pitch < 2^23 (checked at the entry points): one
     // full-rate v_mul_i32_i24 (+ add) instead of a quarter-rate 32-bit multiply.  Footprints
     // that are not inside load from wherever this lands - range-checked buffer loads return 0
-    // beyond the frame - and are redone by sample()
+    // beyond the frame - and are blended by batch_blend_border() or redone by sample()
     e[k] = __mul24(iy0, s.pitch) + ix0;
   }
 #pragma unroll
@@ -558,6 +615,35 @@ __device__ __forceinline__ typename compute_of<ST>::type batch_blend_one(
     o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
   }
   return o;
+}
+
+// footprint k of an issued batch that touches the source border: true + its value where the taps
+// issued can give it (bilinear, constant border mode: the taps outside the source replaced by the
+// border value, none inside = the border value; sample()'s arithmetic), false where sample() has to
+template <typename ST, int INTERP, int N>
+__device__ __forceinline__ bool batch_blend_border(const SrcView& s, const BatchTaps<ST, INTERP, N>& b,
+                                                   int k, typename compute_of<ST>::type cval,
+                                                   typename compute_of<ST>::type& out) {
+  using CT = typename compute_of<ST>::type;
+  if constexpr (INTERP != kLinear) {
+    return false;
+  } else {
+    if (s.border != IPA_BORDER_CONSTANT || (b.tapbits >> 31)) return false;
+    const unsigned tb = (b.tapbits >> (4 * k)) & 15u;
+    const CT v00 = (tb & 1u) ? b.v[k][0][0] : cval, v01 = (tb & 2u) ? b.v[k][0][1] : cval;
+    const CT v10 = (tb & 4u) ? b.v[k][1][0] : cval, v11 = (tb & 8u) ? b.v[k][1][1] : cval;
+    CT wx[2], wy[2];
+    weights_from_frac<kLinear, CT>(s, b.tx[k], wx);
+    weights_from_frac<kLinear, CT>(s, b.ty[k], wy);
+    CT r0 = wx[0] * v00;
+    r0 = ipa_fma(wx[1], v01, r0);
+    CT o = wy[0] * r0;
+    CT r1 = wx[0] * v10;
+    r1 = ipa_fma(wx[1], v11, r1);
+    o = ipa_fma(wy[1], r1, o);
+    out = tb ? o : cval;
+    return true;
+  }
 }
 
 // batch width per interpolation: bounded by the tap registers (N * NT^2)

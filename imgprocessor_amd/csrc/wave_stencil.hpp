@@ -395,13 +395,21 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
 #pragma unroll
       for (int k = 0; k < 4; k++) cur[k] = batch_blend_one<ST, INTERP, 4>(s, ch.t[d], k);
       if (ch.t[d].interior != 0xfu) {
-        // footprints touching the source border (rare): redo them tap by tap
-        C sx[4], sy[4];
-        coords_of_row<FAST>(c, vv[d], sx, sy);
+        // footprints touching the source border (rare): from the taps issued where they can give
+        // them (sampler.hpp::batch_blend_border), else redone tap by tap
+        bool left = false;
 #pragma unroll
         for (int k = 0; k < 4; k++)
           if (!((ch.t[d].interior >> k) & 1u))
-            cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+            left = !batch_blend_border<ST, INTERP, 4>(s, ch.t[d], k, cval, cur[k]) || left;
+        if (left) {
+          C sx[4], sy[4];
+          coords_of_row<FAST>(c, vv[d], sx, sy);
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (!((ch.t[d].interior >> k) & 1u))
+              cur[k] = sample<ST, INTERP, C>(s, sx[k], sy[k], cval);
+        }
       }
       float* row = xp + d * kRowStride + kRowPad;
       // lane-interleaved samples: pixel L + 64 k
@@ -432,9 +440,11 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     for (int d = 0; d < D; d++) {
       float cur = batch_blend_one<ST, INTERP, 1>(s, ch.th[d], 0);
       if (!(ch.th[d].interior & 1u)) {
-        C hx, hy;
-        coord.get(c.uh < 0 ? 0 : c.uh, vv[d] < 0 ? 0 : vv[d], hx, hy);
-        cur = sample<ST, INTERP, C>(s, hx, hy, cval);
+        if (!batch_blend_border<ST, INTERP, 1>(s, ch.th[d], 0, cval, cur)) {
+          C hx, hy;
+          coord.get(c.uh < 0 ? 0 : c.uh, vv[d] < 0 ? 0 : vv[d], hx, hy);
+          cur = sample<ST, INTERP, C>(s, hx, hy, cval);
+        }
       }
       cur = (vv[d] < 0 || c.uh < 0) ? ccval : cur;
       if (lane < 2u * H) xp[d * kRowStride + kRowPad - H + halo_pos<H>(lane)] = cur;
