@@ -617,7 +617,24 @@ def main():
                               'compulsory_bytes': c2,
                               'frac_compulsory': round(c2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                               'launches': 1})
-                del s2, o2
+                # the same chain with the camera matrix LensDistortion.py:350-353 really asks for -
+                # cv2.getOptimalNewCameraMatrix(alpha = 1): every source pixel kept, 2.8 % of the
+                # output outside the source along the rim (BASELINE's configuration says newK = K,
+                # where no footprint touches the border)
+                from imgprocessor_amd.utils.geometry import getOptimalNewCameraMatrix
+                nK = getOptimalNewCameraMatrix(K, dcoef, (w, h), 1.0)[0]
+                ax, ay = ops.build_undistort_map(K, dcoef, nK, h, w, ctx=ctx, device=True)
+                ms3 = timed_settled(ctx, lambda: ops.remap_conv2d(s2, ax, ay, k5, out=o2), 40, 5)
+                extra.append({'workload': "headline with the reference's own camera matrix "
+                                          '(getOptimalNewCameraMatrix, alpha = 1), %d frames/launch' % B2,
+                              'frames': B2, 'ms': round(ms3, 4), 'Mpix_s': round(B2 * h * w / ms3 / 1e3, 1),
+                              'compulsory_bytes': c2,
+                              'frac_compulsory': round(c2 / (ms3 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              'launches': 1,
+                              'note': 'footprints on the source border blended from the taps in registers '
+                                      '(wave_pipe.hpp::border_blend); through sample() this ran 45 % '
+                                      'over the line above'})
+                del s2, o2, ax, ay
             line['other_configs'] = extra + other_configs(ctx, ia, ops)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(h, w, K, dcoef, k5)
