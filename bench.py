@@ -258,7 +258,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
                        budget_launches, 5)
     entry('C3 rotated by 15 degrees: 4K f32, warp (linear) + separable 9+9, %d frames/launch' % B, B, h, w,
           ms, 8 * B * h * w, 2, 'tile warp into the workspace, then the filter (16 B/px of traffic for '
-          'an 8 B/px workload); the one fused kernel takes 0.88 ms at this angle')
+          'an 8 B/px workload); the one fused kernel takes 0.72 ms at this angle')
     ms = timed_settled(ctx, lambda: ops.warp_perspective(src, Hr, (h, w), 'lanczos4', out=dst), budget_launches, 5)
     entry('PerspectiveCorrection default rotated by 15 degrees: 4K f32, Lanczos4 warp, %d frames/launch' % B,
           B, h, w, ms, 8 * B * h * w, 1, 'tile kernel; ring + gather kernels: 1.7 ms at this angle',

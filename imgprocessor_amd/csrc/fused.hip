@@ -150,7 +150,7 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
 
 // A homography whose output rows drift across source rows (a rotation of a few degrees) is where
 // the fused kernels lose: their gathers pay per cache line a wave touches (16 x 4K, perspective
-// warp + separable 9+9: 0.34 ms at no rotation, 0.72 at 7 degrees, 1.66 at 45).  For batches
+// warp + separable 9+9: 0.33 ms at no rotation, 0.47 at 7 degrees, 0.72 at 15, 1.52 at 45).  For batches
 // the tile warp kernel takes (remap_impl.hpp: tile_warp_pays) the chain then runs as two
 // launches - tile warp into the workspace, filter - whose time hardly depends on the angle
 // (0.52 - 0.66 ms); same results (the fused kernels round the remapped rows to float32 too).
@@ -174,7 +174,7 @@ static bool rotated_warp_in_two_launches(const ipa_ctx* ctx, const double* m, in
       if (!(fabs(y1 - y0) < 1e6)) return false;
       drift = fabs(y1 - y0) > drift ? fabs(y1 - y0) : drift;
     }
-  return drift >= (ctx->tune.tile_warp > 1 ? 0.0 : 0.045);
+  return drift >= (ctx->tune.tile_warp > 1 ? 0.0 : 0.2);
 }
 
 extern "C" {

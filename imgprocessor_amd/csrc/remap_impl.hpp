@@ -470,23 +470,25 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
 // Where it pays (tile_warp = 1), measured against the ring + gather kernels on 480p ... 8K frames,
 // batches of 1 ... 16, rotations, perspective quadrilaterals and zooms (profiles/r04_micro.txt):
 //   bilinear  batches of 8+ frames and 64+ Mpx (4+ frames from 100 Mpx) of a picture that is
-//             enlarged (fetch <= 1.05: small boxes) or whose rows drift (0.1+ rows per pixel - the
-//             gathers then pay per cache line) while the boxes stay moderate (fetch <= 2.6); at
-//             scale 1 without rotation the two are level;
-//   bicubic   batches of 4+ frames (up to 2x; a few mild cases on small frames lose 15 %), smaller
-//             ones from a drift of 0.3;
-//   Lanczos4  everything but small batches (under 100 Mpx) of a picture that is enlarged (step
-//             < 0.95) and hardly rotated (drift < 0.02): there the ring kernel, whose strips
-//             then advance through few source rows, is 5-10 % ahead; elsewhere the tile kernel
-//             is up to 3 times faster (16 x 4K at scale 1: 1.19 -> 0.67 ms).
+//             enlarged (fetch <= 1.05: small boxes), or under a perspective / rotation whose rows
+//             drift a little (0.01+ rows per pixel) with boxes up to fetch 1.2 (the bench's
+//             quadrilateral: 0.37 -> 0.23 ms), or whose rows drift by 0.1+ (the gathers then pay
+//             per cache line) while the boxes stay moderate (fetch <= 2.6); at scale 1 without
+//             rotation the two are level;
+//   bicubic   batches of 4+ frames with 16+ Mpx (up to 2x), single 4K frames from a drift of 0.3;
+//             on small frames the gather kernel is 25 % ahead;
+//   Lanczos4  whenever the homography fits: up to 3 times faster (16 x 4K at scale 1: 1.19 ->
+//             0.62 ms), level with the ring kernel on small batches of an enlarged picture.
+// (tools/warp_policy_matrix.py; re-measured after the row-walking kernels stopped paying for
+// footprints on the source border)
 static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, long px) {
-  const double d = ctx->tile_warp_drift, st = ctx->tile_warp_step, g = ctx->tile_warp_fetch;
+  const double d = ctx->tile_warp_drift, g = ctx->tile_warp_fetch;   // (tile_warp_step: recorded, not used)
   const double work = (double)n_frames * (double)px;
   if (base == IPA_INTER_LINEAR)
     return ((n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6)) &&
-           (g <= 1.05 || (d >= 0.1 && g <= 2.6));
-  if (base == IPA_INTER_LANCZOS4) return d >= 0.02 || st >= 0.95 || work >= 100e6;
-  return n_frames >= 4 || d >= 0.3;
+           (g <= 1.05 || (d >= 0.01 && g <= 1.2) || (d >= 0.1 && g <= 2.6));
+  if (base == IPA_INTER_LANCZOS4) return true;
+  return (n_frames >= 4 && work >= 16e6) || (d >= 0.3 && work >= 8e6);
 }
 
 template <int INTERP, typename ST = float>

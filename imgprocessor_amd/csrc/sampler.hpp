@@ -426,9 +426,11 @@ __device__ __forceinline__ void sample_batch(const SrcView& s, const C (&sx)[N],
         rmask[k] = cmask[k] = 0u;   // nothing of it inside: the border value
         redo[k] = false;
       } else {
-        // first and last row that exist: their loads must lie inside the frame
+        // first and last row that exist: their loads must lie inside the frame (element offsets;
+        // a frame narrower than the footprint has rows that start before it further down)
         const int r0 = iy0 < 0 ? 0 : iy0, r1 = iy0 + NT - 1 < s.h - 1 ? iy0 + NT - 1 : s.h - 1;
-        const bool before = r0 == 0 && ix0 < 0, past = r1 == s.h - 1 && ix0 + NT > s.w;
+        const long first = (long)r0 * s.pitch + ix0, last = (long)r1 * s.pitch + ix0 + NT;
+        const bool before = first < 0, past = last > (long)(s.h - 1) * s.pitch + s.w;
         if (!before && !past) {
           e[k] = __mul24(iy0, s.pitch) + ix0;
           redo[k] = false;

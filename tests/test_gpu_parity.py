@@ -118,6 +118,29 @@ def test_remap_all_modes_vs_oracle(ia, oracle):
             oracle.remap(u8, mx, my, oracle.CUBIC_KEYS, out_dtype=np.float32), 'u8->f32')
 
 
+def test_remap_frames_narrower_than_the_footprint(ia, oracle):
+    """sources of 1 .. 5 pixels across or down: every footprint touches the border, and the tap rows
+    of a bicubic / Lanczos4 footprint start before the frame or run past its end even in its
+    middle rows (found by tools/fuzz_tile_warp.py on a 7 x 1 source)"""
+    rng = np.random.default_rng(12)
+    interps = {'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS, 'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5,
+               'lanczos4': oracle.LANCZOS4}
+    for (h, w) in ((7, 1), (1, 7), (1, 1), (2, 3), (3, 2), (5, 4), (4, 9), (9, 3)):
+        img = rng.random((h, w), dtype=np.float32)
+        yy, xx = np.mgrid[0:23, 0:37].astype(np.float32)
+        mx = (xx * (w + 6) / 37.0 - 3.3 + 0.2 * np.sin(yy)).astype(np.float32)
+        my = (yy * (h + 6) / 23.0 - 2.7 + 0.3 * np.cos(xx)).astype(np.float32)
+        for iname, iid in interps.items():
+            for bname, bid in (('constant', oracle.CONSTANT), ('replicate', oracle.REPLICATE)):
+                for src in (img, np.stack([img, img[::-1, ::-1].copy(), img * 0.5])):   # single frame, batch
+                    got = ia.ops.remap(src, mx, my, iname, bname, 0.25)
+                    frames_ = src if src.ndim == 3 else src[None]
+                    for f in range(frames_.shape[0]):
+                        want = oracle.remap(frames_[f], mx, my, iid, bid, 0.25)
+                        close32(got[f] if src.ndim == 3 else got, want,
+                                '%dx%d %s/%s frame %d' % (h, w, iname, bname, f), scale=1.0)
+
+
 def test_remap_uint8_bit_exact(ia, oracle):
     rng = np.random.default_rng(4)
     H, W = 97, 131
