@@ -79,7 +79,7 @@ struct ipa_ctx {
   // the LDS box of the tile warp kernel (tile_warp.hpp) for the last homography + geometry: a
   // host-side walk over the tiles that a repeated call does not pay again (0.4 ms per 4K call)
   double tile_warp_key[14];
-  int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0;
+  int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0, tile_warp_shape = 0;
   double tile_warp_drift = 0, tile_warp_step = 0, tile_warp_fetch = 0;   // see tile_warp_pays()
   // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
   // and the source + geometry it belongs to: ring_plan_prepare's hint

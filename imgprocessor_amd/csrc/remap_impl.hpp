@@ -476,7 +476,8 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
 //             per cache line) while the boxes stay moderate (fetch <= 2.6); at scale 1 without
 //             rotation the two are level;
 //   bicubic   batches of 4+ frames with 16+ Mpx (up to 2x), single 4K frames from a drift of 0.3;
-//             on small frames the gather kernel is 25 % ahead;
+//             on small frames the gather kernel is 25 % ahead, and where the picture shrinks so
+//             much that a 32 x 16 tile reads 8+ times its pixels (fetch > 8) too;
 //   Lanczos4  whenever the homography fits: up to 3 times faster (16 x 4K at scale 1: 1.19 ->
 //             0.62 ms), level with the ring kernel on small batches of an enlarged picture.
 // (tools/warp_policy_matrix.py; re-measured after the row-walking kernels stopped paying for
@@ -488,26 +489,34 @@ static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, lo
     return ((n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6)) &&
            (g <= 1.05 || (d >= 0.01 && g <= 1.2) || (d >= 0.1 && g <= 2.6));
   if (base == IPA_INTER_LANCZOS4) return true;
-  return (n_frames >= 4 && work >= 16e6) || (d >= 0.3 && work >= 8e6);
+  return ((n_frames >= 4 && work >= 16e6) || (d >= 0.3 && work >= 8e6)) && g <= 8.0;
 }
 
 template <int INTERP, typename ST = float>
 static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const HomographyCoord& coord,
                             int n_frames, int base) {
   constexpr bool kU16 = std::is_same<ST, uint16_t>::value;
+  constexpr int NT = ntaps<INTERP>::value;
   TileWarpArgs t;
+  int shape;
   {
     double key[14] = {(double)(INTERP + (kU16 ? 16 : 0)), (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
     for (int k = 0; k < 9; k++) key[5 + k] = coord.m[k];
     if (!ctx->tile_warp_valid || memcmp(key, ctx->tile_warp_key, sizeof key) != 0) {
-      int pitch = 0, rows = 0;
-      const bool ok = tile_warp_box<ntaps<INTERP>::value, kU16>(coord.m, p.dh, p.dw, p.sh, p.sw, &pitch, &rows);
+      // the largest tile shape whose source boxes fit (tile_warp.hpp)
+      int pitch = 0, rows = 0, sh = 0;
+      bool ok = false;
+      for (sh = 0; sh < kWarpShapes && !ok; sh++)
+        ok = tile_warp_box<NT, kU16>(coord.m, p.dh, p.dw, p.sh, p.sw, kWarpTileWs[sh], kWarpTileHs[sh],
+                                     &pitch, &rows);
+      sh -= 1;
       ctx->tile_warp_ok = ok ? 1 : 0;
+      ctx->tile_warp_shape = sh;
       ctx->tile_warp_rows = rows;
-      ctx->tile_warp_pitch = ok ? tile_warp_pitch<ntaps<INTERP>::value>(coord.m, p.dh, p.dw, pitch, rows) : 0;
+      ctx->tile_warp_pitch = ok ? tile_warp_pitch<NT>(coord.m, p.dh, p.dw, pitch, rows) : 0;
       if (ok)
-        tile_warp_measure(coord.m, p.dh, p.dw, pitch, rows, &ctx->tile_warp_drift, &ctx->tile_warp_step,
-                          &ctx->tile_warp_fetch);
+        tile_warp_measure(coord.m, p.dh, p.dw, pitch, rows, kWarpTileWs[sh], kWarpTileHs[sh],
+                          &ctx->tile_warp_drift, &ctx->tile_warp_step, &ctx->tile_warp_fetch);
       memcpy(ctx->tile_warp_key, key, sizeof key);
       ctx->tile_warp_valid = 1;
     }
@@ -521,15 +530,17 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
     }
     t.pitch = ctx->tile_warp_pitch;
     t.rows = ctx->tile_warp_rows;
+    shape = ctx->tile_warp_shape;
   }
+  const int TW = kWarpTileWs[shape], TH = kWarpTileHs[shape];
   t.dst = p.dst; t.dst_frame_elems = p.dst_frame_elems; t.dpitch = p.dpitch;
   t.src = p.src; t.src_frame_bytes = p.src_frame_bytes; t.src_bytes = p.src_bytes;
   t.sh = p.sh; t.sw = p.sw; t.spitch = p.spitch; t.dh = p.dh; t.dw = p.dw;
   t.n_frames = n_frames;
   t.border = p.border; t.q5 = p.q5; t.cubic_a = p.cubic_a; t.lanczos = p.lanczos;
   t.cval = (float)p.cval;
-  t.tiles_x = (p.dw + kWarpTileW - 1) / kWarpTileW;
-  t.tiles = t.tiles_x * ((p.dh + kWarpTileH - 1) / kWarpTileH);
+  t.tiles_x = (p.dw + TW - 1) / TW;
+  t.tiles = t.tiles_x * ((p.dh + TH - 1) / TH);
   // frames a workgroup walks through with one evaluation of its tile's coordinates: as many as
   // still leave the launch four rounds of workgroups (4 per CU)
   t.frames_wg = 8;
@@ -539,9 +550,10 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
   if (dbytes >= (1ull << 31)) return 1;
   t.dst_bytes = (unsigned)dbytes;
   const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
-  const size_t lds = (size_t)tile_warp_lds_bytes<ntaps<INTERP>::value>(t.pitch, t.rows);
-  hipLaunchKernelGGL((tile_warp_kernel<INTERP, ST>), dim3((unsigned)t.tiles * groups), dim3(256), lds,
-                     ctx->stream, t, coord);
+  if ((unsigned long)t.tiles * groups >= (1ul << 31)) return 1;
+  const size_t lds = (size_t)tile_warp_lds_bytes<NT>(t.pitch, t.rows);
+  if (shape == 0) tile_warp_run_a(ctx->stream, t, coord, INTERP, kU16, shape, (unsigned)t.tiles * groups, lds);
+  else tile_warp_run_b(ctx->stream, t, coord, INTERP, kU16, shape, (unsigned)t.tiles * groups, lds);
   return 0;
 }
 

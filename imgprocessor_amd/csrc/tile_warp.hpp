@@ -29,8 +29,12 @@
 
 namespace ipa {
 
-constexpr int kWarpTileW = 64, kWarpTileH = 32;
-constexpr int kWarpTilePx = kWarpTileH / 4;      // pixels per thread: lane = column, rows wave + 4 j
+// Tile shapes (output pixels per workgroup of 256 threads): 64 x 32 wherever its source boxes fit,
+// 32 x 32 and 32 x 16 for homographies that shrink parts of the picture (PerspectiveCorrection's
+// uncorrect / distort, strong trapezoids: a 64 x 32 tile of the far side can span 180 x 96 source
+// pixels).  TW = 64: lane = column, wave + 4 j = row; TW = 32: lanes 0-31 / 32-63 = two rows.
+constexpr int kWarpShapes = 3;
+constexpr int kWarpTileWs[kWarpShapes] = {64, 32, 32}, kWarpTileHs[kWarpShapes] = {32, 32, 16};
 constexpr int kWarpTileLdsBytes = 40960;  // the box of one tile (4 workgroups per CU at the most)
 
 struct TileWarpArgs {
@@ -124,9 +128,13 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, d
   return out;
 }
 
-template <int INTERP, typename ST = float>
+template <int INTERP, typename ST, int TW, int TH>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic || (INTERP == kLanczos4 && sizeof(ST) == 4) ? 4 : 3, 8)))
 tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
+  static_assert((TW == 64 || TW == 32) && (TW * TH) % 256 == 0, "tile shapes of tile_warp.hpp");
+  constexpr int kWarpTileW = TW, kWarpTileH = TH;
+  constexpr int kWarpTilePx = TW * TH / 256;   // pixels per thread
+  constexpr int kRowsPass = 256 / TW;          // output rows the workgroup covers per pixel index j
   constexpr int NT = ntaps<INTERP>::value;
   constexpr bool kLz = INTERP == kLanczos4;
   // uint16 frames: OpenCV's 16U arithmetic (float32 table weights, no fma).  The box is clipped to
@@ -193,11 +201,13 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   s.lanczos = lz;
   int ad[kWarpTilePx];
   float tx[kWarpTilePx], ty[kWarpTilePx];   // Lanczos4: the table rows' float offsets, as ints
-  const int x = x0 + (int)lane;
+  const int x = x0 + (int)(lane & (unsigned)(TW - 1));
+  // row of pixel j of this thread: yl + kRowsPass j (TW = 64: wave-uniform)
+  const int yl = TW == 64 ? (int)wave : 2 * (int)wave + (int)(lane >> 5);
   unsigned slow = 0;
 #pragma unroll
   for (int j = 0; j < kWarpTilePx; j++) {
-    const int y = y0 + (int)wave + 4 * j;
+    const int y = y0 + yl + kRowsPass * j;
     double sx, sy;
     coord.get(x < a.dw ? x : a.dw - 1, y < a.dh ? y : a.dh - 1, sx, sy);
     const bool ok = ipa_abs(sx) < (double)kCoordLimit && ipa_abs(sy) < (double)kCoordLimit;
@@ -420,14 +430,16 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
     // (uint16: `o` is the float32 sum; cv::saturate_cast<ushort> = round half to even, clamp)
     auto store_px = [&](float o, int y) {
-      const int so = (int)((long)y * a.dpitch) << kEsh;
+      // (TW = 64: the row is wave-uniform and its offset a scalar; TW = 32: two rows per wave)
+      const int so = TW == 64 ? (int)((long)y * a.dpitch) << kEsh : 0;
+      const int vo = TW == 64 ? x << kEsh : (int)((long)y * a.dpitch + x) << kEsh;
       if constexpr (kU16) {
         float q = rintf(o);
         q = q > 0.f ? q : 0.f;   // NaN -> 0
         q = q < 65535.f ? q : 65535.f;
-        __builtin_amdgcn_raw_buffer_store_b16((short)(unsigned short)q, drs, x << kEsh, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((short)(unsigned short)q, drs, vo, so, 0);
       } else {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, x << kEsh, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, vo, so, 0);
       }
     };
     constexpr int kGroup = INTERP == kLinear ? 4 : (INTERP == kCubic ? 2 : 1);
@@ -436,7 +448,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       const int pstep = a.pitch << 3;   // bytes from pair to pair
 #pragma unroll
       for (int j = 0; j < kWarpTilePx; j++) {
-        const int y = y0 + (int)wave + 4 * j;
+        const int y = y0 + yl + kRowsPass * j;
         const float4* rx = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) & 0xffff));
         const float4* ry = reinterpret_cast<const float4*>(lz + (__float_as_int(tx[j]) >> 16));
         const float4 a0 = rx[0], a1 = rx[1], b0 = ry[0], b1 = ry[1];
@@ -535,7 +547,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     for (int j0 = 0; j0 < kWarpTilePx; j0 += kGroup) {
 #pragma unroll
       for (int j = j0; j < j0 + kGroup; j++) {
-        const int y = y0 + (int)wave + 4 * j;
+        const int y = y0 + yl + kRowsPass * j;
         float wx[NT], wy[NT];
         const float* tp = tile_lds + (ad[j] < 0 ? 0 : ad[j]);
         float o = 0.f;
@@ -579,13 +591,13 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 #pragma unroll 1
       for (int j = 0; j < kWarpTilePx; j++) {
         if (!((slow >> j) & 1u)) continue;
-        const int y = y0 + (int)wave + 4 * j;
+        const int y = y0 + yl + kRowsPass * j;
         if (x >= a.dw || y >= a.dh) continue;
         double sx, sy;
         coord.get(x, y, sx, sy);
         if constexpr (kU16)
-          __builtin_amdgcn_raw_buffer_store_b16((short)slow_u16(sx, sy), drs, x << kEsh,
-                                                (int)((long)y * a.dpitch) << kEsh, 0);
+          __builtin_amdgcn_raw_buffer_store_b16((short)slow_u16(sx, sy), drs,
+                                                (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
         else
           store_px(tile_slow_sample<INTERP>(s, sx, sy, a.cval), y);
       }
@@ -603,8 +615,8 @@ static inline long tile_warp_lds_bytes(int pitch, int rows) {
 }
 
 template <int NT, bool INSIDE = false>
-static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int* pitch,
-                                 int* rows) {
+static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw, int kWarpTileW,
+                                 int kWarpTileH, int* pitch, int* rows) {
   // w = m6 u + m7 v + m8 keeps one sign over the picture when it does at the four corners
   const double wc[4] = {m[8], m[6] * (dw - 1) + m[8], m[7] * (dh - 1) + m[8],
                         m[6] * (dw - 1) + m[7] * (dh - 1) + m[8]};
@@ -651,7 +663,8 @@ static inline bool tile_warp_box(const double* m, int dh, int dw, int sh, int sw
 //   step   source pixels per output pixel along either axis (> 1: the picture shrinks);
 //   fetch  cells of the largest box per pixel of a tile (what a tile reads over what it writes).
 static inline void tile_warp_measure(const double* m, int dh, int dw, int pitch, int rows,
-                                     double* drift, double* step, double* fetch) {
+                                     int kWarpTileW, int kWarpTileH, double* drift, double* step,
+                                     double* fetch) {
   auto at = [&](double u, double v, double& sx, double& sy) {
     const double W = m[6] * u + m[7] * v + m[8], iw = W != 0.0 ? 1.0 / W : 0.0;
     sx = (m[0] * u + m[1] * v + m[2]) * iw;
@@ -726,6 +739,30 @@ static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch
     }
   }
   return best;
+}
+
+// the launches, by tile shape (tile_warp_a.hip: 64 x 32; tile_warp_b.hip: 32 x 32, 32 x 16)
+void tile_warp_run_a(hipStream_t stream, const TileWarpArgs& t, const HomographyCoord& coord, int interp,
+                     bool u16, int shape, unsigned grid, size_t lds);
+void tile_warp_run_b(hipStream_t stream, const TileWarpArgs& t, const HomographyCoord& coord, int interp,
+                     bool u16, int shape, unsigned grid, size_t lds);
+
+// (for the two translation units above)
+template <int TW, int TH>
+static inline void tile_warp_run_shape(hipStream_t stream, const TileWarpArgs& t, const HomographyCoord& coord,
+                                       int interp, bool u16, unsigned grid, size_t lds) {
+  if (u16) {
+    if (interp == kLanczos4)
+      hipLaunchKernelGGL((tile_warp_kernel<kLanczos4, uint16_t, TW, TH>), dim3(grid), dim3(256), lds, stream, t, coord);
+    else
+      hipLaunchKernelGGL((tile_warp_kernel<kCubic, uint16_t, TW, TH>), dim3(grid), dim3(256), lds, stream, t, coord);
+  } else if (interp == kLinear) {
+    hipLaunchKernelGGL((tile_warp_kernel<kLinear, float, TW, TH>), dim3(grid), dim3(256), lds, stream, t, coord);
+  } else if (interp == kLanczos4) {
+    hipLaunchKernelGGL((tile_warp_kernel<kLanczos4, float, TW, TH>), dim3(grid), dim3(256), lds, stream, t, coord);
+  } else {
+    hipLaunchKernelGGL((tile_warp_kernel<kCubic, float, TW, TH>), dim3(grid), dim3(256), lds, stream, t, coord);
+  }
 }
 
 }  // namespace ipa
