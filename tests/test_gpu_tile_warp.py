@@ -234,3 +234,32 @@ def test_tile_kernel_with_pitches_and_frame_strides(ia, case, odd):
     assert np.array_equal(np.ascontiguousarray(got[:, :dh, :dw]).view(np.uint8), want.view(np.uint8)), \
         'pitched tile warp %s %s' % (interp, np.dtype(dt).name)
     assert (got[:, dh:, :] == dt(9)).all() and (got[:, :, dw:] == dt(9)).all(), 'wrote outside the region'
+
+
+@pytest.mark.parametrize('case', [('linear', np.float32), ('cubic_cv', np.float32), ('lanczos4', np.float32),
+                                  ('cubic_cv_q5', np.uint16), ('lanczos4', np.uint16)])
+def test_small_tiles_where_the_picture_shrinks(ia, case):
+    """homographies that shrink the picture (or parts of it: the far side of a trapezoid): the source
+    box of a 64 x 32 tile exceeds the kernel's 128 columns / 40 KB and the launch goes to 32 x 32 or
+    32 x 16 tiles (two output rows per wave); beyond that, back to the gather kernel - same bits"""
+    from imgprocessor_amd import ops
+    interp, dt = case
+    ctx = ia.default_context(0)
+    n, h, w = 3, 420, 640
+    rng = np.random.default_rng(8)
+    src = (rng.integers(0, 65536, (n, h, w)).astype(np.uint16) if dt == np.uint16
+           else rng.random((n, h, w), dtype=np.float32))
+    d = ctx.to_device(src)
+    trapezoid = np.array([[1.0, 0.35, -70.0], [0.02, 1.9, -150.0], [0.0, 0.0022, 1.0]])   # far side 2x denser
+    Ms = [rot_persp(h, w, 12.0, zoom=z) for z in (1.5, 2.2, 3.4, 4.6)] + [trapezoid]
+    for M in Ms:
+        for border in ('constant', 'reflect'):
+            out = []
+            try:
+                for tw in (0, 2):
+                    ctx.set_tuning(tile_warp=tw)
+                    out.append(ops.warp_perspective(d, M, (h - 20, w + 30), interp, border, border_value=3).get())
+            finally:
+                ctx.set_tuning(tile_warp=1)
+            assert np.array_equal(out[0].view(np.uint8), out[1].view(np.uint8)), \
+                '%s %s %s' % (interp, border, np.round(M, 3).tolist())
