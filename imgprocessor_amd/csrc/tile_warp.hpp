@@ -73,28 +73,27 @@ __host__ __device__ inline void tile_axis_box(double lo, double hi, int n, int& 
 
 // sample() of sampler.hpp tap by tap (rolled loops, a handful of registers): the same weights,
 // products and sums in the same order - for the few footprints a tile's box does not hold
-template <int INTERP>
-__device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, double sy, float cval) {
+template <int INTERP, typename C>
+__device__ __forceinline__ float tile_slow_sample(const SrcView& s, C sx, C sy, float cval) {
   constexpr int NT = ntaps<INTERP>::value;
-  if (!(sx > (double)-kCoordLimit && sx < (double)kCoordLimit && sy > (double)-kCoordLimit &&
-        sy < (double)kCoordLimit)) {
+  if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit && sy < (C)kCoordLimit)) {
     if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cval;
-    sx = sx < (double)-kCoordLimit ? (double)-kCoordLimit : (sx > (double)kCoordLimit ? (double)kCoordLimit : sx);
-    sy = sy < (double)-kCoordLimit ? (double)-kCoordLimit : (sy > (double)kCoordLimit ? (double)kCoordLimit : sy);
+    sx = sx < (C)-kCoordLimit ? (C)-kCoordLimit : (sx > (C)kCoordLimit ? (C)kCoordLimit : sx);
+    sy = sy < (C)-kCoordLimit ? (C)-kCoordLimit : (sy > (C)kCoordLimit ? (C)kCoordLimit : sy);
   }
   int ix0, iy0;
   float wxs[4], wys[4];   // bilinear / bicubic weights (indexed with constants only)
   const float *wxr = s.lanczos, *wyr = s.lanczos;   // Lanczos4: rows of the table (the LDS copy)
   if constexpr (INTERP == kLanczos4) {
-    const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+    const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
     ix0 = (qx >> 5) - 3;
     iy0 = (qy >> 5) - 3;
     wxr += (qx & 31) * 8;
     wyr += (qy & 31) * 8;
   } else {
     float wx[NT], wy[NT];
-    axis_split<INTERP, float, double>(s, sx, ix0, wx);
-    axis_split<INTERP, float, double>(s, sy, iy0, wy);
+    axis_split<INTERP, float, C>(s, sx, ix0, wx);
+    axis_split<INTERP, float, C>(s, sy, iy0, wy);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       wxs[k] = wx[k % NT];
@@ -128,9 +127,16 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, double sx, d
   return out;
 }
 
-template <int INTERP, typename ST, int TW, int TH>
+template <int INTERP, typename ST, int TW, int TH, typename Coord = HomographyCoord>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(INTERP == kCubic || (INTERP == kLanczos4 && sizeof(ST) == 4) ? 4 : 3, 8)))
-tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
+tile_warp_kernel(TileWarpArgs a, Coord coord) {
+  // Coord: the homography (its tile boxes bounded by the tile's corners, the LDS sized by the
+  // host's walk over the tiles) or a coordinate TABLE - cv2.remap's map pair
+  // (camera/LensDistortion.py:323-326): the box of a tile is then the span of its own footprints
+  // (a reduction over the workgroup), clamped to the fixed LDS the launch reserves
+  using C = typename Coord::coord_t;
+  constexpr bool kHom = std::is_same<Coord, HomographyCoord>::value;
+  static_assert(kHom || !std::is_same<ST, uint16_t>::value, "coordinate tables: float32 frames");
   static_assert((TW == 64 || TW == 32) && (TW * TH) % 256 == 0, "tile shapes of tile_warp.hpp");
   constexpr int kWarpTileW = TW, kWarpTileH = TH;
   constexpr int kWarpTilePx = TW * TH / 256;   // pixels per thread
@@ -151,7 +157,7 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     else return __mul24(r, a.pitch) + c;
   };
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
-  __shared__ double corner[8];
+  __shared__ double corner[8];   // (homography: the tile's corners; tables: the waves' footprint spans)
   __shared__ __attribute__((aligned(16))) float lz[kU16 ? 384 : (kLz ? 256 : 4)];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -166,15 +172,15 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   const int x0 = txi * kWarpTileW, y0 = tyi * kWarpTileH;
   const int x1 = x0 + kWarpTileW - 1 < a.dw ? x0 + kWarpTileW - 1 : a.dw - 1;
   const int y1 = y0 + kWarpTileH - 1 < a.dh ? y0 + kWarpTileH - 1 : a.dh - 1;
-  if (tid < 4u) {
-    double sx, sy;
-    coord.get((tid & 1u) ? x1 : x0, (tid & 2u) ? y1 : y0, sx, sy);
-    corner[2 * tid] = sx;
-    corner[2 * tid + 1] = sy;
-  }
-  __syncthreads();
-  int bx0, by0, bw, bh;
-  {
+  int bx0 = 0, by0 = 0, bw = 0, bh = 0;
+  if constexpr (kHom) {
+    if (tid < 4u) {
+      double sx, sy;
+      coord.get((tid & 1u) ? x1 : x0, (tid & 2u) ? y1 : y0, sx, sy);
+      corner[2 * tid] = sx;
+      corner[2 * tid + 1] = sy;
+    }
+    __syncthreads();
     double lox = corner[0], hix = corner[0], loy = corner[1], hiy = corner[1];
     bool fin = true;
 #pragma unroll
@@ -192,7 +198,6 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     bx0 = __builtin_amdgcn_readfirstlane(bx0); by0 = __builtin_amdgcn_readfirstlane(by0);
     bw = __builtin_amdgcn_readfirstlane(bw); bh = __builtin_amdgcn_readfirstlane(bh);
   }
-  const bool inside = bx0 >= 0 && by0 >= 0 && bx0 + bw <= a.sw && by0 + bh <= a.sh;
 
   // the tile's footprints, once: LDS index of the first tap (-1: through sample()), fractions
   SrcView s;
@@ -205,37 +210,86 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   // row of pixel j of this thread: yl + kRowsPass j (TW = 64: wave-uniform)
   const int yl = TW == 64 ? (int)wave : 2 * (int)wave + (int)(lane >> 5);
   unsigned slow = 0;
-#pragma unroll
-  for (int j = 0; j < kWarpTilePx; j++) {
+  // footprint of pixel j: first tap, fractions (or table rows); false for coordinates that are
+  // not finite / far outside
+  auto footprint = [&](int j, int& ix0, int& iy0) -> bool {
     const int y = y0 + yl + kRowsPass * j;
-    double sx, sy;
+    C sx, sy;
     coord.get(x < a.dw ? x : a.dw - 1, y < a.dh ? y : a.dh - 1, sx, sy);
-    const bool ok = ipa_abs(sx) < (double)kCoordLimit && ipa_abs(sy) < (double)kCoordLimit;
-    if (!ok) sx = sy = 0.0;
-    int ix0, iy0;
+    const bool ok = ipa_abs(sx) < (C)kCoordLimit && ipa_abs(sy) < (C)kCoordLimit;
+    if (!ok) sx = sy = (C)0;
     if constexpr (kLz) {
-      const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+      const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
       ix0 = (qx >> 5) - 3;
       iy0 = (qy >> 5) - 3;
       tx[j] = __int_as_float(((qx & 31) << 3) | ((qy & 31) << 19));   // float offsets of both table rows
       ty[j] = 0.f;
     } else if constexpr (kU16) {   // bicubic: rows of the float32 table at 256, 1/32-px coordinates
-      const int qx = (int)ipa_rint(sx * 32.0), qy = (int)ipa_rint(sy * 32.0);
+      const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
       ix0 = (qx >> 5) - 1;
       iy0 = (qy >> 5) - 1;
       tx[j] = __int_as_float((256 + ((qx & 31) << 2)) | ((256 + ((qy & 31) << 2)) << 16));
       ty[j] = 0.f;
     } else {
-      axis_frac<INTERP, float, double>(s, sx, ix0, tx[j]);
-      axis_frac<INTERP, float, double>(s, sy, iy0, ty[j]);
+      axis_frac<INTERP, float, C>(s, sx, ix0, tx[j]);
+      axis_frac<INTERP, float, C>(s, sy, iy0, ty[j]);
     }
+    return ok;
+  };
+  auto place = [&](int j, bool ok, int ix0, int iy0) {
     const int cx = ix0 - bx0, cy = iy0 - by0;
     const bool in = ok && cx >= 0 && cy >= 0 && cx + NT <= bw && cy + NT <= bh;
     // (Lanczos4: first pair and column of the footprint in front, its row parity in bit 0)
     ad[j] = !in ? -1 : (kLz ? ((__mul24(cy >> 1, 2 * a.pitch) + 2 * cx) << 1) | (cy & 1) : __mul24(cy, a.pitch) + cx);
     slow |= in ? 0u : 1u << j;
-    __builtin_amdgcn_sched_barrier(0);   // one pixel's double arithmetic at a time (registers)
+  };
+  if constexpr (kHom) {
+#pragma unroll
+    for (int j = 0; j < kWarpTilePx; j++) {
+      int ix0, iy0;
+      const bool ok = footprint(j, ix0, iy0);
+      place(j, ok, ix0, iy0);
+      __builtin_amdgcn_sched_barrier(0);   // one pixel's double arithmetic at a time (registers)
+    }
+  } else {
+    // coordinate table: all footprints first, their span over the workgroup = the box
+    int fx[kWarpTilePx], fy[kWarpTilePx];
+    unsigned okm = 0;
+    int xmn = INT_MAX, xmx = INT_MIN, ymn = INT_MAX, ymx = INT_MIN;
+#pragma unroll
+    for (int j = 0; j < kWarpTilePx; j++) {
+      const bool ok = footprint(j, fx[j], fy[j]);
+      okm |= ok ? 1u << j : 0u;
+      // (footprints wholly outside the source do not stretch the box: sample() gives them the
+      // border value or resolves them tap by tap)
+      const bool use = ok && fx[j] > -NT && fx[j] < a.sw && fy[j] > -NT && fy[j] < a.sh;
+      xmn = use && fx[j] < xmn ? fx[j] : xmn; xmx = use && fx[j] > xmx ? fx[j] : xmx;
+      ymn = use && fy[j] < ymn ? fy[j] : ymn; ymx = use && fy[j] > ymx ? fy[j] : ymx;
+    }
+    wave_span(xmn, xmx, ymn, ymx);
+    int* wbox = reinterpret_cast<int*>(corner);
+    if (lane == 0) {
+      wbox[4 * wave + 0] = xmn; wbox[4 * wave + 1] = xmx;
+      wbox[4 * wave + 2] = ymn; wbox[4 * wave + 3] = ymx;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      xmn = wbox[4 * k] < xmn ? wbox[4 * k] : xmn; xmx = wbox[4 * k + 1] > xmx ? wbox[4 * k + 1] : xmx;
+      ymn = wbox[4 * k + 2] < ymn ? wbox[4 * k + 2] : ymn; ymx = wbox[4 * k + 3] > ymx ? wbox[4 * k + 3] : ymx;
+    }
+    if (xmn <= xmx && ymn <= ymx) {
+      bx0 = xmn; by0 = ymn;
+      bw = xmx + NT - xmn; bh = ymx + NT - ymn;
+      bw = bw < a.pitch ? bw : a.pitch;
+      bh = bh < a.rows ? bh : a.rows;
+    }
+    bx0 = __builtin_amdgcn_readfirstlane(bx0); by0 = __builtin_amdgcn_readfirstlane(by0);
+    bw = __builtin_amdgcn_readfirstlane(bw); bh = __builtin_amdgcn_readfirstlane(bh);
+#pragma unroll
+    for (int j = 0; j < kWarpTilePx; j++) place(j, (okm >> j) & 1u, fx[j], fy[j]);
   }
+  const bool inside = bx0 >= 0 && by0 >= 0 && bx0 + bw <= a.sw && by0 + bh <= a.sh;
 
   ST* dst0 = reinterpret_cast<ST*>(a.dst);
   // one source element at byte offset voffset + soffset of a frame's descriptor, as float
@@ -249,50 +303,70 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
   const unsigned f1 = f0 + (unsigned)a.frames_wg < (unsigned)a.n_frames ? f0 + (unsigned)a.frames_wg
                                                                         : (unsigned)a.n_frames;
 
-  // The box of a tile INSIDE the source: wave w takes rows w, w + 4, ..., lane l column l - the row
-  // offset is a scalar, nothing but the LDS address is computed per load; the columns past 64 go
-  // 64 >> esh rows per load (lane = row : column, esh bits of column).  The first kRowsFly rows
-  // of a wave and its first 4 loads of the far columns are REQUESTED while the previous frame is
-  // being sampled and written to LDS after it (box_issue / box_commit): the ~1 us of an HBM
-  // round trip is then behind the samples and stores of a frame, not in front of them.
+  // The box of a tile: wave w takes rows w, w + 4, ..., lane l column l - the row offset is a
+  // scalar, nothing but the LDS address is computed per load; the columns past 64 go 64 >> esh
+  // rows per load (lane = row : column, esh bits of column).  The first kRowsFly rows of a wave
+  // and its first 4 loads of the far columns are REQUESTED while the previous frame is being
+  // sampled and written to LDS after it (box_issue / box_commit): the ~1 us of an HBM round trip
+  // is then behind the samples and stores of a frame, not in front of them.
+  // A box INSIDE the source, or ANY box in the constant border mode (`direct`): there the rows and
+  // columns that are not the source's - the rim of a rotated picture, of an alpha = 1
+  // undistortion - load from a clamped place and are written as the border value.  The other
+  // border modes on the rim go cell by cell (below).
   constexpr int kRowsFly = INTERP == kCubic ? 10 : 12;   // (a box of 35 / 37 / 41 rows at no rotation)
-  const int voff = (int)lane << kEsh;
-  const bool c0 = (int)lane < bw;
+  // (bicubic only: in one process, 16 x 4K at 15 degrees, direct against cell by cell: bicubic
+  // 0.392 / 0.414 ms, but bilinear 0.371 / 0.310 and Lanczos4 0.869 / 0.841 - the larger loop body
+  // costs those two more than their rim tiles gain; profiles/r04_micro.txt)
+  constexpr bool kDirectRim = INTERP == kCubic;
+  const bool direct = inside || (kDirectRim && a.border == IPA_BORDER_CONSTANT);
+  const bool c0 = (int)lane < bw;                                               // a cell of the box
+  const bool c0v = c0 && (unsigned)(bx0 + (int)lane) < (unsigned)a.sw;          // ... inside the source
+  const int voff = c0v ? (bx0 + (int)lane) << kEsh : 0;
   const int e = bw - 64;
   const int esh = e <= 4 ? 2 : (e <= 8 ? 3 : (e <= 16 ? 4 : (e <= 32 ? 5 : 6)));
   const int rstep = 64 >> esh;   // rows per load of the far columns
   const int lr = (int)lane >> esh, lc = 64 + ((int)lane & ((1 << esh) - 1));
   const bool cl = lc < bw;
-  const int soff0 = (__mul24(by0, a.spitch) + bx0) << kEsh;
+  const bool clv = cl && (unsigned)(bx0 + lc) < (unsigned)a.sw;
+  const int lcoff = clv ? bx0 + lc : 0;
+  // byte offset of box row r in a frame (scalar; rows that are not the source's: row 0, not used)
+  auto row_off = [&](int r) -> int {
+    const int yy = by0 + r;
+    return (unsigned)yy < (unsigned)a.sh ? __mul24(yy, a.spitch) << kEsh : 0;
+  };
+  auto row_live = [&](int r) -> bool { return (unsigned)(by0 + r) < (unsigned)a.sh; };
   float v0[kRowsFly], v1[4];
   // (addresses stepped from one value the compiler cannot carry across the frame loop: held as
   // loop invariants they are 40 registers)
-  auto box_issue = [&](const __amdgpu_buffer_rsrc_t& rs) {
+  // (RIM: the box has rows / columns that are not the source's; a box inside the source skips the
+  // checks - they cost the bilinear kernel 15 %)
+  auto box_issue = [&](auto rim_, const __amdgpu_buffer_rsrc_t& rs) {
+    constexpr bool RIM = decltype(rim_)::value;
 #pragma unroll
     for (int u = 0; u < kRowsFly; u++) {
       const int r = (int)wave + 4 * u < bh ? (int)wave + 4 * u : bh - 1;
-      v0[u] = load_px(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << kEsh));
+      v0[u] = load_px(rs, voff, RIM ? row_off(r) : __mul24(by0 + r, a.spitch) << kEsh);
     }
     if (e > 0) {
       int r = (int)wave * rstep + lr;
       asm volatile("" : "+v"(r));
-      int off = (__mul24(r, a.spitch) + lc) << kEsh;
-      const int ostep = __mul24(4 * rstep, a.spitch) << kEsh;
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        v1[u] = load_px(rs, cl && r < bh ? off : 0, soff0);
+        const bool live = clv && r < bh && (!RIM || (unsigned)(by0 + r) < (unsigned)a.sh);
+        v1[u] = load_px(rs, live ? (__mul24(by0 + r, a.spitch) + lcoff) << kEsh : 0, 0);
         r += 4 * rstep;
-        off += ostep;
       }
     }
   };
-  auto box_commit = [&]() {
+  auto box_commit = [&](auto rim_) {
+    constexpr bool RIM = decltype(rim_)::value;
     int la = cell((int)wave, (int)lane);   // rows wave + 4 u: 4 rows = 2 pairs further each
     asm volatile("" : "+v"(la));
     const int lstep = 4 * a.pitch;
 #pragma unroll
     for (int u = 0; u < kRowsFly; u++) {
-      if ((int)wave + 4 * u < bh && c0) tile_lds[la] = v0[u];
+      const int r = (int)wave + 4 * u;
+      if (r < bh && c0) tile_lds[la] = (!RIM || (c0v && row_live(r))) ? v0[u] : a.cval;
       la += lstep;
     }
     if (e > 0) {
@@ -300,14 +374,15 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       asm volatile("" : "+v"(r));
 #pragma unroll
       for (int u = 0; u < 4; u++) {
-        if (cl && r < bh) tile_lds[cell(r, lc)] = v1[u];
+        if (cl && r < bh) tile_lds[cell(r, lc)] = (!RIM || (clv && (unsigned)(by0 + r) < (unsigned)a.sh)) ? v1[u] : a.cval;
         r += 4 * rstep;
       }
     }
   };
   // (boxes taller than 4 kRowsFly rows - Lanczos4 under a rotation of 30 degrees and more - or
   // with many far columns: the rest, read when the frame's turn has come)
-  auto box_rest = [&](const __amdgpu_buffer_rsrc_t& rs) {
+  auto box_rest = [&](auto rim_, const __amdgpu_buffer_rsrc_t& rs) {
+    constexpr bool RIM = decltype(rim_)::value;
     constexpr int kMore = 8;   // rows in flight
 #pragma unroll 1
     for (int r0 = (int)wave + 4 * kRowsFly; r0 < bh; r0 += 4 * kMore) {
@@ -315,19 +390,19 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
 #pragma unroll
       for (int u = 0; u < kMore; u++) {
         const int r = r0 + 4 * u < bh ? r0 + 4 * u : bh - 1;
-        t[u] = load_px(rs, c0 ? voff : 0, soff0 + (__mul24(r, a.spitch) << kEsh));
+        t[u] = load_px(rs, voff, RIM ? row_off(r) : __mul24(by0 + r, a.spitch) << kEsh);
       }
 #pragma unroll
       for (int u = 0; u < kMore; u++)
-        if (r0 + 4 * u < bh && c0) tile_lds[cell(r0 + 4 * u, (int)lane)] = t[u];
+        if (r0 + 4 * u < bh && c0) tile_lds[cell(r0 + 4 * u, (int)lane)] = (!RIM || (c0v && row_live(r0 + 4 * u))) ? t[u] : a.cval;
     }
     if (e > 0) {
 #pragma unroll 1
       for (int r0 = ((int)wave + 16) * rstep; r0 < bh; r0 += 4 * rstep) {
         const int r = r0 + lr;
-        const bool live = cl && r < bh;
-        const float t = load_px(rs, live ? (__mul24(r, a.spitch) + lc) << kEsh : 0, soff0);
-        if (live) tile_lds[cell(r, lc)] = t;
+        const bool live = clv && r < bh && (!RIM || (unsigned)(by0 + r) < (unsigned)a.sh);
+        const float t = load_px(rs, live ? (__mul24(by0 + r, a.spitch) + lcoff) << kEsh : 0, 0);
+        if (cl && r < bh) tile_lds[cell(r, lc)] = live ? t : a.cval;
       }
     }
   };
@@ -392,17 +467,25 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
     return (uint16_t)q;
   };
   s.rsrc = make_rsrc(a.src + (long)f0 * a.src_frame_bytes, a.src_bytes);
-  if (inside && f0 < f1) box_issue(s.rsrc);
+  using RimT = std::true_type;
+  using InT = std::false_type;
+  // (ONE issue statement for both kinds of box: two alternative ones would meet at a join, and
+  // the compiler drains the loads there)
+  if (direct && f0 < f1) box_issue(RimT{}, s.rsrc);
 #pragma unroll 1
   for (unsigned f = f0; f < f1; f++) {
     s.rsrc = make_rsrc(a.src + (long)f * a.src_frame_bytes, a.src_bytes);
     __syncthreads();   // the previous frame's taps are read (first pass: the Lanczos table is written)
     // 1. the box
     if (inside) {
-      box_commit();
-      box_rest(s.rsrc);
+      box_commit(InT{});
+      box_rest(InT{}, s.rsrc);
+    } else if (kDirectRim && direct) {
+      box_commit(RimT{});
+      box_rest(RimT{}, s.rsrc);
     } else {
-      // on the rim of the source: cell by cell (i = row i / bw, column i % bw) through the border mode
+      // on the rim of the source in the other border modes: cell by cell (i = row i / bw, column
+      // i % bw) through the border mode
 #pragma unroll 1
       for (int i = (int)tid; i < cells; i += 256) {
         const int row = (int)(((float)i + 0.5f) * inv_bw), col = i - row * bw;
@@ -415,8 +498,10 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
       }
     }
     __syncthreads();
-    if (inside && f + 1 < f1)
-      box_issue(make_rsrc(a.src + (long)(f + 1) * a.src_frame_bytes, a.src_bytes));
+    if (f + 1 < f1) {
+      const __amdgpu_buffer_rsrc_t nrs = make_rsrc(a.src + (long)(f + 1) * a.src_frame_bytes, a.src_bytes);
+      if (direct) box_issue(RimT{}, nrs);
+    }
     // (the weights are formed anew for every frame: kept across the frame loop they are 8 registers
     // per pixel the compiler would hold - bicubic 178 registers, 2 workgroups per CU)
     if constexpr (INTERP != kLinear) {   // (Lanczos4: the table rows read anew - 16 registers per pixel)
@@ -593,13 +678,13 @@ tile_warp_kernel(TileWarpArgs a, HomographyCoord coord) {
         if (!((slow >> j) & 1u)) continue;
         const int y = y0 + yl + kRowsPass * j;
         if (x >= a.dw || y >= a.dh) continue;
-        double sx, sy;
+        C sx, sy;
         coord.get(x, y, sx, sy);
         if constexpr (kU16)
           __builtin_amdgcn_raw_buffer_store_b16((short)slow_u16(sx, sy), drs,
                                                 (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
         else
-          store_px(tile_slow_sample<INTERP>(s, sx, sy, a.cval), y);
+          store_px(tile_slow_sample<INTERP, C>(s, sx, sy, a.cval), y);
       }
     }
   }
@@ -746,6 +831,10 @@ void tile_warp_run_a(hipStream_t stream, const TileWarpArgs& t, const Homography
                      bool u16, int shape, unsigned grid, size_t lds);
 void tile_warp_run_b(hipStream_t stream, const TileWarpArgs& t, const HomographyCoord& coord, int interp,
                      bool u16, int shape, unsigned grid, size_t lds);
+
+// coordinate tables (cv2.remap's map pair), float32 frames, 64 x 32 tiles (tile_warp_a.hip)
+void tile_warp_run_map(hipStream_t stream, const TileWarpArgs& t, const MapCoord& coord, int interp,
+                       unsigned grid, size_t lds);
 
 // (for the two translation units above)
 template <int TW, int TH>

@@ -263,3 +263,46 @@ def test_small_tiles_where_the_picture_shrinks(ia, case):
                 ctx.set_tuning(tile_warp=1)
             assert np.array_equal(out[0].view(np.uint8), out[1].view(np.uint8)), \
                 '%s %s %s' % (interp, border, np.round(M, 3).tolist())
+
+
+@pytest.mark.parametrize('interp', INTERPS)
+def test_map_remaps_on_the_tile_kernel(ia, oracle, interp):
+    """cv2.remap's map pair as the coordinate source (camera/LensDistortion.py:323-326): the box of a
+    tile is the span of its own footprints, clamped to a fixed reserve of LDS - smooth lens maps,
+    zooms, rotations, a map that jumps about (most of it tap by tap then), NaN / far-away entries;
+    the gather kernel's bits, and the oracle"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    rng = np.random.default_rng(2)
+    oi = {'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS, 'cubic_cv': oracle.CUBIC_CV,
+          'linear_cv_q5': oracle.LINEAR | oracle.Q5, 'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5,
+          'lanczos4': oracle.LANCZOS4}[interp]
+    for (h, w, n) in ((301, 517, 3), (33, 200, 5), (150, 520, 1)):
+        src = rng.random((n, h, w), dtype=np.float32)
+        d = ctx.to_device(src)
+        yy, xx = np.mgrid[0:h + 9, 0:w - 5].astype(np.float32)
+        r2 = (xx - w / 2) ** 2 + (yy - h / 2) ** 2
+        mapsets = {'radial': ((xx - w / 2) * (1 + 1e-6 * r2) + w / 2, (yy - h / 2) * (1 + 1e-6 * r2) + h / 2),
+                   'zoom out': ((xx - w / 2) * 1.07 + w / 2, (yy - h / 2) * 1.07 + h / 2),
+                   'rotated': (np.cos(.35) * (xx - w / 2) - np.sin(.35) * (yy - h / 2) + w / 2,
+                               np.sin(.35) * (xx - w / 2) + np.cos(.35) * (yy - h / 2) + h / 2),
+                   'wild': (xx + 30 * np.sin(yy / 7), yy + 25 * np.cos(xx / 5))}
+        for mname, (mx, my) in mapsets.items():
+            mx, my = mx.astype(np.float32), my.astype(np.float32)
+            if mname == 'wild':
+                mx[3, 4] = np.nan
+                my[5, 6] = 1e9
+            dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+            for border, ob in (('constant', oracle.CONSTANT), ('replicate', oracle.REPLICATE),
+                               ('reflect', oracle.REFLECT), ('wrap', oracle.WRAP)):
+                out = []
+                try:
+                    for tw in (0, 2):
+                        ctx.set_tuning(tile_warp=tw)
+                        out.append(ops.remap(d, dmx, dmy, interp, border, 0.25).get())
+                finally:
+                    ctx.set_tuning(tile_warp=1)
+                same_bits(out[1], out[0], '%s %s %s %dx%d' % (mname, interp, border, h, w))
+                if (h, w) == (33, 200) and border in ('constant', 'reflect') and mname != 'wild':
+                    want = oracle.remap(src[0], mx, my, oi, ob, 0.25)
+                    assert_close(out[1][0], want, 1e-5, 1e-5, '%s %s %s vs oracle' % (mname, interp, border))

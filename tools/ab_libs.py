@@ -79,6 +79,12 @@ def main():
     k9 /= k9.sum()
     k11 = np.random.default_rng(321).random((11, 11))
     k11 /= k11.sum()
+    def rot(deg):
+        a = np.deg2rad(deg)
+        cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+        R = np.array([[np.cos(a), -np.sin(a), cx - np.cos(a) * cx + np.sin(a) * cy],
+                      [np.sin(a), np.cos(a), cy - np.sin(a) * cx - np.cos(a) * cy], [0, 0, 1.0]])
+        return np.array([[1, 0, 0], [0, 1, 0], [2e-6, 1e-6, 1.0]]) @ R
     rng = np.random.default_rng(0)
     one = rng.random((16, h, w), dtype=np.float32)
     host = np.concatenate([one] * (batch // 16)) if batch >= 16 else one[:batch]
@@ -128,6 +134,12 @@ def main():
             'fused9': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k9, out=m.dst),
             'fused11': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k11, out=m.dst),
             'remap': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, out=m.dst),
+            # perspective warps on the tile kernel under a rotation of 15 / 45 degrees
+            'lin15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'linear', out=m.dst),
+            'lin45': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(45), (h, w), 'linear', out=m.dst),
+            'cub15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'cubic', out=m.dst),
+            'lz15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'lanczos4', out=m.dst),
+            'lin0': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(0), (h, w), 'linear', out=m.dst),
             'copy': lambda m=mod: m.dst.copy_from(m.src),
         }
         builds.append((spec, mod, ctx, knobs, calls))
