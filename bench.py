@@ -215,6 +215,21 @@ def other_configs(ctx, ia, ops, budget_launches=60):
           B, h, w, ms, (8 * B + 8) * h * w, 1)
     del src, dst, dmx, dmy
 
+    # LensDistortion.correct itself: cv2.remap from the map pair, no filter behind it (SURVEY section
+    # 8, rows a1 - a3) - bilinear as the reference calls it, and Lanczos4
+    h, w, B = H4K, W4K, 16
+    K, dcoef = camera(h, w)
+    src = ctx.to_device(synth_frames(B, h, w, 250))
+    dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
+    dst = ctx.empty((B, h, w), np.float32)
+    for interp in ('linear', 'lanczos4'):
+        ms = timed_settled(ctx, lambda: ops.remap(src, dmx, dmy, interp, out=dst), budget_launches, 5)
+        entry('LensDistortion.correct 4K f32, cv2.remap from the map pair (%s), %d frames/launch' % (interp, B),
+              B, h, w, ms, (8 * B + 8) * h * w, 1,
+              'tile kernel with the map pair as coordinate source (csrc/tile_warp.hpp)',
+              **({'bound': 'lds', 'work': 40 * 8 * B * h * w} if interp == 'lanczos4' else {}))
+    del src, dst, dmx, dmy
+
     # C3: 4K float32, perspective remap (homography in the kernel: no maps) + separable 9+9
     h, w, B = H4K, W4K, 16
     quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
