@@ -81,6 +81,14 @@ struct ipa_ctx {
   double tile_warp_key[14];
   int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0, tile_warp_shape = 0;
   double tile_warp_drift = 0, tile_warp_step = 0, tile_warp_fetch = 0;   // see tile_warp_pays()
+  // map remaps on the tile kernel: device word the kernel counts its tap-by-tap pixels in, the
+  // page-locked word it is read back to (async: possibly one call old), and the maps + geometry
+  // it belongs to
+  unsigned* tile_slow_dev = nullptr;
+  unsigned* tile_slow_host = nullptr;
+  double tile_slow_key[10];
+  int tile_slow_valid = 0;
+  unsigned tile_slow_skips = 0;
   // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
   // and the source + geometry it belongs to: ring_plan_prepare's hint
   unsigned* ring_hint = nullptr;

@@ -533,6 +533,7 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
     shape = ctx->tile_warp_shape;
   }
   const int TW = kWarpTileWs[shape], TH = kWarpTileHs[shape];
+  t.slow_count = nullptr;
   t.dst = p.dst; t.dst_frame_elems = p.dst_frame_elems; t.dpitch = p.dpitch;
   t.src = p.src; t.src_frame_bytes = p.src_frame_bytes; t.src_bytes = p.src_bytes;
   t.sh = p.sh; t.sw = p.sw; t.spitch = p.spitch; t.dh = p.dh; t.dw = p.dw;
@@ -558,14 +559,48 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
 }
 
 // map-based remaps of float32 frames on the tile kernel: the box of a tile is the span of its own
-// footprints, the LDS a fixed reserve (97 columns x 48 rows: a 64 x 32 tile of a lens map with its
-// halo and some rows of drift; what does not fit goes tap by tap).  knob tile_warp as above
+// footprints, the LDS a fixed reserve (what does not fit goes tap by tap).  knob tile_warp as above
 template <int INTERP>
 static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoord& coord, int n_frames) {
   constexpr int NT = ntaps<INTERP>::value;
   TileWarpArgs t;
-  t.pitch = 97;
-  t.rows = 48;
+  // (the registers limit every instantiation to 4 workgroups per CU: 39 KB of box per workgroup
+  // cost no occupancy - 127 columns x 72 rows hold a 64 x 32 tile of a map that shrinks the picture
+  // up to 1.8 x 2 times)
+  // (bilinear fits 5 workgroups per CU into its registers: a reserve of 97 x 48 - a lens map's
+  // tile with its halo and some drift - keeps them; 16 x 4K: 0.228 against 0.281 ms)
+  // bicubic: beyond a zoom of 1.4 its boxes make it slower than the gather kernel (1.7: 0.66
+  // against 0.48 ms) - a reserve that does not hold them hands such maps back through the count
+  t.pitch = NT == 8 ? 127 : 97;
+  t.rows = NT == 2 ? 48 : (NT == 8 ? 72 : 56);
+  // A map whose tiles need more - the host cannot know: the map is device data - sends the pixels
+  // outside the box tap by tap, at 10 - 100 times the cost (16 x 4K zoomed out 2.5 x: Lanczos4
+  // 4.7 ms against 1.2 on the gather kernel).  The kernel counts them for its first frame group;
+  // the count comes back without a wait (so: one call late), and from the second call on a map
+  // pair with more than 0.5 % such pixels takes the ring / gather kernels (every 64th call tries
+  // again: the map's contents may have changed behind the same pointers)
+  {
+    double key[10] = {(double)(uintptr_t)coord.mx, (double)(uintptr_t)coord.my, (double)coord.pitch,
+                      (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw, (double)INTERP,
+                      (double)p.border, (double)p.q5};
+    if (!ctx->tile_slow_dev) {
+      IPA_HIP(ctx, hipMalloc((void**)&ctx->tile_slow_dev, 2 * sizeof(unsigned)));
+      IPA_HIP(ctx, hipHostMalloc((void**)&ctx->tile_slow_host, 2 * sizeof(unsigned)));
+      ctx->tile_slow_host[0] = 0;
+    }
+    const bool same = ctx->tile_slow_valid && memcmp(key, ctx->tile_slow_key, sizeof key) == 0;
+    if (same && ctx->tune.tile_warp < 2 &&
+        (double)ctx->tile_slow_host[0] > 0.005 * (double)p.dh * p.dw && (++ctx->tile_slow_skips & 63u) != 0)
+      return 1;
+    if (!same) {
+      memcpy(ctx->tile_slow_key, key, sizeof key);
+      ctx->tile_slow_valid = 1;
+      ctx->tile_slow_skips = 0;
+      ctx->tile_slow_host[0] = 0;   // (a read-back still in flight may land here once: a late hint)
+    }
+    IPA_HIP(ctx, hipMemsetAsync(ctx->tile_slow_dev, 0, sizeof(unsigned), ctx->stream));
+  }
+  t.slow_count = ctx->tile_slow_dev;
   t.dst = p.dst; t.dst_frame_elems = p.dst_frame_elems; t.dpitch = p.dpitch;
   t.src = p.src; t.src_frame_bytes = p.src_frame_bytes; t.src_bytes = p.src_bytes;
   t.sh = p.sh; t.sw = p.sw; t.spitch = p.spitch; t.dh = p.dh; t.dw = p.dw;
@@ -584,6 +619,8 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
   if ((unsigned long)t.tiles * groups >= (1ul << 31)) return 1;
   tile_warp_run_map(ctx->stream, t, coord, INTERP, (unsigned)t.tiles * groups,
                     (size_t)tile_warp_lds_bytes<NT>(t.pitch, t.rows));
+  IPA_HIP(ctx, hipMemcpyAsync(ctx->tile_slow_host, ctx->tile_slow_dev, sizeof(unsigned), hipMemcpyDeviceToHost,
+                              ctx->stream));
   return 0;
 }
 

@@ -51,6 +51,10 @@ struct TileWarpArgs {
   float cval;
   int tiles_x, tiles;
   int pitch, rows;   // the LDS box: floats per row (chosen against bank conflicts: tile_warp_pitch), rows
+  // coordinate tables: pixels of the first frame group whose footprints the box did not hold are
+  // counted here (the host cannot know a map's boxes: remap_impl.hpp reads the count back
+  // without waiting and keeps the next call with this map away if they were many); else null
+  unsigned* slow_count;
 };
 
 // first and last source index the footprints of coordinates in [lo, hi] can touch, clipped to what
@@ -209,7 +213,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
   const int x = x0 + (int)(lane & (unsigned)(TW - 1));
   // row of pixel j of this thread: yl + kRowsPass j (TW = 64: wave-uniform)
   const int yl = TW == 64 ? (int)wave : 2 * (int)wave + (int)(lane >> 5);
-  unsigned slow = 0;
+  unsigned slow = 0, costly = 0;   // costly: a footprint sample() has to walk tap by tap
   // footprint of pixel j: first tap, fractions (or table rows); false for coordinates that are
   // not finite / far outside
   auto footprint = [&](int j, int& ix0, int& iy0) -> bool {
@@ -263,6 +267,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
       // (footprints wholly outside the source do not stretch the box: sample() gives them the
       // border value or resolves them tap by tap)
       const bool use = ok && fx[j] > -NT && fx[j] < a.sw && fy[j] > -NT && fy[j] < a.sh;
+      costly |= (use || (ok && a.border != IPA_BORDER_CONSTANT)) ? 1u << j : 0u;
       xmn = use && fx[j] < xmn ? fx[j] : xmn; xmx = use && fx[j] > xmx ? fx[j] : xmx;
       ymn = use && fy[j] < ymn ? fy[j] : ymn; ymx = use && fy[j] > ymx ? fy[j] : ymx;
     }
@@ -290,6 +295,18 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
     for (int j = 0; j < kWarpTilePx; j++) place(j, (okm >> j) & 1u, fx[j], fy[j]);
   }
   const bool inside = bx0 >= 0 && by0 >= 0 && bx0 + bw <= a.sw && by0 + bh <= a.sh;
+  if constexpr (!kHom) {
+    if (a.slow_count && grp == 0u) {
+      // (pixels outside the output do not count, nor the ones sample() answers with the border
+      // value at once: footprints wholly outside the source in the constant border mode)
+      unsigned cnt = 0;
+#pragma unroll
+      for (int j = 0; j < kWarpTilePx; j++)
+        cnt += ((slow & costly) >> j) & 1u && x < a.dw && y0 + yl + kRowsPass * j < a.dh ? 1u : 0u;
+      // wave sum by ballot per bit would be 8 ballots; one atomic per lane that has any is rare
+      if (cnt) atomicAdd(a.slow_count, cnt);
+    }
+  }
 
   ST* dst0 = reinterpret_cast<ST*>(a.dst);
   // one source element at byte offset voffset + soffset of a frame's descriptor, as float
