@@ -306,3 +306,28 @@ def test_map_remaps_on_the_tile_kernel(ia, oracle, interp):
                 if (h, w) == (33, 200) and border in ('constant', 'reflect') and mname != 'wild':
                     want = oracle.remap(src[0], mx, my, oi, ob, 0.25)
                     assert_close(out[1][0], want, 1e-5, 1e-5, '%s %s %s vs oracle' % (mname, interp, border))
+
+
+def test_maps_that_need_more_than_the_reserve(ia):
+    """a map pair that shrinks the picture 2.5 times: its tiles' boxes exceed the kernel's LDS
+    reserve, the pixels outside go tap by tap and are counted; the default policy hands the pair to
+    the gather kernel from the second call on - the same bits on every call, on either kernel"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    n, h, w = 8, 1100, 1930          # 17 Mpx: the default policy takes the tile kernel for Lanczos4
+    rng = np.random.default_rng(4)
+    d = ctx.to_device(rng.random((n, h, w), dtype=np.float32))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    dmx = ctx.to_device(((xx - w / 2) * 2.5 + w / 2).astype(np.float32))
+    dmy = ctx.to_device(((yy - h / 2) * 2.5 + h / 2).astype(np.float32))
+    for interp in ('lanczos4', 'cubic'):
+        try:
+            ctx.set_tuning(tile_warp=0)
+            ref = ops.remap(d, dmx, dmy, interp, 'reflect').get()
+            ctx.set_tuning(tile_warp=2)
+            same_bits(ops.remap(d, dmx, dmy, interp, 'reflect').get(), ref, interp + ' forced')
+        finally:
+            ctx.set_tuning(tile_warp=1)
+        for call in range(3):
+            same_bits(ops.remap(d, dmx, dmy, interp, 'reflect').get(), ref, '%s default, call %d' % (interp, call))
+            ctx.synchronize()
