@@ -29,7 +29,7 @@ def _embed(a, pad_x, pad_rows, fill):
 
 @pytest.mark.parametrize('odd', [0, 1])
 @pytest.mark.parametrize('interp', ['linear', 'cubic', 'lanczos4'])
-@pytest.mark.parametrize('tune', [dict(ring_remap=0), dict(ring_remap=2)])
+@pytest.mark.parametrize('tune', [dict(ring_remap=0), dict(ring_remap=2), dict(tile_warp=2)])
 def test_remap_with_pitches(ia, interp, tune, odd):
     from imgprocessor_amd import ops
     from imgprocessor_amd.device import dtype_id
@@ -39,7 +39,9 @@ def test_remap_with_pitches(ia, interp, tune, odd):
     mx, my, _, _ = radial_maps(h, w)
     old = ctx.set_tuning(ring_min=1, **tune)
     try:
+        ref_knobs = ctx.set_tuning(tile_warp=0, ring_remap=0)   # the reference: the plain gather kernel
         want = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), interp).get()
+        ctx.set_tuning(**{k: v for k, v in ref_knobs.items()})
         # pitches (elements): rows 16-byte aligned, or (odd) at every 4-byte alignment
         sp, dp, mp = w + 24 + odd, w + 8 + 3 * odd, w + 12 + odd
         sbig = ctx.to_device(_embed(src, sp - w, 5, 7.0))
