@@ -103,7 +103,8 @@ def main():
                 mod.src = ctx.to_device(host)
                 mod.dst = ctx.empty((batch, h, w), np.float32)
                 mod.dmx, mod.dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
-                mod.u16 = ctx.to_device(np.round(host * 4095).astype(np.uint16)) if 'c4' in what else None
+                mod.u16 = ctx.to_device(np.round(host * 4095).astype(np.uint16)) if ('c4' in what or 'lz16' in what or 'lz16r' in what) else None
+                mod.d16 = ctx.empty((batch, h, w), np.uint16) if mod.u16 is not None else None
             else:
                 # the SAME device buffers for every build (one process, one device: a pointer of
                 # the first build's allocator is valid in the others) - where a buffer lands in
@@ -121,6 +122,7 @@ def main():
                 mod.src, mod.dst = view(first.src), view(first.dst)
                 mod.dmx, mod.dmy = view(first.dmx), view(first.dmy)
                 mod.u16 = view(first.u16) if first.u16 is not None else None
+                mod.d16 = view(first.d16) if first.u16 is not None else None
         calls = {
             'fused5': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5, out=m.dst),
             'fused7': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k7, out=m.dst),
@@ -140,6 +142,9 @@ def main():
             'cub15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'cubic', out=m.dst),
             'lz15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'lanczos4', out=m.dst),
             'lin0': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(0), (h, w), 'linear', out=m.dst),
+            # uint16 frames, OpenCV's 16U Lanczos4 (PerspectiveCorrection's default on the camera's frames)
+            'lz16': lambda o=ops, m=mod: o.warp_perspective(m.u16, Hq, (h, w), 'lanczos4', out=m.d16),
+            'lz16r': lambda o=ops, m=mod: o.warp_perspective(m.u16, rot(15), (h, w), 'lanczos4', out=m.d16),
             'copy': lambda m=mod: m.dst.copy_from(m.src),
         }
         builds.append((spec, mod, ctx, knobs, calls))
