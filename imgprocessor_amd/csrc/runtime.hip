@@ -70,6 +70,7 @@ const TuneName kTuneNames[] = {
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
+    {"halo_shared", "IPA_HALO_SHARED", &ipa_tuning::halo_shared},
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };

@@ -51,6 +51,22 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef IPA_PIPE_STAY
 #define IPA_PIPE_STAY 0   // ... the footprint-did-not-move case from registers too (measured: no gain, 1.035 vs 1.034 ms)
 #endif
+#ifndef IPA_SHARE_TAPS
+#define IPA_SHARE_TAPS 0   // 9: measurement only (WRONG results): no right-hand tap gathers at all, the
+                           // right tap of a footprint = the left tap of the neighbouring lane (DPP)
+#endif
+#ifndef IPA_DEBUG_HALO_LEVEL
+#define IPA_DEBUG_HALO_LEVEL 0   // measurement only (WRONG results): 1 = no halo gathers, 2 = no halo work at all
+#endif
+#ifndef IPA_STEP_ORDER
+#define IPA_STEP_ORDER 1   // shared-record loop: 1 = the records of row t + 1 are requested from LDS at the top of
+                           // step t and the filter's windows right behind the sample row, both BEFORE the
+                           // gathers of row t + 1 are issued (their LDS latency under the blend / the gather
+                           // issue); 0 = rounds 3 - 4: records, gathers, then windows
+#endif
+#ifndef IPA_LANE_NATURAL
+#define IPA_LANE_NATURAL 0   // shared-record loop: sample k of lane L is strip pixel 4 L + k instead of L + 64 k
+#endif
 
 // ------------------------------------------------------------------ asm primitives --
 // A gfx9-family hazard the compiler cannot guard for us: a vector-memory instruction that reads
@@ -186,16 +202,30 @@ __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned
 
 // ------------------------------------------------------------------ the K x K row step --
 // sample row (LDS, natural pixel order) -> the K running rows; returns the completed row
+// (in two halves, so that a caller can put other work between the LDS reads and their use)
+template <int K>
+__device__ __forceinline__ void pipe_filter_load(const float* xp, unsigned lane, unsigned lane4_opaque,
+                                                 v2f (&pair)[K + 2]) {
+  using G = wave_geom<K>;
+  const float* wp = xp + kRowPad - G::H + 4u * lane;
+  const float* wq = xp + kRowPad - G::H + lane4_opaque;
+#pragma unroll
+  for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+}
+template <int K>
+__device__ __forceinline__ v4f pipe_filter_sums(const Weights<float, K * K>& wts, const v2f (&pair)[K + 2],
+                                                v2f (&acc)[K][2]);
 template <int K>
 __device__ __forceinline__ v4f pipe_filter_row(const Weights<float, K * K>& wts, const float* xp,
                                                unsigned lane, unsigned lane4_opaque,
                                                v2f (&acc)[K][2]) {
-  using G = wave_geom<K>;
-  const float* wp = xp + kRowPad - G::H + 4u * lane;
-  const float* wq = xp + kRowPad - G::H + lane4_opaque;
   v2f pair[K + 2];
-#pragma unroll
-  for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+  pipe_filter_load<K>(xp, lane, lane4_opaque, pair);
+  return pipe_filter_sums<K>(wts, pair, acc);
+}
+template <int K>
+__device__ __forceinline__ v4f pipe_filter_sums(const Weights<float, K * K>& wts, const v2f (&pair)[K + 2],
+                                                v2f (&acc)[K][2]) {
   // coefficient n = i K + j is one half of the SGPR pair {w[n & ~1], w[(n & ~1) + 1]}, broadcast
   // by op_sel: K K / 2 scalar pairs instead of the K K {w, w} pairs the compiler forms (which
   // spill to VGPR lanes: 45 v_readlane per row in the first build of this loop)
@@ -340,6 +370,12 @@ template <typename Coord, int K> struct pipe_unshared<SampleRowSrc<float, kLinea
 #ifndef IPA_HALO_SAMPLE
 #define IPA_HALO_SAMPLE 0
 #endif
+// sampling kernels with a second flavour on 256-px ALIGNED strips (round 5): the shared-record loop
+// with the halo pixels sampled by quads of lanes (wave_run_strip_shared, HALO).  Launched for the
+// batches that run that loop (frames_wg); knob halo_shared
+template <typename Src, int K> struct halo_shared {
+  static constexpr bool value = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && shared_capable<Src, K>::value && K <= 7;
+};
 template <typename Src, int K, bool STREAM> struct geom_halo {
   static constexpr bool value = (IPA_PIPE != 0) && (IPA_HALO != 0) && !STREAM && K <= 9 &&
                                 pipe_capable<Src, K>::value && (IPA_HALO_SAMPLE != 0 || !Src::kHasQ5);
@@ -657,9 +693,9 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
 // instead of issued (43 % of them on the 4K lens map).
 // The filter is a policy: dense K x K (DenseFilter) or separable K + K (SepFilter, wave_sep.hpp).
 // Same footprints, same words, same blend as wave_run_strip_pipe / the chunked loop: identical bits.
-// floats per record row: offsets, tx, ty (256 each), inside bits (64); HALO geometry: + the halo
-// sample's offset, tx, ty per lane (3 x 64)
-template <bool HALO> struct ring_row { static constexpr int value = HALO ? 1024 : 832; };
+// floats per record row: offsets, tx, ty (256 each), inside bits (64); HALO geometry: + one 16-byte
+// entry per HALO LANE (see wave_run_strip_shared: 4 lanes per halo pixel, at most 8 halo pixels)
+template <bool HALO> struct ring_row { static constexpr int value = HALO ? 832 + 128 : 832; };
 
 template <int K> struct DenseFilter {
   static constexpr int kTaps = K;
@@ -674,6 +710,14 @@ template <int K> struct DenseFilter {
   template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols&) {
     return pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
   }
+  // the same in two halves: the windows out of the LDS row, later the sums
+  v2f pair[K + 2];
+  __device__ __forceinline__ void load(const float* xp, unsigned lane) {
+    pipe_filter_load<K>(xp, lane, lane4_opaque, pair);
+  }
+  template <bool EDGE> __device__ __forceinline__ v4f sums(const Cols&) {
+    return pipe_filter_sums<K>(wts, pair, acc);
+  }
 };
 
 template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord>
@@ -684,10 +728,23 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       int nrows, bool writer, float* dst) {
   using G = wave_geom<K, HALO>;
   using C = typename Coord::coord_t;
-  // samples per lane and row: pixels lane + 64 k (k = 0..3) and, in the HALO geometry (256-px
-  // aligned strips, all lanes store), the halo pixel of lanes 0 .. 2H-1 as a fifth sample under
-  // an EXEC mask
-  constexpr int NS = HALO ? 5 : 4;
+  // samples per lane and row: pixels lane + 64 k (k = 0..3).
+  // HALO geometry (round 5: 256-px ALIGNED strips, all 64 lanes store whole 128-byte lines - the
+  // 248-px step of the overlapping strips costs a plain copy 16 %, tools/pipe_micro.hip G1 / G0):
+  // the HP = 2 H halo pixels of a row (H left of the strip, H right of it) are sampled by QUADS of
+  // lanes: lane 4 j + tap holds tap `tap` (0 top-left, 1 top-right, 2 bottom-left, 3 bottom-right)
+  // of halo pixel j - ONE gather instruction and ONE register per row for all of them; the blend
+  // picks the four taps of a quad with DPP quad_perm broadcasts (sample()'s arithmetic in its
+  // order: identical bits) and lane 4 j writes the sample into the pad of the LDS row.  The
+  // producer of a record row forms the halo footprints as a fifth sample of its lanes 0 .. HP-1
+  // and publishes them per halo lane: {byte offset of the lane's tap, tx, ty, flags}.  (The
+  // first form of this geometry - the halo pixel as a fifth sample of lanes 0 .. HP-1 with its
+  // own tap rows, fractions and need masks - took 128 VGPRs + 5 spilled and measured 5 % slower
+  // than the overlapping strips, profiles/r03_micro.txt.)
+  constexpr int NS = 4;
+  constexpr int NSP = HALO ? 5 : 4;           // producer: footprints per lane
+  constexpr int HP = 2 * G::H;                // halo pixels per row
+  static_assert(!HALO || HP <= 8, "at most 8 halo pixels (32 halo lanes, 128 record floats)");
   constexpr int RR = ring_row<HALO>::value;   // floats per record row
   constexpr bool kTable = coord_is_table<Coord>::value;   // coordinates from a float32 table
   // registers per tap row of a footprint: float32 frames two dwords, uint16 frames ONE dword that
@@ -696,14 +753,26 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   constexpr int SH = sizeof(ST) == 4 ? 2 : 1;   // log2 of the element size
   static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value, "float32 / uint16 frames");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
+  // lane order of the samples: interleaved (sample k of lane L = strip pixel L + 64 k: the 64
+  // gathers of an instruction walk along the source row) or natural (pixel 4 L + k; measurement
+  // only: 55 % slower - every gather then touches the 8 - 9 lines of the whole row segment)
+  constexpr bool NAT = IPA_LANE_NATURAL != 0 && !HALO;
   constexpr int R = 2 * W;          // ring rows
-  constexpr int kMapOps = kTable ? 2 * NS : 0;
+  // (IPA_STEP_ORDER; not in the quad-halo geometry, whose 128 registers leave no room for it)
+#if defined(IPA_DEBUG_NO_FOOTPRINT) || defined(IPA_DEBUG_NO_FILTER)
+  constexpr bool kEarly = false;
+#else
+  constexpr bool kEarly = IPA_STEP_ORDER == 1 && !HALO;
+#endif
+  constexpr int kMapOps = kTable ? 2 * NSP : 0;
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
   const int T = nrows + K - 1;
   const unsigned lane = threadIdx.x & 63u;
   // (tables of float32 coordinates - maps - or of the 8-byte ones stored_coords.hpp keeps)
   constexpr unsigned CB = sizeof(C);
-  const unsigned voff = 16u * lane, moff = CB * lane;
+  const unsigned voff = 16u * lane, moff = NAT ? 4u * CB * lane : CB * lane;
+  auto ucol = [&](int k) -> int { return NAT ? c.uu[k] : c.uq[k]; };            // EDGE: resolved column of sample k
+  auto pxcol = [&](int k) -> int { return NAT ? 4 * (int)lane + k : (int)lane + 64 * k; };   // strip pixel of sample k
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
   const int yb = y0 - G::H;                          // first input row of the strip
   // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
@@ -726,76 +795,99 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned pitch_b = (unsigned)s.pitch << SH;
   // a lane's four values of a record array are one aligned 16-byte word (conflict-free b128)
   float* rlane = ring + 4u * lane;
-  // HALO: the halo pixel of lane j < 2H is column xs - H + halo_pos(j); the lanes' mask
+  // HALO, producer side: the halo pixel of lane j < HP is column xs - H + halo_pos(j)
   const unsigned hcol = halo_pos<G::H>(lane);
-  const unsigned long long hmask = (1ull << (2 * G::H)) - 1ull;
+  const unsigned long long pmask = (1ull << HP) - 1ull;           // the producer's halo lanes
+  const unsigned long long qmask = (1ull << (4 * HP)) - 1ull;     // the halo lanes of a row (quads)
+  // HALO, consumer side: this lane's halo pixel (lanes past the quads mirror the last one: their
+  // values are never stored) and its place in the LDS row
+  const unsigned hq = lane < 4u * HP ? lane >> 2 : (unsigned)HP - 1u;
+  const unsigned hpos = kRowPad - G::H + halo_pos<G::H>(hq);
+  // ... EDGE: its resolved column (-1: the filter's constant border supplies the pixel)
+  int uhq = 0;
+  if constexpr (HALO && EDGE) uhq = resolve_idx(c.xs - G::H + (int)halo_pos<G::H>(hq), p.dw, p.cbx);
+  // halo flags (record word 3)
+  constexpr unsigned kHTapIn = 1u, kHAnyIn = 2u, kHSlow = 4u, kHInterior = 8u;
 
   // ---- producer: this wave's row of a block.  Table sources: the 8 map dwords (clamped to the
   // strip) into pm; the record is formed when they have arrived.
-  C pm[2 * NS] = {};
+  C pm[2 * NSP] = {};
   auto issue_coords = [&](int r) {
     if constexpr (kTable) {
       if constexpr (EDGE) {
         const int rr = row_of(r < T ? r : T - 1);
         const long o = (long)(rr < 0 ? 0 : rr) * src.coord.pitch;  // scalar
 #pragma unroll
-        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], CB * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), mxr + o);
-        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), mxr + o, hmask);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[k], CB * (unsigned)(ucol(k) < 0 ? 0 : ucol(k)), mxr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), mxr + o, pmask);
 #pragma unroll
-        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[NS + k], CB * (unsigned)(c.uq[k] < 0 ? 0 : c.uq[k]), myr + o);
-        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), myr + o, hmask);
+        for (int k = 0; k < 4; k++) pipe_load1<0>(pm[NSP + k], CB * (unsigned)(ucol(k) < 0 ? 0 : ucol(k)), myr + o);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NSP + 4], CB * (unsigned)(c.uh < 0 ? 0 : c.uh), myr + o, pmask);
       } else {
         const long o = (long)(r < T ? r : T - 1) * src.coord.pitch;  // scalar
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          pipe_load1<64 * (int)CB * k>(pm[k], moff, mxr + o);
+          pipe_load1<(NAT ? 1 : 64) * (int)CB * k>(pm[k], moff, mxr + o);
         });
-        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * hcol, mxr + o - G::H, hmask);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[4], CB * hcol, mxr + o - G::H, pmask);
         static_for<0, 4>([&](auto Kk) {
           constexpr int k = decltype(Kk)::value;
-          pipe_load1<64 * (int)CB * k>(pm[NS + k], moff, myr + o);
+          pipe_load1<(NAT ? 1 : 64) * (int)CB * k>(pm[NSP + k], moff, myr + o);
         });
-        if constexpr (HALO) pipe_load1_masked<0>(pm[NS + 4], CB * hcol, myr + o - G::H, hmask);
+        if constexpr (HALO) pipe_load1_masked<0>(pm[NSP + 4], CB * hcol, myr + o - G::H, pmask);
       }
     }
   };
   auto publish = [&](int r) {   // (table sources: after a wait that covers pm)
-    C sx[NS], sy[NS];
+    C sx[NSP], sy[NSP];
     if constexpr (kTable) {
 #pragma unroll
-      for (int k = 0; k < 2 * NS; k++) vm_pin(pm[k]);
+      for (int k = 0; k < 2 * NSP; k++) vm_pin(pm[k]);
 #pragma unroll
-      for (int k = 0; k < NS; k++) { sx[k] = pm[k]; sy[k] = pm[NS + k]; }
+      for (int k = 0; k < NSP; k++) { sx[k] = pm[k]; sy[k] = pm[NSP + k]; }
     } else {
       const int rc = r < T ? r : T - 1;
       const int rr = row_of(rc);
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if constexpr (EDGE) src.coord.get(c.uq[k] < 0 ? 0 : c.uq[k], rr < 0 ? 0 : rr, sx[k], sy[k]);
-        else src.coord.get(c.xs + (int)lane + 64 * k, rr, sx[k], sy[k]);
+        if constexpr (EDGE) src.coord.get(ucol(k) < 0 ? 0 : ucol(k), rr < 0 ? 0 : rr, sx[k], sy[k]);
+        else src.coord.get(c.xs + pxcol(k), rr, sx[k], sy[k]);
       }
       if constexpr (HALO) {
         if constexpr (EDGE) src.coord.get(c.uh < 0 ? 0 : c.uh, rr < 0 ? 0 : rr, sx[4], sy[4]);
-        else src.coord.get(c.xs - G::H + (int)(lane < 2u * G::H ? hcol : (unsigned)G::H), rr, sx[4], sy[4]);
+        else src.coord.get(c.xs - G::H + (int)(lane < (unsigned)HP ? hcol : (unsigned)G::H), rr, sx[4], sy[4]);
       }
     }
-    float tx[NS], ty[NS];
-    int e[NS];
+    float tx[NSP], ty[NSP];
+    int e[NSP];
     unsigned interior;
-    batch_footprint_linear<NS, QM>(s, sx, sy, tx, ty, e, interior);
-    if constexpr (HALO) interior |= lane < 2u * G::H ? 0u : 0x10u;   // lanes without a halo pixel
-    if (s.border == IPA_BORDER_CONSTANT && __builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u))
-      interior |= border_tap_bits<NS, QM, NR == 1, C>(s, sx, sy, interior);
+    batch_footprint_linear<NSP, QM>(s, sx, sy, tx, ty, e, interior);
+    if constexpr (HALO) interior |= lane < (unsigned)HP ? 0u : 0x10u;   // lanes without a halo pixel
+    if (s.border == IPA_BORDER_CONSTANT && __builtin_amdgcn_ballot_w64(interior != (1u << NSP) - 1u))
+      interior |= border_tap_bits<NSP, QM, NR == 1, C>(s, sx, sy, interior);
     float* slot = rlane + (unsigned)(r % R) * RR;
     *reinterpret_cast<v4i*>(slot) = v4i{e[0] << SH, e[1] << SH, e[2] << SH, e[3] << SH};
     *reinterpret_cast<v4f*>(slot + 256) = v4f{tx[0], tx[1], tx[2], tx[3]};
     *reinterpret_cast<v4f*>(slot + 512) = v4f{ty[0], ty[1], ty[2], ty[3]};
     float* rowp = ring + (unsigned)(r % R) * RR;
-    reinterpret_cast<unsigned*>(rowp + 768)[lane] = interior;
+    reinterpret_cast<unsigned*>(rowp + 768)[lane] = interior & ~0x0f000010u;   // (the halo's bits stay here)
     if constexpr (HALO) {
-      reinterpret_cast<int*>(rowp + 832)[lane] = e[4] << SH;
-      rowp[896 + lane] = tx[4];
-      rowp[960 + lane] = ty[4];
+      if (lane < (unsigned)HP) {
+        const bool in4 = (interior >> 4) & 1u;
+        const unsigned vb = (interior >> 24) & 15u;   // taps of the halo footprint inside the source
+        // what the blend cannot do from the taps: the other border modes, and (packed frames) the
+        // one corner border_tap_bits leaves to sample()
+        const bool slow = !in4 && (s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow) != 0u);
+        float* hrow = rowp + 832 + 16u * lane;
+#pragma unroll
+        for (int tap = 0; tap < 4; tap++) {
+          const unsigned o = ((unsigned)e[4] << SH) + (NR == 2 ? (unsigned)(tap & 1) * 4u : 0u) +
+                             (unsigned)(tap >> 1) * pitch_b;
+          const unsigned fl = ((in4 || ((vb >> tap) & 1u)) ? kHTapIn : 0u) | ((in4 || vb) ? kHAnyIn : 0u) |
+                              (slow ? kHSlow : 0u) | (in4 ? kHInterior : 0u);
+          *reinterpret_cast<v4f*>(hrow + 4 * tap) = v4f{__uint_as_float(o), tx[4], ty[4], __uint_as_float(fl)};
+        }
+      }
     }
   };
   // ---- consumer: the footprints of ring row r
@@ -809,32 +901,42 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     off[0] = (unsigned)qo.x; off[1] = (unsigned)qo.y; off[2] = (unsigned)qo.z; off[3] = (unsigned)qo.w;
     tx[0] = qx.x; tx[1] = qx.y; tx[2] = qx.z; tx[3] = qx.w;
     ty[0] = qy.x; ty[1] = qy.y; ty[2] = qy.z; ty[3] = qy.w;
-    if constexpr (HALO) {
-      off[4] = reinterpret_cast<const unsigned*>(rowp + 832)[lane];
-      tx[4] = rowp[896 + lane];
-      ty[4] = rowp[960 + lane];
-    }
+  };
+  // ... and the halo lane's entry of it: byte offset of its tap, the fractions, the flags
+  auto halo_record = [&](int r, unsigned& off, float& tx, float& ty, unsigned& fl) {
+    const float* rowp = ring + (unsigned)(r % R) * RR;
+    const v4f q = *reinterpret_cast<const v4f*>(rowp + 832 + 4u * (lane < 4u * HP ? lane : 4u * HP - 1u));
+    off = __float_as_uint(q.x); tx = q.y; ty = q.z; fl = __float_as_uint(q.w);
   };
   // the tap row of footprint k at byte offset o -> g[NR k .. NR k + NR - 1]
   auto gather = [&](float (&g)[NS * NR], int k, unsigned o) {
+#if IPA_SHARE_TAPS == 9
+    if constexpr (NR == 2) { pipe_gather1(g[2 * k], o, rs); return; }
+#endif
     if constexpr (NR == 2) pipe_gather2(g[2 * k], g[2 * k + 1], o, rs);
     else pipe_gather1(g[k], o, rs);
   };
   auto gather_masked = [&](float (&g)[NS * NR], int k, unsigned o, unsigned long long m) {
+#if IPA_SHARE_TAPS == 9
+    if constexpr (NR == 2) { pipe_gather1_masked(g[2 * k], o, rs, m); return; }
+#endif
     if constexpr (NR == 2) pipe_gather2_masked(g[2 * k], g[2 * k + 1], o, rs, m);
     else pipe_gather1_masked(g[k], o, rs, m);
   };
   auto pin_taps = [&](float (&g)[NS * NR]) {
 #pragma unroll
-    for (int k = 0; k < NS * NR; k++) vm_pin(g[k]);
+    for (int k = 0; k < NS * NR; k++)
+      if (IPA_SHARE_TAPS != 9 || NR != 2 || (k & 1) == 0) vm_pin(g[k]);
   };
-  // a full tap row: the strip's pixels by the whole wave, the halo sample by its lanes
+  // a full tap row of the strip's pixels
   auto gather_row = [&](float (&g)[NS * NR], const unsigned (&off)[NS], unsigned add) {
 #pragma unroll
     for (int k = 0; k < 4; k++) gather(g, k, off[k] + add);
-    if constexpr (HALO) gather_masked(g, 4, off[4] + add, hmask);
   };
   auto taps_of = [&](const float (&g)[NS * NR], int k, float& v0, float& v1) {
+#if IPA_SHARE_TAPS == 9
+    if constexpr (NR == 2) { v0 = g[2 * k]; v1 = from_lane_above(v0); return; }
+#endif
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = g[2 * k + 1]; }
     else TapLoad<uint16_t, float>::unpack(__float_as_uint(g[k]), v0, v1);
   };
@@ -842,7 +944,22 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   float ga[NS * NR] = {}, gb[NS * NR] = {};    // tap rows of the footprints (see NR)
   float txa[NS], tya[NS], txb[NS], tyb[NS];
   unsigned offa[NS], offb[NS], ina, inb;
+  // HALO: the halo lane's tap dword of the row in flight / being consumed, its fractions and flags
+  float hga = 0.f, hgb = 0.f, htxa = 0.f, htya = 0.f, htxb = 0.f, htyb = 0.f;
+  unsigned hfla = 0u, hflb = 0u;
 
+#ifdef IPA_DEBUG_STAMPS   // measurement only (the first output row of a strip receives the sums)
+  // cycles (s_memtime) a wave spends per phase of a step, summed over the strip:
+  // 0 barrier, 1 wait for the gathers, 2 blend + LDS row (+ publish), 3 footprints + gather issue,
+  // 4 filter, 5 store issue, 6 the whole loop, 7 steps
+  unsigned stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned stamp_prev = 0;
+#define IPA_STAMP0() stamp_prev = (unsigned)__builtin_amdgcn_s_memtime()
+#define IPA_STAMP(i) { const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); stamp_acc[i] += now_ - stamp_prev; stamp_prev = now_; }
+#else
+#define IPA_STAMP0()
+#define IPA_STAMP(i)
+#endif
   // prologue: the records of block 0 into the ring (row `wave` by this wave), barrier, the
   // loads of block 1's row issued, row 0's gathers in flight
   issue_coords((int)wave);
@@ -853,21 +970,32 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   footprint(0, txa, tya, offa, ina);
   gather_row(ga, offa, 0u);
   gather_row(gb, offa, pitch_b);
+  if constexpr (HALO && IPA_DEBUG_HALO_LEVEL < 2) {
+    unsigned ho;
+    halo_record(0, ho, htxa, htya, hfla);
+    if (IPA_DEBUG_HALO_LEVEL < 1) pipe_gather1_masked(hga, ho, rs, qmask);
+  }
 
   // one iteration (row t, step STEP = t mod W of its block); TOP / BOT = tap-row registers of
   // row t; the bottom registers become the top registers of row t + 1
   auto step = [&](auto St, int t, float (&top)[NS * NR], float (&bot)[NS * NR], const float (&tx)[NS],
                   const float (&ty)[NS], const unsigned (&off)[NS], unsigned interior,
-                  float (&txn)[NS], float (&tyn)[NS], unsigned (&offn)[NS], unsigned& interiorn) {
+                  float (&txn)[NS], float (&tyn)[NS], unsigned (&offn)[NS], unsigned& interiorn,
+                  float& hg, float htx, float hty, unsigned hfl,
+                  float& hgn, float& htxn, float& htyn, unsigned& hfln) {
     constexpr int STEP = decltype(St)::value;
+    IPA_STAMP0();
     if constexpr (STEP == W - 1) {
       // the block's barrier: behind it the records of the next block are in the ring and nobody
       // reads this block's half any more; the next row of this wave is requested at once
 #ifndef IPA_DEBUG_NO_BARRIER   // (measurement only: racy without it)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
+      IPA_STAMP(0);
       issue_coords(t + 1 + W + (int)wave);
     }
+    // 0. the records of row t + 1: requested now, used after the blend
+    if constexpr (kEarly) footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
     // 1. the gathers of row t (and everything older): the only younger operations are the
     //    store of iteration t-1 and, on the last step of a block, the map loads above
     // (rows past the strip - the last block is filled up - store nothing either)
@@ -881,6 +1009,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     }
     pin_taps(top);
     pin_taps(bot);
+    IPA_STAMP(1);
+    if constexpr (HALO && IPA_DEBUG_HALO_LEVEL < 1) vm_pin(hg);
     if constexpr (STEP == W - 2) publish(t + 2 + (int)wave);  // (its loads: W - 1 iterations ago)
     // 2. blend (the arithmetic and order of batch_blend_one) -> LDS row, natural pixel order
     float cur[NS];
@@ -902,13 +1032,50 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       rowt = row_of(t < T ? t : T - 1);
       // positions the filter's constant border supplies
 #pragma unroll
-      for (int k = 0; k < 4; k++) cur[k] = (rowt < 0 || c.uq[k] < 0) ? src.ccval : cur[k];
-      if constexpr (HALO) cur[4] = (rowt < 0 || c.uh < 0) ? src.ccval : cur[4];
+      for (int k = 0; k < 4; k++) cur[k] = (rowt < 0 || ucol(k) < 0) ? src.ccval : cur[k];
     }
+    if constexpr (NAT) {
+      *reinterpret_cast<v4f*>(xp + kRowPad + 4u * lane) = v4f{cur[0], cur[1], cur[2], cur[3]};
+    } else {
 #pragma unroll
-    for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
-    if constexpr (HALO) {
-      if (lane < 2u * G::H) xp[kRowPad - G::H + hcol] = cur[4];
+      for (int k = 0; k < 4; k++) xp[kRowPad + 64u * k + lane] = cur[k];
+    }
+    if constexpr (HALO && IPA_DEBUG_HALO_LEVEL < 2) {
+      // the halo pixels: tap `lane & 3` of halo pixel `lane >> 2` is in hg; a tap outside the
+      // source is the border value (constant border mode; border_blend's rule), the blend takes
+      // the quad's four taps by DPP broadcasts - sample()'s arithmetic in its order
+      float v = hg;
+      if constexpr (NR == 1) {
+        float lo, hi;
+        TapLoad<uint16_t, float>::unpack(__float_as_uint(hg), lo, hi);
+        v = (lane & 1u) ? hi : lo;
+      }
+      v = (hfl & kHTapIn) ? v : src.cval;
+      const int vi = __float_as_int(v);
+      const float v00 = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x00, 0xf, 0xf, false));
+      const float v01 = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0x55, 0xf, 0xf, false));
+      const float v10 = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xaa, 0xf, 0xf, false));
+      const float v11 = __int_as_float(__builtin_amdgcn_update_dpp(vi, vi, 0xff, 0xf, 0xf, false));
+      const float wx0 = 1.f - htx, wx1 = htx, wy0 = 1.f - hty, wy1 = hty;
+      float r0 = wx0 * v00;
+      r0 = ipa_fma(wx1, v01, r0);
+      float o = wy0 * r0;
+      float r1 = wx0 * v10;
+      r1 = ipa_fma(wx1, v11, r1);
+      o = ipa_fma(wy1, r1, o);
+      o = (hfl & kHAnyIn) ? o : src.cval;
+      if (__builtin_amdgcn_ballot_w64((hfl & kHSlow) != 0u && lane < 4u * HP)) {
+        // the other border modes and the lanes border_tap_bits left to it (rare): tap by tap
+        if (hfl & kHSlow) {
+          C sx, sy;
+          const int col = c.xs - G::H + (int)halo_pos<G::H>(hq);
+          if constexpr (EDGE) src.coord.get(uhq < 0 ? 0 : uhq, rowt < 0 ? 0 : rowt, sx, sy);
+          else src.coord.get(col, yb + t, sx, sy);
+          o = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+        }
+      }
+      if constexpr (EDGE) o = (rowt < 0 || uhq < 0) ? src.ccval : o;
+      if ((lane & 3u) == 0u && lane < 4u * HP) xp[hpos] = o;
     }
     if (s.border == IPA_BORDER_CONSTANT) {
       if (__builtin_amdgcn_ballot_w64(interior != (1u << NS) - 1u)) {
@@ -923,8 +1090,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             const float o = border_blend(v00, v01, v10, v11, tx[k], ty[k], (interior >> (8 + 4 * k)) & 15u,
                                          src.cval);
             bool keep = true;   // EDGE: positions the filter's constant border supplies stay
-            if constexpr (EDGE) keep = !(rowt < 0 || (k < 4 ? c.uq[k < 4 ? k : 0] : c.uh) < 0);
-            if (keep) xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] = o;
+            if constexpr (EDGE) keep = !(rowt < 0 || ucol(k) < 0);
+            if (keep) xp[kRowPad + (unsigned)pxcol(k)] = o;
           }
         }
       }
@@ -939,8 +1106,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
         if (!((interior >> k) & 1u) && (s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow))) {
           C sx, sy;
           // pixel column of sample k and its place in the LDS row
-          const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
-          const unsigned pos = k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol;
+          const int col = c.xs + pxcol(k);
+          const unsigned pos = kRowPad + (unsigned)pxcol(k);
           if constexpr (EDGE) {
             // (the column is resolved again: c.uq[k] with a run-time k would live in scratch)
             const int uqk = resolve_idx(col, p.dw, p.cbx);
@@ -953,6 +1120,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
         }
       }
     }
+    IPA_STAMP(2);
     // 3. row t + 1: footprints from the ring, its top tap row into `bot` for the lanes whose
     //    footprint did not move straight down (no instruction at all when there is none), its
     //    bottom row into `top`
@@ -961,8 +1129,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     for (int k = 0; k < NS; k++) { txn[k] = tx[k]; tyn[k] = ty[k]; offn[k] = off[k] + pitch_b; }
     interiorn = (1u << NS) - 1u;
 #else
-    footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
+    if constexpr (!kEarly) footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
 #endif
+    if constexpr (kEarly) {
+      // (the sample row is complete: its windows are requested before the gathers go out)
+      __builtin_amdgcn_wave_barrier();
+      filt.load(xp, lane);
+    }
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #if IPA_PIPE_REUSE
@@ -977,26 +1150,41 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       }
       unsigned long long need =
           __builtin_amdgcn_ballot_w64(offn[k] != off[k] + pitch_b && !stay);
-      if (k == 4) need &= hmask;
       if (need) gather_masked(bot, k, offn[k], need);
 #else
-      if (k < 4) gather(bot, k, offn[k]);
-      else gather_masked(bot, k, offn[k], hmask);
+      gather(bot, k, offn[k]);
 #endif
     }
     gather_row(top, offn, pitch_b);
+    if constexpr (HALO && IPA_DEBUG_HALO_LEVEL < 2) {
+      unsigned ho;
+      halo_record(t + 1 < T ? t + 1 : T - 1, ho, htxn, htyn, hfln);
+      if (IPA_DEBUG_HALO_LEVEL < 1) pipe_gather1_masked(hgn, ho, rs, qmask);
+      else hgn = __uint_as_float(ho | 0x3f000000u);
+    }
     __builtin_amdgcn_wave_barrier();
+    IPA_STAMP(3);
     // 4. filter + store
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
     const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
 #else
-    const v4f q = filt.template row<EDGE>(xp, lane, c);
+    v4f q;
+    if constexpr (kEarly) q = filt.template sums<EDGE>(c);
+    else q = filt.template row<EDGE>(xp, lane, c);
 #endif
     const int o = t - (K - 1);
+#ifdef IPA_DEBUG_STAMPS
+    { float qx = q.x; asm volatile("" : "+v"(qx)); }   // (the filter's result is due here)
+#endif
+    IPA_STAMP(4);
     if (o >= 0 && o < nrows) {
       if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
     }
     __builtin_amdgcn_wave_barrier();
+    IPA_STAMP(5);
+#ifdef IPA_DEBUG_STAMPS
+    stamp_acc[7] += 1;
+#endif
   };
 
   // the loop body is one block (W steps: the tap registers swap roles every step, W is even);
@@ -1007,11 +1195,24 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   do {
     static_for<0, W>([&](auto St) {
       constexpr int st = decltype(St)::value;
-      if constexpr (st % 2 == 0) step(St, tb + st, ga, gb, txa, tya, offa, ina, txb, tyb, offb, inb);
-      else step(St, tb + st, gb, ga, txb, tyb, offb, inb, txa, tya, offa, ina);
+      if constexpr (st % 2 == 0)
+        step(St, tb + st, ga, gb, txa, tya, offa, ina, txb, tyb, offb, inb, hga, htxa, htya, hfla, hgb, htxb, htyb, hflb);
+      else
+        step(St, tb + st, gb, ga, txb, tyb, offb, inb, txa, tya, offa, ina, hgb, htxb, htyb, hflb, hga, htxa, htya, hfla);
     });
     tb += W;
   } while (tb < Tb);
+#ifdef IPA_DEBUG_STAMPS
+  stamp_acc[6] = stamp_acc[0] + stamp_acc[1] + stamp_acc[2] + stamp_acc[3] + stamp_acc[4] + stamp_acc[5];
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!EDGE) {
+    float* o0 = outs + 4u * lane;
+    if (lane == 1) *reinterpret_cast<v4f*>(o0) = v4f{(float)stamp_acc[0], (float)stamp_acc[1], (float)stamp_acc[2], (float)stamp_acc[3]};
+    if (lane == 2) *reinterpret_cast<v4f*>(o0) = v4f{(float)stamp_acc[4], (float)stamp_acc[5], (float)stamp_acc[6], (float)stamp_acc[7]};
+  }
+#endif
+#undef IPA_STAMP0
+#undef IPA_STAMP
 }
 
 }  // namespace ipa

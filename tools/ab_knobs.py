@@ -122,6 +122,22 @@ def main():
             v = res[(name, c)]
             print('%-8s %-10s %-40s %s   min %.4f' % (c, name, knobs, '  '.join('%.4f' % x for x in v),
                                                       min(v)))
+    # the results of every knob set against the first one, bit for bit (last frame of the batch)
+    for c in what:
+        if c == 'copy':
+            continue
+        ref = None
+        for name, knobs in sets:
+            ctx.set_tuning(**base)
+            ctx.set_tuning(**knobs)
+            calls[c]()
+            got = dst.frame(batch - 1).get() if batch > 1 else dst.get()
+            if ref is None:
+                ref = got
+            same = np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+            print('%-8s %-10s %s' % (c, name, 'identical bits' if same else 'DIFFERS from %s (max |d| %.3g, %d px)'
+                                     % (sets[0][0], np.nanmax(np.abs(got - ref)), int((got != ref).sum()))))
+    ctx.set_tuning(**base)
 
 
 if __name__ == '__main__':

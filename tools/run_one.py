@@ -57,6 +57,10 @@ def main():
             ops.warp_perspective(src, H, (h, w), interpolation='cubic', out=dst)
         elif case.startswith('rot'):
             ops.warp_perspective(src, H, (h, w), interpolation=interp, out=dst)
+        elif case == 'conv5':
+            ops.conv2d(src, k5, out=dst)
+        elif case == 'copy':
+            dst.copy_from(src)
         elif case == 'lanczos_h':
             ops.warp_perspective(src, H, (h, w), interpolation='lanczos4', out=dst)
         elif analytic:
