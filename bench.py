@@ -374,6 +374,13 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     return out
 
 
+def self_launch_cmd(n_gpus, argv, port):
+    """the command a bare `python bench.py --gpus N` (N > 1, no launcher around it) runs as a child:
+    the driver's own launch line, one rank per GPU, rendezvous on 127.0.0.1"""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -390,17 +397,32 @@ def main():
     ap.add_argument('--width', type=int, default=W4K)
     ap.add_argument('--no-cpu', action='store_true', help='skip the cpu_baseline leg')
     ap.add_argument('--placements', type=int, default=0,
-                    help='candidate allocations per large block of the context pool (0 = the '
-                         "library's default, IMGPROC_HIP_PLACE; 1 = every allocation as it comes)")
+                    help="candidate allocations per large block of the context pool (0 = the library's "
+                         'default: IMGPROC_HIP_PLACE, 1 = every allocation as it comes; 2 = the better of two)')
     ap.add_argument('--no-settle', action='store_true',
                     help='skip the untimed clock-settling launches of the setup phase')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other_configs leg (BASELINE configurations C2..C5)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # --gpus N without a launcher: this process becomes the launcher.  It has not touched the
+        # GPU (no HIP call, not even a device count), starts the N ranks as CHILD processes through
+        # torch.distributed.run - one rank per GPU, rank r on device r modulo the devices the box
+        # has - and ends with their exit code; rank 0's JSON line passes through.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        sys.exit(subprocess.call(self_launch_cmd(args.gpus, sys.argv[1:], port)))
+
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d: the line below is a %d-rank measurement'
+              % (args.gpus, world, world), file=sys.stderr)
     dist_on = world > 1
     if dist_on:
         import torch
@@ -426,29 +448,37 @@ def main():
     ndev = ia.device_count()
     ctx = ia.Context(local_rank % max(ndev, 1))
     if args.placements > 0:
-        ctx._place_n = args.placements
+        ctx._place_n = min(2, args.placements)
     h, w, B = args.height, args.width, args.batch
     K, dcoef = camera(h, w)
     k5 = gauss5()
 
     # per-rank batch: distinct frames, resident in HBM before the timed region
     frames = synth_frames(B, h, w, seed0=rank * B)
-    d_src = ctx.to_device(frames)
+    d_src = ctx.empty((B, h, w), np.float32)
     d_dst = ctx.empty((B, h, w), np.float32)
     d_tmp = ctx.empty((B, h, w), np.float32) if args.variant.startswith('two') else None
+    # WHERE in the device memory a 2 GB batch buffer lies moves this streaming kernel by up to 10 %
+    # on this part - a property of physical regions of the HBM that no caller can choose
+    # (profiles/r05_micro.txt).  The buffers above are taken as the driver
+    # hands them out (the library's default since round 5; --placements 2 / IMGPROC_HIP_PLACE=2:
+    # the better of two allocations, logged below).  What class this run drew is reported, not
+    # chosen: the pool's strip-shaped probe (a plain 3x3 filter from one half of the block into
+    # the other) on both buffers before the frames go in - ~0.377 ms: the fast class of a 2 GiB
+    # block, ~0.39: the middle one, ~0.425: the slow one.
+    probe_ms = {'source': round(ctx._probe_block(d_src.ptr, d_src.nbytes), 4),
+                'result': round(ctx._probe_block(d_dst.ptr, d_dst.nbytes), 4)}
+    d_src.set(frames)
     dmx, dmy = ops.build_undistort_map(K, dcoef, K, h, w, ctx=ctx, device=True)
     ctx.synchronize()
-    # WHERE a 2 GB batch buffer lands in physical memory moves this streaming kernel by up to 10 %
-    # on this part (a property of the allocation: profiles/r04_micro.txt).  Since round 4 the
-    # PRODUCT deals with it: the context's block pool chooses every block of 256 MiB and more
-    # among up to IMGPROC_HIP_PLACE candidate allocations (default 24; fewer once one of the fast
-    # class has shown up) by a strip-shaped probe, once per
-    # block (device.py::_alloc_placed) - d_src / d_dst above were allocated that way, exactly as a
-    # caller's arrays are, and `config.buffer_placement` is the pool's own log.  --placements N
-    # overrides the candidate count for this run (1 = every allocation as it comes).
-    placement = {'by': 'Context block pool (product default: up to IMGPROC_HIP_PLACE=%d candidates per block '
-                       '>= 256 MiB, strip-shaped 3x3 probe, drawing stops at the first of the fast class)' % ctx._place_n,
-                 'candidates': ctx._place_n, 'blocks': list(ctx.placement_log)}
+    placement = {'by': 'none: every buffer as the driver hands it out (library default)' if ctx._place_n <= 1 else
+                       'Context block pool, opt-in: the better of two allocations per block >= 256 MiB by a '
+                       'strip-shaped 3x3 probe, at most one extra block held',
+                 'candidates': ctx._place_n, 'blocks': list(ctx.placement_log),
+                 'class_probe_ms': probe_ms,
+                 'class_probe_note': '3x3 filter from one half of the block into the other; 2 GiB blocks: ~0.377 fast, '
+                                     '~0.39 middle, ~0.425 slow class (the headline launch on pairs of them: '
+                                     '0.95 / 1.04 / 1.09 ms)'}
 
     px = B * h * w
     # bytes per launch.  `compulsory`: what must cross the HBM interface - source and result

@@ -32,6 +32,7 @@ PROTOTYPES = {
     'ipa_ctx_set_tuning': [_vp, C.c_char_p, _i],
     'ipa_ctx_get_tuning': [_vp, C.c_char_p, C.POINTER(_i)],
     'ipa_ctx_device_info': [_vp, C.c_char_p, _sz, C.POINTER(_i), C.POINTER(_sz)],
+    'ipa_mem_info': [_vp, C.POINTER(_sz), C.POINTER(_sz)],
     'ipa_malloc': [_vp, _sz, C.POINTER(_vp)],
     'ipa_free': [_vp, _vp],
     'ipa_host_alloc': [_vp, _sz, C.POINTER(_vp)],

@@ -32,8 +32,6 @@ struct ipa_tuning {
   int pipe = 1;           // 0: no strip on the hand-scheduled loops of wave_pipe.hpp (hand-counted vmcnt
                           // waits) - the compiler-scheduled chunked loops everywhere: the fallback
                           // and cross-check of that scheme (same bits, slower)
-  int halo_shared = 0;    // batches on the shared-record loop: aligned 256-px strips, halo pixels sampled by quads
-                          // of lanes (round 5); 0: the overlapping 248-px strips of rounds 3 - 4
   int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
   int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
                           // XCD streaming through frames of its own

@@ -110,22 +110,6 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   s.border = f.border; s.q5 = f.q5; s.cubic_a = f.cubic_a; s.lanczos = nullptr;
   s.cval = (float)f.cval; s.ccval = (float)f.conv_cval; s.map_vec = f.map_vec;
   WaveParams p = f.p;
-  // batches on the shared-record loop: the flavour on 256-px aligned strips (whole 128-byte lines
-  // stored, 15 strips per 4K row instead of 16), halo pixels sampled by quads of lanes
-  if constexpr (halo_shared<Src, K>::value) {
-    if (ctx->tune.halo_shared != 0 && ctx->tune.pipe != 0 && fused_strip_piped<Src, K>(ctx, f.n_frames) == 2) {
-      using GH = wave_geom<K, true>;
-      p.strips_x = (p.dw + GH::OW - 1) / GH::OW;
-      p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false, 2);
-      p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-      dim3 gridh = wave_grid(ctx, p, f.n_frames, IPA_WPB, true, true);
-      if (p.frames_wg) {
-        hipLaunchKernelGGL((wave_stencil_kernel<Src, K, true>), gridh, dim3(64 * IPA_WPB), 0, ctx->stream, p, s, w);
-        return;
-      }
-      p = f.p;
-    }
-  }
   using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false,

@@ -70,7 +70,6 @@ const TuneName kTuneNames[] = {
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
-    {"halo_shared", "IPA_HALO_SHARED", &ipa_tuning::halo_shared},
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };
@@ -194,6 +193,13 @@ int ipa_ctx_device_info(ipa_ctx* c, char* name, size_t name_len, int* cu_count,
   }
   if (cu_count) *cu_count = prop.multiProcessorCount;
   if (total_mem) *total_mem = prop.totalGlobalMem;
+  return IPA_OK;
+}
+
+int ipa_mem_info(ipa_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+  if (!c || !free_bytes || !total_bytes) return IPA_ERR_BAD_ARG;
+  IPA_HIP(c, hipSetDevice(c->device));
+  IPA_HIP(c, hipMemGetInfo(free_bytes, total_bytes));
   return IPA_OK;
 }
 

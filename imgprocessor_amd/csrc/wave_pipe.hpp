@@ -58,12 +58,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #ifndef IPA_DEBUG_HALO_LEVEL
 #define IPA_DEBUG_HALO_LEVEL 0   // measurement only (WRONG results): 1 = no halo gathers, 2 = no halo work at all
 #endif
-#ifndef IPA_STEP_ORDER
-#define IPA_STEP_ORDER 1   // shared-record loop: 1 = the records of row t + 1 are requested from LDS at the top of
-                           // step t and the filter's windows right behind the sample row, both BEFORE the
-                           // gathers of row t + 1 are issued (their LDS latency under the blend / the gather
-                           // issue); 0 = rounds 3 - 4: records, gathers, then windows
-#endif
 #ifndef IPA_LANE_NATURAL
 #define IPA_LANE_NATURAL 0   // shared-record loop: sample k of lane L is strip pixel 4 L + k instead of L + 64 k
 #endif
@@ -202,30 +196,16 @@ __device__ __forceinline__ void pipe_gather2_masked(float& a, float& b, unsigned
 
 // ------------------------------------------------------------------ the K x K row step --
 // sample row (LDS, natural pixel order) -> the K running rows; returns the completed row
-// (in two halves, so that a caller can put other work between the LDS reads and their use)
-template <int K>
-__device__ __forceinline__ void pipe_filter_load(const float* xp, unsigned lane, unsigned lane4_opaque,
-                                                 v2f (&pair)[K + 2]) {
-  using G = wave_geom<K>;
-  const float* wp = xp + kRowPad - G::H + 4u * lane;
-  const float* wq = xp + kRowPad - G::H + lane4_opaque;
-#pragma unroll
-  for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
-}
-template <int K>
-__device__ __forceinline__ v4f pipe_filter_sums(const Weights<float, K * K>& wts, const v2f (&pair)[K + 2],
-                                                v2f (&acc)[K][2]);
 template <int K>
 __device__ __forceinline__ v4f pipe_filter_row(const Weights<float, K * K>& wts, const float* xp,
                                                unsigned lane, unsigned lane4_opaque,
                                                v2f (&acc)[K][2]) {
+  using G = wave_geom<K>;
+  const float* wp = xp + kRowPad - G::H + 4u * lane;
+  const float* wq = xp + kRowPad - G::H + lane4_opaque;
   v2f pair[K + 2];
-  pipe_filter_load<K>(xp, lane, lane4_opaque, pair);
-  return pipe_filter_sums<K>(wts, pair, acc);
-}
-template <int K>
-__device__ __forceinline__ v4f pipe_filter_sums(const Weights<float, K * K>& wts, const v2f (&pair)[K + 2],
-                                                v2f (&acc)[K][2]) {
+#pragma unroll
+  for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
   // coefficient n = i K + j is one half of the SGPR pair {w[n & ~1], w[(n & ~1) + 1]}, broadcast
   // by op_sel: K K / 2 scalar pairs instead of the K K {w, w} pairs the compiler forms (which
   // spill to VGPR lanes: 45 v_readlane per row in the first build of this loop)
@@ -370,12 +350,6 @@ template <typename Coord, int K> struct pipe_unshared<SampleRowSrc<float, kLinea
 #ifndef IPA_HALO_SAMPLE
 #define IPA_HALO_SAMPLE 0
 #endif
-// sampling kernels with a second flavour on 256-px ALIGNED strips (round 5): the shared-record loop
-// with the halo pixels sampled by quads of lanes (wave_run_strip_shared, HALO).  Launched for the
-// batches that run that loop (frames_wg); knob halo_shared
-template <typename Src, int K> struct halo_shared {
-  static constexpr bool value = (IPA_PIPE != 0) && (IPA_PIPE_SHARED != 0) && shared_capable<Src, K>::value && K <= 7;
-};
 template <typename Src, int K, bool STREAM> struct geom_halo {
   static constexpr bool value = (IPA_PIPE != 0) && (IPA_HALO != 0) && !STREAM && K <= 9 &&
                                 pipe_capable<Src, K>::value && (IPA_HALO_SAMPLE != 0 || !Src::kHasQ5);
@@ -710,14 +684,6 @@ template <int K> struct DenseFilter {
   template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols&) {
     return pipe_filter_row<K>(wts, xp, lane, lane4_opaque, acc);
   }
-  // the same in two halves: the windows out of the LDS row, later the sums
-  v2f pair[K + 2];
-  __device__ __forceinline__ void load(const float* xp, unsigned lane) {
-    pipe_filter_load<K>(xp, lane, lane4_opaque, pair);
-  }
-  template <bool EDGE> __device__ __forceinline__ v4f sums(const Cols&) {
-    return pipe_filter_sums<K>(wts, pair, acc);
-  }
 };
 
 template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord>
@@ -758,12 +724,6 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   // only: 55 % slower - every gather then touches the 8 - 9 lines of the whole row segment)
   constexpr bool NAT = IPA_LANE_NATURAL != 0 && !HALO;
   constexpr int R = 2 * W;          // ring rows
-  // (IPA_STEP_ORDER; not in the quad-halo geometry, whose 128 registers leave no room for it)
-#if defined(IPA_DEBUG_NO_FOOTPRINT) || defined(IPA_DEBUG_NO_FILTER)
-  constexpr bool kEarly = false;
-#else
-  constexpr bool kEarly = IPA_STEP_ORDER == 1 && !HALO;
-#endif
   constexpr int kMapOps = kTable ? 2 * NSP : 0;
   static_assert(W == 2 || W == 4 || W == 8, "steps of a block alternate the tap-register roles");
   const int T = nrows + K - 1;
@@ -994,8 +954,6 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       IPA_STAMP(0);
       issue_coords(t + 1 + W + (int)wave);
     }
-    // 0. the records of row t + 1: requested now, used after the blend
-    if constexpr (kEarly) footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
     // 1. the gathers of row t (and everything older): the only younger operations are the
     //    store of iteration t-1 and, on the last step of a block, the map loads above
     // (rows past the strip - the last block is filled up - store nothing either)
@@ -1129,13 +1087,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     for (int k = 0; k < NS; k++) { txn[k] = tx[k]; tyn[k] = ty[k]; offn[k] = off[k] + pitch_b; }
     interiorn = (1u << NS) - 1u;
 #else
-    if constexpr (!kEarly) footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
+    footprint(t + 1 < T ? t + 1 : T - 1, txn, tyn, offn, interiorn);
 #endif
-    if constexpr (kEarly) {
-      // (the sample row is complete: its windows are requested before the gathers go out)
-      __builtin_amdgcn_wave_barrier();
-      filt.load(xp, lane);
-    }
 #pragma unroll
     for (int k = 0; k < NS; k++) {
 #if IPA_PIPE_REUSE
@@ -1168,9 +1121,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #ifdef IPA_DEBUG_NO_FILTER   // measurement only (WRONG results): the sample row goes straight out
     const v4f q = *reinterpret_cast<const v4f*>(xp + kRowPad + 4u * lane);
 #else
-    v4f q;
-    if constexpr (kEarly) q = filt.template sums<EDGE>(c);
-    else q = filt.template row<EDGE>(xp, lane, c);
+    const v4f q = filt.template row<EDGE>(xp, lane, c);
 #endif
     const int o = t - (K - 1);
 #ifdef IPA_DEBUG_STAMPS

@@ -139,18 +139,9 @@ template <int K> struct SepFilter {
   float xcval;
   float acc[K][4];
   __device__ __forceinline__ SepFilter(const SepTaps<K>& taps, float xc) : w(taps), xcval(xc) {}
-  // in two halves (wave_run_strip_shared puts the gather issue between them): the lane's four
-  // samples out of the LDS row, later the two passes
-  float4 q;
-  __device__ __forceinline__ void load(const float* xp, unsigned lane) {
-    q = *reinterpret_cast<const float4*>(xp + kRowPad + 4u * lane);
-  }
   template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols& c) {
-    load(xp, lane);
-    return sums<EDGE>(c);
-  }
-  template <bool EDGE> __device__ __forceinline__ v4f sums(const Cols& c) {
     constexpr int H = K / 2;
+    const float4 q = *reinterpret_cast<const float4*>(xp + kRowPad + 4u * lane);
     const float cur[4] = {q.x, q.y, q.z, q.w};
     static_for<0, K>([&](auto Ii) {
       constexpr int i = K - 1 - decltype(Ii)::value;

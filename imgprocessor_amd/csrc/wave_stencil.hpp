@@ -638,13 +638,11 @@ namespace ipa {
 #ifndef IPA_WAVE_MIN_WAVES
 #define IPA_WAVE_MIN_WAVES 1
 #endif
-template <typename Src, int K, bool STREAM = false, bool HS = false>
+template <typename Src, int K, bool STREAM = false>
 __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
                                                   const Weights<float, K * K>& wts,
                                                   kernarg_f32 wk) {
-  // HS: the flavour on aligned 256-px strips whose batches run the shared-record loop with the
-  // halo pixels sampled by quads of lanes (wave_pipe.hpp); launched with p.frames_wg only
-  constexpr bool HALO = HS || geom_halo<Src, K, STREAM>::value;
+  constexpr bool HALO = geom_halo<Src, K, STREAM>::value;
   using G = wave_geom<K, HALO>;
   constexpr int D = Src::template depth<K>::value;
   const int lane = threadIdx.x & 63;
@@ -703,7 +701,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   const bool fast = !p.no_pipe && src.vectors_ok() && p.vec_out && xs - hx >= 0 &&
                     xs + 256 + hx <= p.dw && y0 - G::H >= 0 && y0 - G::H + rows_touched <= p.dh;
   if (fast && p.rim_only) return;
-  if (fast && (!HS || p.frames_wg)) {
+  if (fast) {
 #pragma unroll
     for (int k = 0; k < 4; k++) c.uu[k] = c.xo + k;
     if constexpr (kShared) {
@@ -715,9 +713,7 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
         return;
       }
     }
-    if constexpr (HS) {
-      // (not reached: a launch of this flavour has p.frames_wg set)
-    } else if constexpr (IPA_PIPE && !STREAM && pipe_unshared<Src, K>::value) {
+    if constexpr (IPA_PIPE && !STREAM && pipe_unshared<Src, K>::value) {
       if constexpr (Src::kHasQ5) {
         if (src.q5) wave_run_strip_pipe<K, 1, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
         else wave_run_strip_pipe<K, 0, HALO>(p, src, wts, xp, c, y0, nrows, writer, dst);
@@ -765,10 +761,10 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
 template <typename Src, int K> struct wave_min_waves {
   static constexpr int value = (pipe_capable<Src, K>::value && Src::kHasQ5 && IPA_PIPE && K <= 5) ? IPA_PIPE_MIN_WAVES : IPA_WAVE_MIN_WAVES;   // (7x7: 46 filter registers more - no cap, no spills)
 };
-template <typename Src, int K, bool HS = false>
+template <typename Src, int K>
 __global__ void __launch_bounds__(64 * IPA_WPB, (wave_min_waves<Src, K>::value))
 wave_stencil_kernel(WaveParams p, Src src, Weights<float, K * K> wts) {
-  wave_stencil_body<Src, K, false, HS>(p, src, wts, nullptr);
+  wave_stencil_body<Src, K>(p, src, wts, nullptr);
 }
 
 // K = 9, 11: one argument struct, so that the coefficients' place in the kernel-argument

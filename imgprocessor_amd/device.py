@@ -42,24 +42,28 @@ class Context(object):
         self._pool_bytes = 0
         self._pool_limit = int(os.environ.get('IMGPROC_HIP_POOL_MB', '8192')) << 20
         self._pool_lock = threading.Lock()
-        # Placement of large blocks (round 4).  WHERE the driver puts a multi-GB batch buffer moves
-        # the strip-shaped streaming kernels of this library by up to 10 % on MI355X - a property
-        # of the allocation, not of the address inside it (profiles/r04_micro.txt: one offset is
-        # as good as another within an allocation; a linear copy does not see it at all; a plain
-        # 3x3 filter from one half of the block into the other does, and ranks the blocks like the
-        # fused kernel).  The fresh 2 GiB allocations of a process fall into three classes by that
-        # probe (tools/placement_classes.py, 40 held at once: 8 at 0.377 ms, 8 at 0.391, 24 at 0.423;
-        # the headline launch on pairs of them 0.95 - 0.98 / 1.04 / 1.09 ms).  So a block of
-        # >= 256 MiB that the pool cannot serve is chosen among up to IMGPROC_HIP_PLACE candidate
-        # allocations (default 24, at most 64 GiB of candidates at a time; 1 = take the first) by
-        # that probe - ~3 ms per candidate of 2 GiB, once per block, the pool hands it out again
-        # afterwards - and the drawing stops early once a candidate of the fast class has shown up
-        # (>= 6 drawn and the best 9.5 % under their median).
-        self._place_n = max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '24')))
-        self._place_bytes = 64 << 30
+        # Placement of large blocks: OPT-IN since round 5 (IMGPROC_HIP_PLACE=2; default 1 = off).
+        # WHERE in the device memory a multi-GB batch buffer lies moves the strip-shaped streaming
+        # kernels of this library by up to 10 % on MI355X (64 x 4K undistort + 5x5: 0.95 - 1.09 ms).
+        # Round 5 (profiles/r05_micro.txt) narrowed it down to a property of physical REGIONS of the
+        # HBM, 16 - 32 GB each - fresh allocations of one process fall into their classes in runs of
+        # 8 - 16 in allocation order; padding the frame stride / the pitch, the distance between the
+        # source and the result, and the way the buffer is put together from physical chunks
+        # (hipMemCreate / hipMemMap) do not move a block out of its class; a linear copy does not see
+        # the classes at all.  A caller cannot choose the region; what it can do is take the better
+        # of TWO allocations by the probe below (`_probe_block`: a plain 3x3 filter from one half of
+        # the block into the other, ~3 ms per 2 GiB) - with the hard limits that no more than one
+        # extra block of the requested size is ever held (2 x the requested bytes in all) and that
+        # the extra block fits into a quarter of the device's free memory.  Rounds 3 - 4 drew up to
+        # 24 candidates (64 GiB held at once) by default: reliable it was not (the runs are longer
+        # than that), and a library that allocates 24 x what it was asked for is no design.
+        self._place_n = min(2, max(1, int(os.environ.get('IMGPROC_HIP_PLACE', '1'))))
         self._place_min = 256 << 20
         self._place_max = 16 << 30
-        self._placing = False
+        self._place_tls = threading.local()   # .active: this thread is choosing a block right now
+        self._placed_ptrs = set()             # blocks the probe chose
+        self._no_place_sizes = set()          # sizes whose placed block went back to the driver: a caller
+                                              # that cycles through such blocks does not pay the probe again
         self.placement_log = []   # one entry per placed block: nbytes, probe ms per candidate, kept
 
     # -- info -------------------------------------------------------------
@@ -79,7 +83,7 @@ class Context(object):
 
     # -- launch-shape knobs ----------------------------
     def set_tuning(self, **knobs):
-        """e.g. ctx.set_tuning(strip_h=48, group=0); returns the previous values"""
+        """e.g. ctx.set_tuning(strip_h=48, frames_wg=0); returns the previous values"""
         old = {k: self.get_tuning(k) for k in knobs}
         for k, v in knobs.items():
             self._check(self._lib.ipa_ctx_set_tuning(self.handle, k.encode(), int(v)),
@@ -100,48 +104,60 @@ class Context(object):
             if blocks:
                 self._pool_bytes -= nbytes
                 return blocks.pop()
-        if (self._place_n > 1 and not self._placing and
-                self._place_min <= nbytes <= self._place_max):
+        if (self._place_n > 1 and not getattr(self._place_tls, 'active', False) and
+                self._place_min <= nbytes <= self._place_max and nbytes not in self._no_place_sizes):
             return self._alloc_placed(nbytes)
         return self._alloc_raw(nbytes)
 
-    def _alloc_raw(self, nbytes):
+    def _alloc_raw(self, nbytes, trim=True):
         p = C.c_void_p()
         try:
             self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
         except MemoryError:
+            if not trim:
+                raise
             self.trim()  # give the pooled blocks back and retry once
             self._check(self._lib.ipa_malloc(self.handle, nbytes, C.byref(p)), 'ipa_malloc')
         return p
 
+    def mem_info(self):
+        """(free, total) bytes of the context's device"""
+        free, total = C.c_size_t(), C.c_size_t()
+        self._check(self._lib.ipa_mem_info(self.handle, C.byref(free), C.byref(total)), 'mem_info')
+        return free.value, total.value
+
     def _alloc_placed(self, nbytes):
-        """the best of up to `_place_n` allocations of `nbytes` by `_probe_block` (fewer when one of
-        the fast class shows up early); the others go back to the driver (all candidates are
-        held until the choice is made: a freed one would be handed out again)"""
-        self._placing = True
+        """the better of two allocations of `nbytes` by `_probe_block`.  Never more than one extra
+        block is held (and none when it would take more than a quarter of the free device memory);
+        whatever is not returned goes back to the driver, also when a probe raises; a failed
+        candidate allocation leaves the block pool alone.  (The block pool hands a placed block out
+        again; once one had to go back to the driver - larger than the pool's limit - its size is
+        not placed a second time.)"""
+        self._place_tls.active = True
+        first = extra = keep = None
         try:
-            cands, times = [], []
-            for _ in range(max(1, min(self._place_n, self._place_bytes // nbytes))):
-                try:
-                    p = self._alloc_raw(nbytes)
-                except MemoryError:
-                    if not cands:
-                        raise
-                    break   # out of device memory: choose among what there is
-                cands.append(p)
-                times.append(self._probe_block(p, nbytes))
-                if len(times) >= 6 and min(times) <= 0.905 * float(np.median(times)):
-                    break   # one of the fast class is among them
-            best = int(np.argmin(times))
+            first = self._alloc_raw(nbytes)
+            times = [self._probe_block(first, nbytes)]
+            keep = first
+            try:
+                if nbytes <= self.mem_info()[0] // 4:
+                    extra = self._alloc_raw(nbytes, trim=False)
+            except MemoryError:
+                extra = None
+            if extra is not None:
+                times.append(self._probe_block(extra, nbytes))
+                if times[1] < times[0]:
+                    keep = extra
             self.synchronize()
-            for i, p in enumerate(cands):
-                if i != best:
-                    self._lib.ipa_free(self.handle, p)
+            self._placed_ptrs.add(keep.value)
             self.placement_log.append({'nbytes': int(nbytes), 'ms': [round(t, 4) for t in times],
-                                       'kept': best})
-            return cands[best]
+                                       'kept': 0 if keep is first else 1})
+            return keep
         finally:
-            self._placing = False
+            self._place_tls.active = False
+            for p in (first, extra):
+                if p is not None and p is not keep:
+                    self._lib.ipa_free(self.handle, p)
 
     def _probe_block(self, ptr, nbytes):
         """milliseconds of a plain 3x3 filter streaming the first half of the block into the
@@ -178,6 +194,9 @@ class Context(object):
                 self._pool.setdefault(nbytes, []).append(ptr)
                 self._pool_bytes += nbytes
                 return
+        if ptr.value in self._placed_ptrs:
+            self._placed_ptrs.discard(ptr.value)
+            self._no_place_sizes.add(nbytes)
         self._lib.ipa_free(self.handle, ptr)
 
     def trim(self):
@@ -187,6 +206,7 @@ class Context(object):
             self._pool.clear()
             self._pool_bytes = 0
         for p in blocks:
+            self._placed_ptrs.discard(p.value)
             self._lib.ipa_free(self.handle, p)
 
     def empty(self, shape, dtype):

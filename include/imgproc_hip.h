@@ -95,6 +95,10 @@ int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value);
 /* name (e.g. "gfx950...") and compute-unit count of the context's device */
 int ipa_ctx_device_info(ipa_ctx* ctx, char* name, size_t name_len, int* cu_count,
                         size_t* total_mem_bytes);
+/* free and total bytes of the context's device right now (hipMemGetInfo): what the Python layer's
+ * block pool bounds its optional second candidate allocation by (imgprocessor_amd/device.py; the
+ * reference has no device memory - this is library plumbing, not a reference call site) */
+int ipa_mem_info(ipa_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 
 /* device / pinned-host memory owned by the caller until freed */
 int ipa_malloc(ipa_ctx* ctx, size_t bytes, void** dptr);

@@ -318,6 +318,38 @@ def test_two_rank_partition_gloo(tmp_path):
     assert res['cover'] == [1] * 37
 
 
+def test_bench_gpus_n_means_n(tmp_path):
+    """`python bench.py --gpus N` without a launcher around it starts the N ranks itself (review
+    item 6 of round 4: it used to measure one GPU and print n_gpus 1): the child command is the
+    driver's own launch line, and the parent hands its arguments through and ends with the
+    children's exit code - checked with a stand-in for the Python interpreter that records how it
+    was called (no GPU here: the ranks themselves cannot run)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.self_launch_cmd(4, ['--gpus', '4', '--steps', '7'], 29555)
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '4'
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[cmd.index('--master-port') + 1] == '29555'
+    assert cmd[-5:] == [os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '7']
+    # the parent: a fake interpreter in place of sys.executable
+    fake = tmp_path / 'fakepython'
+    log = tmp_path / 'called.txt'
+    fake.write_text('#!/bin/sh\necho "$@" > %s\nexit 7\n' % log)
+    fake.chmod(0o755)
+    code = ('import sys, runpy; sys.executable = %r; sys.argv = [%r, "--gpus", "2", "--steps", "3"]; '
+            'runpy.run_path(%r, run_name="__main__")' % (str(fake), os.path.join(ROOT, 'bench.py'),
+                                                         os.path.join(ROOT, 'bench.py')))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, timeout=120)
+    assert r.returncode == 7, r.stderr.decode()[-2000:]
+    called = log.read_text().split()
+    assert called[:2] == ['-m', 'torch.distributed.run'] and '--nproc-per-node' in called
+    assert called[called.index('--nproc-per-node') + 1] == '2' and called[-4:] == ['--gpus', '2', '--steps', '3']
+
+
 def test_optimal_new_camera_matrix_independent_restatement():
     """utils.getOptimalNewCameraMatrix (what LensDistortion uses for cv2.getOptimalNewCameraMatrix,
     camera/LensDistortion.py:350-353) against the second numpy restatement of OpenCV 4.x's

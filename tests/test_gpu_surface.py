@@ -244,27 +244,47 @@ def test_empty_placed_keeps_the_fastest_candidate(ia):
 
 
 def test_large_blocks_are_placed_by_the_pool():
-    """device.py::_alloc_placed: a block of 256 MiB and more that the pool cannot serve is chosen
-    among several candidate allocations by a strip-shaped probe and logged; the pool hands the same
-    block out again; smaller blocks and contexts with one candidate take the first allocation"""
+    """device.py::_alloc_placed (opt-in, IMGPROC_HIP_PLACE=2): a block of 256 MiB and more that the
+    pool cannot serve is the better of TWO allocations by a strip-shaped probe - never more than one
+    extra block held - and logged; the pool hands the same block out again; smaller blocks and the
+    default context (placement off) take the first allocation"""
     import imgprocessor_amd as ia
     ctx = ia.Context(0)
     try:
-        assert ctx._place_n >= 1 and ctx.placement_log == []
-        ctx._place_n = 3
+        assert ctx._place_n == 1 and ctx.placement_log == []      # off by default
+        free0 = ctx.mem_info()[0]
+        plain = ctx.empty((72, 1024, 1024), np.float32)
+        assert ctx.placement_log == []
+        del plain
+        ctx.trim()
+        ctx._place_n = 2
         small = ctx.empty((1024, 1024), np.float32)
         assert ctx.placement_log == []
         big = ctx.empty((72, 1024, 1024), np.float32)          # 288 MiB
         assert len(ctx.placement_log) == 1
         e = ctx.placement_log[0]
-        assert e['nbytes'] == big.nbytes and 1 <= len(e['ms']) <= 3 and 0 <= e['kept'] < len(e['ms'])
+        assert e['nbytes'] == big.nbytes and 1 <= len(e['ms']) <= 2 and 0 <= e['kept'] < len(e['ms'])
         assert e['ms'][e['kept']] == min(e['ms']) and all(t > 0 for t in e['ms'])
+        # the candidate that was not kept went back to the driver
+        assert free0 - ctx.mem_info()[0] < 2 * big.nbytes
         ptr = big.ptr.value
         big.set(np.ones(big.shape, np.float32))                 # the block is usable
         assert float(big.frame(71).get()[5, 5]) == 1.0
         del big
         again = ctx.empty((72, 1024, 1024), np.float32)          # from the pool: the same block, no probe
         assert again.ptr.value == ptr and len(ctx.placement_log) == 1
+        # a probe that raises leaves no candidate behind
+        free1 = ctx.mem_info()[0]
+        real = ctx._probe_block
+
+        def boom(p, n):
+            raise RuntimeError('probe failed')
+        ctx._probe_block = boom
+        with pytest.raises(RuntimeError):
+            ctx.empty((80, 1024, 1024), np.float32)
+        ctx._probe_block = real
+        ctx.synchronize()
+        assert abs(free1 - ctx.mem_info()[0]) < (64 << 20)
         ctx._place_n = 1
         other = ctx.empty((80, 1024, 1024), np.float32)
         assert len(ctx.placement_log) == 1
