@@ -63,6 +63,8 @@ PROTOTYPES = {
                           _d],
     'ipa_sepconv2d': [_vp, _vp, _i, _i, _i, _dp, _i, _dp, _i, _vp, _i, _i, _i, _d],
     'ipa_extend_array_dev': [_vp, _vp, _i, _i, _i, _l, _i, _i, _i, _i, _vp, _l],
+    'ipa_deinterleave_dev': [_vp, _vp, _i, _i, _i, _i, _l, _vp, _l, _l],
+    'ipa_interleave_dev': [_vp, _vp, _i, _i, _i, _i, _l, _l, _vp, _l],
     'ipa_conv_ydep_dev': [_vp, _vp, _i, _i, _i, _l, _vp, _i, _i, _i, _i, _vp, _l],
     'ipa_var_y_gauss_dev': [_vp, _vp, _i, _i, _i, _l, C.c_double, C.c_double, _i,
                             C.POINTER(C.c_double), _i, _i, _i, _vp, _l],

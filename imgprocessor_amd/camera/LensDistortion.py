@@ -166,9 +166,9 @@ class LensDistortion(object):
         if isinstance(image, DeviceArray):
             return fn(image)
         image = np.asarray(image)
-        if image.ndim == 3:  # (H, W, C) like cv2: channels are independent frames
-            d = self.ctx.to_device(np.ascontiguousarray(np.moveaxis(image, 2, 0)))
-            return np.ascontiguousarray(np.moveaxis(fn(d).get(), 0, 2))
+        if image.ndim == 3:  # (H, W, C) like cv2: channels are independent frames - the layout
+            # copies both ways run on the device (no transposed copy on the host)
+            return ops.from_planes(fn(ops.to_planes(image, ctx=self.ctx))).get()
         if image.ndim != 2:
             raise ValueError('expected a (H,W) or (H,W,C) image')
         return fn(self.ctx.to_device(image)).get()

@@ -114,9 +114,8 @@ class PerspectiveCorrection(object):
         if isinstance(img, DeviceArray):
             return run(img)
         img = np.asarray(img)
-        if img.ndim == 3:
-            d = self.ctx.to_device(np.ascontiguousarray(np.moveaxis(img, 2, 0)))
-            return np.ascontiguousarray(np.moveaxis(run(d).get(), 0, 2))
+        if img.ndim == 3:   # (H, W, C): the layout copies both ways run on the device
+            return ops.from_planes(run(ops.to_planes(img, ctx=self.ctx))).get()
         return run(self.ctx.to_device(img)).get()
 
     def correct(self, img):

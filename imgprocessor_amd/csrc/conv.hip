@@ -418,6 +418,51 @@ static int check_border(ipa_ctx* ctx, int b) {
   return IPA_OK;
 }
 
+// ---------------------------------------------------- channel layout --
+// (H, W, C) images as cv2 hands them to remap / warpPerspective (camera/LensDistortion.py:323-326,
+// camera/PerspectiveCorrection.py:401-405; the reference's own demo warps a colour PNG, :858-900)
+// against the library's planes: C frames of (H, W).  One thread per pixel, its C elements in a
+// row: the plane accesses are coalesced, the interleaved ones contiguous over the wave.
+template <typename T, bool TO_PLANES>
+__global__ void __launch_bounds__(256) channels_kernel(const T* __restrict__ src, T* __restrict__ dst, int h,
+                                                       int w, int ch, long ipitch, long ppitch,
+                                                       long pstride) {
+  // src / dst: the interleaved image (row pitch ipitch elements) and the planes (row pitch ppitch,
+  // plane stride pstride), in the direction TO_PLANES says
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x >= w || y >= h) return;
+  const long io = (long)y * ipitch + (long)x * ch, po = (long)y * ppitch + x;
+  for (int c = 0; c < ch; c++) {
+    if constexpr (TO_PLANES) dst[po + c * pstride] = src[io + c];
+    else dst[io + c] = src[po + c * pstride];
+  }
+}
+
+template <bool TO_PLANES>
+static int channels_launch(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, int ch, long ipitch,
+                           long ppitch, long pstride, void* d_dst) {
+  if (!ctx) return IPA_ERR_BAD_ARG;
+  IPA_REQUIRE(ctx, d_src && d_dst && h > 0 && w > 0 && ch > 0, "bad arguments");
+  IPA_REQUIRE(ctx, ipitch >= (long)w * ch && ppitch >= w && pstride >= (long)(h - 1) * ppitch + w,
+              "pitch / plane stride smaller than the image");
+  dim3 grid((w + 63) / 64, (h + 3) / 4), block(256);
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+#define IPA_CH(T)                                                                                   \
+  hipLaunchKernelGGL((channels_kernel<T, TO_PLANES>), grid, block, 0, ctx->stream, (const T*)d_src, \
+                     (T*)d_dst, h, w, ch, ipitch, ppitch, pstride)
+  switch (dtype) {
+    case IPA_U8: IPA_CH(uint8_t); break;
+    case IPA_U16: IPA_CH(uint16_t); break;
+    case IPA_F32: IPA_CH(float); break;
+    case IPA_F64: IPA_CH(double); break;
+    default: IPA_REQUIRE(ctx, false, "unknown dtype %d", dtype);
+  }
+#undef IPA_CH
+  IPA_HIP(ctx, hipGetLastError());
+  return IPA_OK;
+}
+
+
 extern "C" {
 
 int ipa_conv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
@@ -595,6 +640,15 @@ int ipa_extend_array_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int 
   }
   IPA_HIP(ctx, hipGetLastError());
   return IPA_OK;
+}
+
+int ipa_deinterleave_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, int channels,
+                         long src_pitch, void* d_dst, long dst_pitch, long dst_plane_stride) {
+  return channels_launch<true>(ctx, d_src, dtype, h, w, channels, src_pitch, dst_pitch, dst_plane_stride, d_dst);
+}
+int ipa_interleave_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, int channels,
+                       long src_pitch, long src_plane_stride, void* d_dst, long dst_pitch) {
+  return channels_launch<false>(ctx, d_src, dtype, h, w, channels, dst_pitch, src_pitch, src_plane_stride, d_dst);
 }
 
 // ---------------------------------------------------- host-pointer variants --

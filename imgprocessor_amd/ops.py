@@ -85,6 +85,33 @@ def _dev_out(ctx, out, shape, dtype):
 
 
 # ------------------------------------------------------------------ maps --
+def to_planes(img, ctx=None):
+    """(H, W, C) image (host or device) -> device batch (C, H, W), the layout copy on the device
+    (ipa_deinterleave_dev): what cv2.remap / warpPerspective do channel by channel
+    (camera/LensDistortion.py:323-326, camera/PerspectiveCorrection.py:401-405)"""
+    ctx = _ctx_of(img, ctx=ctx)
+    d = img if _is_dev(img) else ctx.to_device(img)
+    if d.ndim != 3:
+        raise ValueError('to_planes expects a (H,W,C) image')
+    h, w, c = d.shape
+    out = ctx.empty((c, h, w), d.dtype)
+    ctx._check(ctx._lib.ipa_deinterleave_dev(ctx.handle, d.ptr, dtype_id(d.dtype), h, w, c, w * c,
+                                             out.ptr, w, h * w), 'deinterleave')
+    return out
+
+
+def from_planes(planes, out=None, ctx=None):
+    """device batch (C, H, W) -> device (H, W, C) image (ipa_interleave_dev)"""
+    ctx = _ctx_of(planes, ctx=ctx)
+    if not _is_dev(planes) or planes.ndim != 3:
+        raise TypeError('from_planes expects a device batch (C,H,W)')
+    c, h, w = planes.shape
+    dst = _dev_out(ctx, out, (h, w, c), planes.dtype)
+    ctx._check(ctx._lib.ipa_interleave_dev(ctx.handle, planes.ptr, dtype_id(planes.dtype), h, w, c, w,
+                                           h * w, dst.ptr, w * c), 'interleave')
+    return dst
+
+
 def build_undistort_map(K, dist5, newK, h, w, ctx=None, device=False):
     """cv2.initUndistortRectifyMap(K, d, None, newK, (w,h), CV_32FC1)"""
     ctx = ctx or default_context()

@@ -296,6 +296,18 @@ int ipa_calib_prefilter_dev(ipa_ctx* ctx, const void* d_img, int dtype, const vo
 int ipa_extend_array_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, long src_pitch,
                          int kx, int ky, int modex, int modey, void* d_dst, long dst_pitch);
 
+/* (H, W, C) images - what cv2.remap / cv2.warpPerspective take in LensDistortion.correct
+ * (camera/LensDistortion.py:323-326) and PerspectiveCorrection.correct
+ * (camera/PerspectiveCorrection.py:401-405; the reference's own demo warps a colour PNG,
+ * :858-900) - against the C planes of (H, W) every entry point above works on (n_frames = C):
+ * device-side layout copies, so that a colour frame goes host -> device -> host once, without a
+ * transposed copy on the host.  Pitches in elements (src_pitch of the interleaved image >= w * C),
+ * any dtype. */
+int ipa_deinterleave_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, int channels,
+                         long src_pitch, void* d_dst, long dst_pitch, long dst_plane_stride);
+int ipa_interleave_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, int channels,
+                       long src_pitch, long src_plane_stride, void* d_dst, long dst_pitch);
+
 /* --------------------------------------------- fused remap -> K x K filter */
 /* the headline chain (LensDistortion.correct followed by a K x K filter, the
  * in-tree archetype being estimateSystematicErrorLensCorrection.py:199-207):

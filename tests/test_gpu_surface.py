@@ -226,6 +226,44 @@ def test_headline_64x4k_every_frame(ia, orc):
     assert worst < 1e-5
 
 
+def test_colour_frames_without_a_host_transpose(ia, capsys):
+    """(H, W, C) images as the reference hands them to cv2 (camera/PerspectiveCorrection.py:401-405 -
+    its demo warps a colour PNG, :858-900 -, camera/LensDistortion.py:323-326): the channels are
+    split into planes and put back ON THE DEVICE (ipa_deinterleave_dev / ipa_interleave_dev);
+    the result is bit for bit the per-plane result"""
+    from imgprocessor_amd import ops
+    from imgprocessor_amd.camera.PerspectiveCorrection import PerspectiveCorrection
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    rng = np.random.default_rng(5)
+    h, w = 203, 317
+    # layout copies alone, every dtype, odd sizes
+    ctx = ia.default_context(0)
+    for dt, c in ((np.uint8, 4), (np.uint16, 3), (np.float32, 2), (np.float64, 1)):
+        a = (rng.random((h, w, c)) * 200).astype(dt)
+        planes = ops.to_planes(a)
+        assert planes.shape == (c, h, w)
+        assert np.array_equal(planes.get(), np.moveaxis(a, 2, 0))
+        assert np.array_equal(ops.from_planes(planes).get(), a)
+    # PerspectiveCorrection.correct on a 4-channel uint8 frame (the class default: Lanczos4)
+    rgba = (rng.random((h, w, 4)) * 255).astype(np.uint8)
+    quad = np.array([(12, 9), (300, 14), (305, 190), (8, 185)], float)
+    pc = PerspectiveCorrection((h, w), new_size=(180, 260))
+    pc.setReference(quad)
+    got = pc.correct(rgba)
+    assert got.shape == (180, 260, 4) and got.dtype == np.uint8 and got.flags.c_contiguous
+    for k in range(4):
+        assert np.array_equal(got[:, :, k], pc.correct(np.ascontiguousarray(rgba[:, :, k])))
+    # LensDistortion.correct on a 3-channel float32 frame
+    rgb = rng.random((h, w, 3)).astype(np.float32)
+    ld = LensDistortion()
+    ld.setCameraParams(300., 300., (w - 1) / 2, (h - 1) / 2, -0.1, 0.02, 0.0, 1e-3, -5e-4)
+    und = ld.correct(rgb, keepSize=True)
+    assert und.shape == rgb.shape and und.dtype == np.float32
+    for k in range(3):
+        assert np.array_equal(und[:, :, k], ld.correct(np.ascontiguousarray(rgb[:, :, k]), keepSize=True))
+    capsys.readouterr()
+
+
 def test_empty_placed_keeps_the_fastest_candidate(ia):
     """Context.empty_placed: candidates are distinct allocations, the one the probe likes best
     is returned, the others go back to the driver"""

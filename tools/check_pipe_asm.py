@@ -9,6 +9,17 @@ around the border-aware sampler are followed.
 A kernel that carries such loops must not spill vector registers either, nor contain flat / scratch
 accesses (they count in vmcnt) (exit 1).
 
+The LDS form of the same construct (tile_warp.hpp, ring_remap.hpp: `ds_read_b64` / `ds_read2_b32`
+issued from asm statements the compiler does not see as memory accesses, released by
+`s_waitcnt lgkmcnt(N)`): LDS operations of a wave return in order and count in lgkmcnt together
+with scalar memory reads, which return out of order.  Every kernel with such reads is walked block
+by block with the queue of its outstanding lgkm operations: a wait with N > 0 retires all but the
+N youngest only while no scalar read is outstanding; no instruction may touch the destination of
+an asm-issued read that is still in the queue; none may be outstanding at a block boundary; and
+the kernel must not use scratch memory (`.private_segment_fixed_size` 0, no spilled vector
+register): a spill the compiler puts between a read group and its counted wait would be invisible
+here and in the source alike.
+
     tools/check_pipe_asm.py file.s [name filter ...]       exit 1 on a violation
 """
 import re
@@ -196,6 +207,76 @@ def check(name, lines):
     return bad, nload, npin
 
 
+LGKM = re.compile(r'lgkmcnt\((\d+)\)')
+
+
+def check_lds(name, lines):
+    """the asm-issued LDS reads of a kernel against its lgkmcnt waits (see the module docstring)"""
+    queue = []      # outstanding lgkm operations, oldest first: (kind, destination registers, line)
+    bad = []
+    in_asm = False
+    nread = nwait = 0
+    for ln, l in lines:
+        t = l.strip()
+        if t.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if t.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        if re.match(r'^(\.LBB\d+_\d+):', t):
+            for k, d, src in queue:
+                if k == 'asm':
+                    bad.append((ln, 'block boundary (label) with an asm-issued LDS read in flight', min(d), src))
+            queue = []
+            continue
+        if not t or t.startswith((';', '.')):
+            continue
+        code = t.split(';')[0].strip()
+        op = code.split()[0]
+        regs = regs_of(code)
+        for k, d, src in queue:
+            if k == 'asm' and regs & d:
+                bad.append((ln, code, min(regs & d), src))
+        if op == 's_waitcnt':
+            m = LGKM.search(code)
+            if m:
+                n = int(m.group(1))
+                nwait += 1 if in_asm else 0
+                if n == 0:
+                    queue = []
+                elif not any(k == 'smem' for k, _, _ in queue):
+                    queue = queue[len(queue) - n:] if n < len(queue) else queue
+        elif op.startswith('ds_'):
+            is_read = op.startswith(('ds_read', 'ds_bpermute', 'ds_permute', 'ds_swizzle'))
+            dst = regs_of(code.split()[1].rstrip(',')) if is_read and len(code.split()) > 1 else set()
+            if in_asm and is_read:
+                nread += 1
+                queue.append(('asm', dst, ln))
+            else:
+                queue.append(('lds', set(), ln))
+        elif op.startswith(('s_load', 's_buffer_load', 's_memtime', 's_memrealtime', 's_dcache', 's_store')):
+            queue.append(('smem', set(), ln))
+        elif op == 's_endpgm' or op == 's_branch' or op.startswith('s_cbranch') or op == 's_barrier':
+            for k, d, src in queue:
+                if k == 'asm' and op != 's_barrier':
+                    bad.append((ln, 'block boundary (%s) with an asm-issued LDS read in flight' % op, min(d), src))
+            if op != 's_barrier':
+                queue = []
+    return bad, nread, nwait
+
+
+def private_segments(text):
+    """kernel name -> .private_segment_fixed_size of the code object metadata"""
+    out = {}
+    for blk in text.split('  - .agpr_count:')[1:]:
+        n = re.search(r'\.name:\s+(\S+)', blk)
+        v = re.search(r'\.private_segment_fixed_size:\s+(\d+)', blk)
+        if n and v:
+            out[n.group(1)] = int(v.group(1))
+    return out
+
+
 def spills(text):
     """kernel name -> .vgpr_spill_count of the code object metadata"""
     out = {}
@@ -210,6 +291,7 @@ def spills(text):
 def main():
     text = open(sys.argv[1]).read()
     spill = spills(text)
+    private = private_segments(text)
     s = text.split('\n')
     flts = sys.argv[2:]
     rc = 0
@@ -236,6 +318,26 @@ def main():
                         print('   line %d: v%d (loaded at line %d) may still be in flight: %s'
                               % (ln, r, src, t))
                     rc |= 1 if bad else 0
+                in_asm_ds = False
+                flag = False
+                for _, x in body:
+                    xs = x.strip()
+                    if xs.startswith(';;#ASMSTART'):
+                        flag = True
+                    elif xs.startswith(';;#ASMEND'):
+                        flag = False
+                    elif flag and xs.startswith('ds_read'):
+                        in_asm_ds = True
+                        break
+                if in_asm_ds:
+                    bad, nread, nwait = check_lds(name, body)
+                    nsp, prv = spill.get(name, 0), private.get(name, 0)
+                    print('%s: %d asm LDS reads, %d asm lgkmcnt waits, %d violations, %d spilled VGPRs, '
+                          '%d bytes of scratch per lane' % (name[:100], nread, nwait, len(bad), nsp, prv))
+                    for ln, t, r, src in bad[:20]:
+                        print('   line %d: v%d (LDS read issued at line %d) may still be in flight: %s'
+                              % (ln, r, src, t))
+                    rc |= 1 if (bad or nsp or prv) else 0
             i = j
         i += 1
     sys.exit(rc)

@@ -50,6 +50,9 @@ def main():
             interp = interp[:-4]
             src = ctx.to_device((src.get() * 65535).astype(np.uint16))
             dst = ctx.empty((batch, h, w), np.uint16)
+    k7 = np.random.default_rng(123).random((7, 7))
+    k7 /= k7.sum()
+    u16 = ctx.to_device(np.round(src.get() * 4095).astype(np.uint16)) if case == 'c4' else None
     for _ in range(steps):
         if case == 'cubic_maps':
             ops.remap(src, dmx, dmy, interpolation='cubic', out=dst)
@@ -57,6 +60,12 @@ def main():
             ops.warp_perspective(src, H, (h, w), interpolation='cubic', out=dst)
         elif case.startswith('rot'):
             ops.warp_perspective(src, H, (h, w), interpolation=interp, out=dst)
+        elif case == 'c4':
+            ops.remap_conv2d(u16, dmx, dmy, k7, out=dst)
+        elif case == 'fused7':
+            ops.remap_conv2d(src, dmx, dmy, k7, out=dst)
+        elif case == 'conv7':
+            ops.conv2d(src, k7, out=dst)
         elif case == 'conv5':
             ops.conv2d(src, k5, out=dst)
         elif case == 'copy':
