@@ -76,19 +76,32 @@ struct ipa_ctx {
   // ipa_plan_reserve() clears it, the user that wants reuse sets it after filling the buffer.
   double plan_key[40];
   int plan_key_n = 0;
-  // the LDS box of the tile warp kernel (tile_warp.hpp) for the last homography + geometry: a
-  // host-side walk over the tiles that a repeated call does not pay again (0.4 ms per 4K call)
-  double tile_warp_key[14];
-  int tile_warp_valid = 0, tile_warp_pitch = 0, tile_warp_rows = 0, tile_warp_ok = 0, tile_warp_shape = 0;
-  double tile_warp_drift = 0, tile_warp_step = 0, tile_warp_fetch = 0;   // see tile_warp_pays()
-  // map remaps on the tile kernel: device word the kernel counts its tap-by-tap pixels in, the
-  // page-locked word it is read back to (async: possibly one call old), and the maps + geometry
-  // it belongs to
-  unsigned* tile_slow_dev = nullptr;
-  unsigned* tile_slow_host = nullptr;
-  double tile_slow_key[10];
-  int tile_slow_valid = 0;
-  unsigned tile_slow_skips = 0;
+  // the LDS boxes of the tile warp kernel (tile_warp.hpp) for the last few homographies +
+  // geometries (least recently used of kTileWarpPlans replaced): a host-side walk over the tiles
+  // that a repeated call - or two matrices used in turn - does not pay again (0.4 ms per 4K call)
+  static constexpr int kTileWarpPlans = 4;
+  struct TileWarpPlan {
+    double key[14];
+    int valid = 0, pitch = 0, rows = 0, ok = 0, shape = 0;
+    double drift = 0, step = 0, fetch = 0;   // see tile_warp_pays()
+    unsigned long used = 0;
+  } tile_warp_plans[kTileWarpPlans];
+  unsigned long tile_warp_clock = 0;
+  // map remaps on the tile kernel: per (map pair, geometry) - least recently used of kTileSlowHints
+  // replaced - a device word the kernel counts its tap-by-tap pixels in, the page-locked word it is
+  // read back to by an asynchronous copy, and the event behind that copy: the word is the hint of
+  // ITS key once the event has passed (the host never writes it)
+  static constexpr int kTileSlowHints = 4;
+  struct TileSlowHint {
+    double key[10];
+    int valid = 0;
+    unsigned skips = 0;
+    unsigned long used = 0, launches = 0;
+    hipEvent_t copied = nullptr;
+  } tile_slow[kTileSlowHints];
+  unsigned long tile_slow_clock = 0;
+  unsigned* tile_slow_dev = nullptr;    // kTileSlowHints words
+  unsigned* tile_slow_host = nullptr;   // kTileSlowHints words
   // clean strip pairs / pairs of the last planning pass (page-locked, written by an async copy)
   // and the source + geometry it belongs to: ring_plan_prepare's hint
   unsigned* ring_hint = nullptr;

@@ -482,8 +482,16 @@ static int ring_remap_launch(ipa_ctx* ctx, RemapParams& p, const Coord& coord, i
 //             0.62 ms), level with the ring kernel on small batches of an enlarged picture.
 // (tools/warp_policy_matrix.py; re-measured after the row-walking kernels stopped paying for
 // footprints on the source border)
-static inline bool tile_warp_pays(const ipa_ctx* ctx, int base, int n_frames, long px) {
-  const double d = ctx->tile_warp_drift, g = ctx->tile_warp_fetch;   // (tile_warp_step: recorded, not used)
+// what of that does not depend on the boxes: false = the tile kernel does not pay whatever they are
+// (tested BEFORE the host walks over the tiles: 0.4 ms per new matrix on a 4K frame)
+static inline bool tile_warp_may_pay(int base, int n_frames, long px) {
+  const double work = (double)n_frames * (double)px;
+  if (base == IPA_INTER_LINEAR) return (n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6);
+  if (base == IPA_INTER_LANCZOS4) return true;
+  return (n_frames >= 4 && work >= 16e6) || work >= 8e6;
+}
+static inline bool tile_warp_pays(const ipa_ctx::TileWarpPlan& pl, int base, int n_frames, long px) {
+  const double d = pl.drift, g = pl.fetch;   // (step: recorded, not used)
   const double work = (double)n_frames * (double)px;
   if (base == IPA_INTER_LINEAR)
     return ((n_frames >= 8 && work >= 64e6) || (n_frames >= 4 && work >= 100e6)) &&
@@ -500,9 +508,20 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
   TileWarpArgs t;
   int shape;
   {
+    // (the conditions that do not depend on the boxes first: a call they reject pays no walk)
+    if (ctx->tune.tile_warp < 2) {
+      if (kU16 ? (double)n_frames * p.dh * p.dw < 2e6 : !tile_warp_may_pay(base, n_frames, (long)p.dh * p.dw))
+        return 1;
+    }
     double key[14] = {(double)(INTERP + (kU16 ? 16 : 0)), (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw};
     for (int k = 0; k < 9; k++) key[5 + k] = coord.m[k];
-    if (!ctx->tile_warp_valid || memcmp(key, ctx->tile_warp_key, sizeof key) != 0) {
+    ipa_ctx::TileWarpPlan* pl = nullptr;
+    for (auto& q : ctx->tile_warp_plans)
+      if (q.valid && memcmp(key, q.key, sizeof key) == 0) pl = &q;
+    if (!pl) {
+      pl = &ctx->tile_warp_plans[0];
+      for (auto& q : ctx->tile_warp_plans)
+        if (!q.valid || q.used < pl->used) { pl = &q; if (!q.valid) break; }
       // the largest tile shape whose source boxes fit (tile_warp.hpp)
       int pitch = 0, rows = 0, sh = 0;
       bool ok = false;
@@ -510,27 +529,24 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
         ok = tile_warp_box<NT, kU16>(coord.m, p.dh, p.dw, p.sh, p.sw, kWarpTileWs[sh], kWarpTileHs[sh],
                                      &pitch, &rows);
       sh -= 1;
-      ctx->tile_warp_ok = ok ? 1 : 0;
-      ctx->tile_warp_shape = sh;
-      ctx->tile_warp_rows = rows;
-      ctx->tile_warp_pitch = ok ? tile_warp_pitch<NT>(coord.m, p.dh, p.dw, pitch, rows) : 0;
+      pl->ok = ok ? 1 : 0;
+      pl->shape = sh;
+      pl->rows = rows;
+      pl->pitch = ok ? tile_warp_pitch<NT>(coord.m, p.dh, p.dw, pitch, rows) : 0;
       if (ok)
         tile_warp_measure(coord.m, p.dh, p.dw, pitch, rows, kWarpTileWs[sh], kWarpTileHs[sh],
-                          &ctx->tile_warp_drift, &ctx->tile_warp_step, &ctx->tile_warp_fetch);
-      memcpy(ctx->tile_warp_key, key, sizeof key);
-      ctx->tile_warp_valid = 1;
+                          &pl->drift, &pl->step, &pl->fetch);
+      memcpy(pl->key, key, sizeof key);
+      pl->valid = 1;
     }
-    if (!ctx->tile_warp_ok) return 1;
-    if constexpr (kU16) {
-      // the gather kernel's 16U arithmetic is 4 - 10 times slower than this kernel's on 4K frames
-      // (profiles/r04_micro.txt): every batch with some work in it
-      if (ctx->tune.tile_warp < 2 && (double)n_frames * p.dh * p.dw < 2e6) return 1;
-    } else {
-      if (ctx->tune.tile_warp < 2 && !tile_warp_pays(ctx, base, n_frames, (long)p.dh * p.dw)) return 1;
+    pl->used = ++ctx->tile_warp_clock;
+    if (!pl->ok) return 1;
+    if constexpr (!kU16) {
+      if (ctx->tune.tile_warp < 2 && !tile_warp_pays(*pl, base, n_frames, (long)p.dh * p.dw)) return 1;
     }
-    t.pitch = ctx->tile_warp_pitch;
-    t.rows = ctx->tile_warp_rows;
-    shape = ctx->tile_warp_shape;
+    t.pitch = pl->pitch;
+    t.rows = pl->rows;
+    shape = pl->shape;
   }
   const int TW = kWarpTileWs[shape], TH = kWarpTileHs[shape];
   t.slow_count = nullptr;
@@ -579,28 +595,46 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
   // the count comes back without a wait (so: one call late), and from the second call on a map
   // pair with more than 0.5 % such pixels takes the ring / gather kernels (every 64th call tries
   // again: the map's contents may have changed behind the same pointers)
+  ipa_ctx::TileSlowHint* hint = nullptr;
+  int hslot = 0;
   {
     double key[10] = {(double)(uintptr_t)coord.mx, (double)(uintptr_t)coord.my, (double)coord.pitch,
                       (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw, (double)INTERP,
                       (double)p.border, (double)p.q5};
     if (!ctx->tile_slow_dev) {
-      IPA_HIP(ctx, hipMalloc((void**)&ctx->tile_slow_dev, 2 * sizeof(unsigned)));
-      IPA_HIP(ctx, hipHostMalloc((void**)&ctx->tile_slow_host, 2 * sizeof(unsigned)));
-      ctx->tile_slow_host[0] = 0;
+      IPA_HIP(ctx, hipMalloc((void**)&ctx->tile_slow_dev, ipa_ctx::kTileSlowHints * sizeof(unsigned)));
+      IPA_HIP(ctx, hipHostMalloc((void**)&ctx->tile_slow_host, ipa_ctx::kTileSlowHints * sizeof(unsigned)));
+      for (int k = 0; k < ipa_ctx::kTileSlowHints; k++) {
+        ctx->tile_slow_host[k] = 0;
+        IPA_HIP(ctx, hipEventCreateWithFlags(&ctx->tile_slow[k].copied, hipEventDisableTiming));
+      }
     }
-    const bool same = ctx->tile_slow_valid && memcmp(key, ctx->tile_slow_key, sizeof key) == 0;
-    if (same && ctx->tune.tile_warp < 2 &&
-        (double)ctx->tile_slow_host[0] > 0.005 * (double)p.dh * p.dw && (++ctx->tile_slow_skips & 63u) != 0)
+    for (int k = 0; k < ipa_ctx::kTileSlowHints; k++)
+      if (ctx->tile_slow[k].valid && memcmp(key, ctx->tile_slow[k].key, sizeof key) == 0) { hint = &ctx->tile_slow[k]; hslot = k; }
+    if (!hint) {
+      // a new map pair: the least recently used slot.  Its word may still receive the old key's
+      // last copy - `launches` = 0 keeps it from being read as this key's until a copy of THIS
+      // key has passed its event (copies of one stream land in order)
+      hslot = 0;
+      for (int k = 0; k < ipa_ctx::kTileSlowHints; k++) {
+        if (!ctx->tile_slow[k].valid) { hslot = k; break; }
+        if (ctx->tile_slow[k].used < ctx->tile_slow[hslot].used) hslot = k;
+      }
+      hint = &ctx->tile_slow[hslot];
+      memcpy(hint->key, key, sizeof key);
+      hint->valid = 1;
+      hint->skips = 0;
+      hint->launches = 0;
+    }
+    hint->used = ++ctx->tile_slow_clock;
+    // the word is this key's count once a launch for this key has been copied back
+    const bool known = hint->launches > 0 && hipEventQuery(hint->copied) == hipSuccess;
+    if (known && ctx->tune.tile_warp < 2 &&
+        (double)ctx->tile_slow_host[hslot] > 0.005 * (double)p.dh * p.dw && (++hint->skips & 63u) != 0)
       return 1;
-    if (!same) {
-      memcpy(ctx->tile_slow_key, key, sizeof key);
-      ctx->tile_slow_valid = 1;
-      ctx->tile_slow_skips = 0;
-      ctx->tile_slow_host[0] = 0;   // (a read-back still in flight may land here once: a late hint)
-    }
-    IPA_HIP(ctx, hipMemsetAsync(ctx->tile_slow_dev, 0, sizeof(unsigned), ctx->stream));
+    IPA_HIP(ctx, hipMemsetAsync(ctx->tile_slow_dev + hslot, 0, sizeof(unsigned), ctx->stream));
   }
-  t.slow_count = ctx->tile_slow_dev;
+  t.slow_count = ctx->tile_slow_dev + hslot;
   t.dst = p.dst; t.dst_frame_elems = p.dst_frame_elems; t.dpitch = p.dpitch;
   t.src = p.src; t.src_frame_bytes = p.src_frame_bytes; t.src_bytes = p.src_bytes;
   t.sh = p.sh; t.sw = p.sw; t.spitch = p.spitch; t.dh = p.dh; t.dw = p.dw;
@@ -619,8 +653,10 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
   if ((unsigned long)t.tiles * groups >= (1ul << 31)) return 1;
   tile_warp_run_map(ctx->stream, t, coord, INTERP, (unsigned)t.tiles * groups,
                     (size_t)tile_warp_lds_bytes<NT>(t.pitch, t.rows));
-  IPA_HIP(ctx, hipMemcpyAsync(ctx->tile_slow_host, ctx->tile_slow_dev, sizeof(unsigned), hipMemcpyDeviceToHost,
-                              ctx->stream));
+  IPA_HIP(ctx, hipMemcpyAsync(ctx->tile_slow_host + hslot, ctx->tile_slow_dev + hslot, sizeof(unsigned),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  IPA_HIP(ctx, hipEventRecord(hint->copied, ctx->stream));
+  hint->launches++;
   return 0;
 }
 

@@ -162,6 +162,8 @@ int ipa_ctx_destroy(ipa_ctx* c) {
   if (c->tab) (void)hipFree(c->tab);
   if (c->plan) (void)hipFree(c->plan);
   if (c->lens_map) (void)hipFree(c->lens_map);
+  for (auto& hnt : c->tile_slow)
+    if (hnt.copied) (void)hipEventDestroy(hnt.copied);
   if (c->tile_slow_dev) (void)hipFree(c->tile_slow_dev);
   if (c->tile_slow_host) (void)hipHostFree(c->tile_slow_host);
   if (c->ring_hint) (void)hipHostFree(c->ring_hint);

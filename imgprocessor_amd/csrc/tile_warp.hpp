@@ -198,6 +198,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
     tile_axis_box<NT, kU16>(loy, hiy, a.sh, by0, bh);
     if (!fin) bw = bh = 0;
     bw = bw < a.pitch ? bw : a.pitch;
+    bw = bw < 128 ? bw : 128;   // (the fill covers columns 0 .. 127; tile_warp_pitch may pad the pitch past them)
     bh = bh < a.rows ? bh : a.rows;
     bx0 = __builtin_amdgcn_readfirstlane(bx0); by0 = __builtin_amdgcn_readfirstlane(by0);
     bw = __builtin_amdgcn_readfirstlane(bw); bh = __builtin_amdgcn_readfirstlane(bh);
@@ -287,6 +288,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
       bx0 = xmn; by0 = ymn;
       bw = xmx + NT - xmn; bh = ymx + NT - ymn;
       bw = bw < a.pitch ? bw : a.pitch;
+      bw = bw < 128 ? bw : 128;
       bh = bh < a.rows ? bh : a.rows;
     }
     bx0 = __builtin_amdgcn_readfirstlane(bx0); by0 = __builtin_amdgcn_readfirstlane(by0);
@@ -330,7 +332,10 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
   // columns that are not the source's - the rim of a rotated picture, of an alpha = 1
   // undistortion - load from a clamped place and are written as the border value.  The other
   // border modes on the rim go cell by cell (below).
-  constexpr int kRowsFly = INTERP == kCubic ? 10 : 12;   // (a box of 35 / 37 / 41 rows at no rotation)
+  // (a box of 35 / 37 / 41 rows at no rotation: 9 / 10 / 11 rows per wave.  Lanczos4 on float32 frames
+  // keeps exactly its 11: with a twelfth prefetch register the 64 x 32 instantiation spilled one
+  // register to scratch memory under its 128-register cap - tools/check_pipe_asm.py)
+  constexpr int kRowsFly = INTERP == kCubic ? 10 : (kLz && !kU16 ? 11 : 12);
   // (bicubic only: in one process, 16 x 4K at 15 degrees, direct against cell by cell: bicubic
   // 0.392 / 0.414 ms, but bilinear 0.371 / 0.310 and Lanczos4 0.869 / 0.841 - the larger loop body
   // costs those two more than their rim tiles gain; profiles/r04_micro.txt)

@@ -6,8 +6,9 @@ shrunk to ``round(shape / f)`` with ``cv2.resize(..., INTER_AREA)`` and enlarged
 cv2-unpinned) for float32 / float64 images.  Integer images (the reference's demo feeds a uint8
 one) keep their dtype like ``cv2.resize`` does: they are resized in float32 (``toFloatArray``'s
 rule for uint8 / uint16; cv2's 8-bit fixed-point arithmetic differs between OpenCV versions and is
-not restated) and the result is rounded half-to-even and saturated to the dtype's range -
-``cv::saturate_cast`` - for the returned array and for the in-place write alike.
+not restated) and BOTH results - ``cv2.resize`` hands an integer image back each time: the small
+one before it is enlarged, and the enlarged one - are rounded half-to-even and saturated to the
+dtype's range (``cv::saturate_cast``), for the returned array and for the in-place write alike.
 ``inplace=True`` writes the result into ``img``.
 """
 import numpy as np
@@ -25,9 +26,11 @@ def fastMean(img, f=10, inplace=False, ctx=None):
     ss0 = int(round(s0 / f))
     ss1 = int(round(s1 / f))
     small = ops.resize(src, (ss0, ss1), 'area', ctx=ctx)
-    big = ops.resize(small, (s0, s1), 'linear', ctx=ctx)
     if src.dtype.kind in 'ui':
         info = np.iinfo(src.dtype)
+        small = np.clip(np.rint(small), info.min, info.max).astype(small.dtype)   # cv2's integer `small`
+    big = ops.resize(small, (s0, s1), 'linear', ctx=ctx)
+    if src.dtype.kind in 'ui':
         big = np.clip(np.rint(big), info.min, info.max).astype(src.dtype)
     if inplace:
         img[...] = big

@@ -121,10 +121,14 @@ def test_fast_filter_and_fast_mean_end_to_end(ia, oracle):
             got = fastMean(a, fac)
             assert got.dtype == dt
             assert np.array_equal(got, oracle.fastMean(a, fac)), (dt.__name__, fac)
-    # integer images keep their dtype like cv2.resize: float32 arithmetic, round half to even, saturate
+    # integer images keep their dtype like cv2.resize - BOTH times: the INTER_AREA result is an integer
+    # image (rounded half to even, saturated) before INTER_LINEAR enlarges it, and so is the result
     for dt in (np.uint8, np.uint16):
         ui = (rng.random((100, 70)) * np.iinfo(dt).max).astype(dt)
-        want = np.clip(np.rint(oracle.fastMean(ui.astype(np.float32), 20)), 0, np.iinfo(dt).max).astype(dt)
+        mx = np.iinfo(dt).max
+        small = oracle.resize(ui.astype(np.float32), (5, 4), oracle.RESIZE_AREA)
+        small = np.clip(np.rint(small), 0, mx).astype(np.float32)
+        want = np.clip(np.rint(oracle.resize(small, (100, 70), oracle.RESIZE_LINEAR)), 0, mx).astype(dt)
         got = fastMean(ui, 20)
         assert got.dtype == dt and np.array_equal(got, want)
         ci = ui.copy()
