@@ -627,11 +627,13 @@ def main():
                          'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
                          'compulsory_bytes_per_step': compulsory,
-                         'limiter': 'the streaming rate of the marching-strip launch shape (a plain '
-                                    '5x5 on the same skeleton runs at 5.8 TB/s) plus the gathers: '
-                                    'a vector-memory instruction costs the CU ~4.6 clocks whatever '
-                                    'its EXEC mask (DESIGN.md section 5); HBM is the roofline the '
-                                    'compulsory bytes are priced against, not what saturates',
+                         'limiter': 'the stream rate of the marching-strip shape in the 248-px geometry of the '
+                                    'sampling kernels (a gather COPY in that shape - same strips, same order, same '
+                                    'stores, no arithmetic - runs 0.80 - 0.97 ms by the box, tools/sector_micro.hip: '
+                                    '992-byte rows that start 16 bytes into a line) with the vector work (0.47 ms '
+                                    'of issue time) next to it; the aligned geometry streams 15 - 20 % faster but '
+                                    'its halo samples cost more than that (profiles/r05_micro.txt); HBM is the '
+                                    'roofline the compulsory bytes are priced against, not what saturates',
                          'kernel': kname, 'launches_per_step': launches,
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
                          'literal_survey_8d': {

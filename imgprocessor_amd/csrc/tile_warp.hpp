@@ -591,6 +591,9 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
         // (counted s_waitcnt lgkmcnt(8): the 8 reads of the older pair have returned - LDS reads
         // return in order, anything else in flight only makes the wait stricter).
         auto issue = [&](v2f (&t)[8]) {
+#ifdef IPA_DEBUG_LZ_HALF_READS   // measurement only (WRONG results): every other sample re-uses the taps in the registers
+          if (j & 1) return;
+#endif
           static_for<0, 8>([&](auto cc) {
             constexpr int c = decltype(cc)::value;
             t[c] = lds_read_b64<c * 8>(ra);

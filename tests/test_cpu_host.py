@@ -376,19 +376,21 @@ def test_optimal_new_camera_matrix_independent_restatement():
 
 
 def test_hand_scheduled_kernels_static_check(tmp_path):
-    """every translation unit that carries the hand-scheduled loops of csrc/wave_pipe.hpp (inline-asm
-    loads with hand-counted vmcnt waits: the dense 3x3 / 5x5 / 7x7 kernels, the separable ones)
-    compiled here for gfx950 and checked statically: no instruction touches a register whose load
-    is still in flight, every vector-memory asm statement carries the SGPR hazard guard, no vector
-    register is spilled (tools/check_pipe_asm.py; `make -C imgprocessor_amd/csrc check-asm` runs
-    the same)"""
+    """every translation unit that carries hand-counted waits - the hand-scheduled loops of
+    csrc/wave_pipe.hpp (inline-asm loads with counted vmcnt waits: the dense 3x3 / 5x5 / 7x7 kernels,
+    the separable ones) and, since round 5, the Lanczos4 samplers of csrc/tile_warp.hpp (asm-issued
+    ds_read_b64 groups released by counted lgkmcnt waits) - compiled here for gfx950 and checked
+    statically: no instruction touches a register whose load / LDS read is still in flight, every
+    vector-memory asm statement carries the SGPR hazard guard, no vector register is spilled, no
+    kernel with counted LDS waits uses scratch memory (tools/check_pipe_asm.py; `make -C
+    imgprocessor_amd/csrc check-asm` runs the same)"""
     import shutil
     import subprocess
     from concurrent.futures import ThreadPoolExecutor
     if not shutil.which('hipcc'):
         pytest.skip('no hipcc')
     src = os.path.join(ROOT, 'imgprocessor_amd', 'csrc')
-    units = ['fused_k3', 'fused_k5', 'fused_k7', 'fused_sep_a', 'fused_sep_b']
+    units = ['fused_k3', 'fused_k5', 'fused_k7', 'fused_sep_a', 'fused_sep_b', 'tile_warp_a', 'tile_warp_b']
 
     def one(u):
         d = tmp_path / u
@@ -405,5 +407,11 @@ def test_hand_scheduled_kernels_static_check(tmp_path):
         results = dict(zip(units, ex.map(one, units)))
     for u, r in results.items():
         assert r.returncode == 0, u + ':\n' + r.stdout + r.stderr
-        assert 'SampleRowSrc' in r.stdout, u + ':\n' + r.stdout
+        if u.startswith('tile_warp'):
+            # the Lanczos4 instantiations (float32 and uint16 frames) with their counted LDS waits
+            assert 'asm LDS reads' in r.stdout and 'tile_warp_kernelILi4Ef' in r.stdout and \
+                'tile_warp_kernelILi4Et' in r.stdout, u + ':\n' + r.stdout
+            assert ' 0 bytes of scratch per lane' in r.stdout
+        else:
+            assert 'SampleRowSrc' in r.stdout, u + ':\n' + r.stdout
     assert 'LoadRowSrc' in results['fused_k5'].stdout

@@ -276,7 +276,17 @@ def test_c5_8k_bicubic_k11(ia, orc):
     d_img = ctx.to_device(img)
     got = ia.ops.warp_perspective_conv2d(d_img, M, (h, w), k11, 'cubic').get()
     want_w = orc.warp_perspective(img, M, (h, w), orc.CUBIC_KEYS)
-    close32(got, orc.conv2d(want_w, k11), 'C5', scale=1.0)
+    # Why close32 (1e-5 relative + 1e-5 of the image's scale) and not the pointwise close32p here: a
+    # bicubic (Keys, a = -0.5) footprint has NEGATIVE lobes - its 16 products cancel in part - and 121
+    # more float32 products follow; against the oracle's double sums the worst pixel of this frame is
+    # 1.1e-5 relative (tests/rel_err.py), 7.9e-7 of the scale.  The chains whose
+    # weights are all positive (C1 - C4) are held to the pointwise bound; this one to 2e-5 pointwise
+    # on top of close32.
+    want = orc.conv2d(want_w, k11)
+    close32(got, want, 'C5', scale=1.0)
+    floor = 1e-3 * float(np.max(np.abs(want)))
+    worst = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), floor)))
+    assert worst <= 2e-5, 'C5: max pointwise relative error %.3g > 2e-5' % worst
     # row-band split (single huge frame over G GPUs): bands of OUTPUT rows with an
     # 11//2 halo computed from the same source equal the monolithic result
     bands = []

@@ -30,7 +30,7 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned n) {
 // GEO 0: 256-px aligned strips (15 per 4K row, all lanes store whole lines); GEO 1: the 248-px step of
 // the product's sampling kernels (16 strips per row, lanes 1 .. 62 store: 992-byte rows that start
 // 16 bytes into a line); MODE 6: no reads at all (the store stream alone)
-template <int MODE, int D, int GEO = 0>
+template <int MODE, int D, int GEO = 0, int NT = 1>
 __global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, int strips_y, int frames) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -95,26 +95,38 @@ __global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, 
         o = *(const v4f*)(xp + 4u * lane);
         __builtin_amdgcn_wave_barrier();
       }
-      if (writer) __builtin_nontemporal_store(o, (v4f*)(dp + (long)(r + k) * W + 4u * lane));
+      // NT 1: every store non-temporal (the product's sampling kernels); 0: plain stores; 2: plain stores for
+      // the lanes whose 16 bytes lie in a line this strip row does not cover whole, non-temporal for the rest
+      v4f* op = (v4f*)(dp + (long)(r + k) * W + 4u * lane);
+      bool plain = NT == 0;
+      if constexpr (NT == 2) {
+        const unsigned long a0 = (unsigned long)(dp + (long)(r + k) * W + 4) * 1, a1 = (unsigned long)(dp + (long)(r + k) * W + 252);
+        const unsigned long me = (unsigned long)op;
+        plain = (me & ~127ul) < a0 || (me & ~127ul) + 128 > a1;
+      }
+      if (writer) {
+        if (plain) *op = o;
+        else __builtin_nontemporal_store(o, op);
+      }
     }
   }
 }
 
-template <int MODE, int D, int GEO = 0> static void run(const char* name, const float* a, float* d, int frames, int sh) {
+template <int MODE, int D, int GEO = 0, int NT = 1> static void run(const char* name, const float* a, float* d, int frames, int sh) {
   const int strips_y = H / sh;
   dim3 grid((GEO ? 16 : 15) * strips_y * (frames / 4)), block(256);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((strips<MODE, D, GEO>), grid, block, 0, 0, a, d, sh, strips_y, frames);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
   const int reps = 20;
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((strips<MODE, D, GEO>), grid, block, 0, 0, a, d, sh, strips_y, frames);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
   // (GEO 1 skips its two rim strips of 16: the time is scaled to the whole frame)
   if (GEO) ms *= 3840.0 / (14 * 248);
-  printf("%-56s D=%d geo %d  %8.1f us  %6.0f GB/s\n", name, D, GEO, ms * 1e3, (MODE == 6 ? 1.0 : 2.0) * frames * W * H * 4 / (ms * 1e-3) / 1e9);
+  printf("%-56s D=%d geo %d nt %d  %8.1f us  %6.0f GB/s\n", name, D, GEO, NT, ms * 1e3, (MODE == 6 ? 1.0 : 2.0) * frames * W * H * 4 / (ms * 1e-3) / 1e9);
   fflush(stdout);
 }
 
@@ -144,6 +156,12 @@ int main(int argc, char** argv) {
     run<1, 2, 1>("1 four dwords per lane, interleaved", a, d, frames, sh);
     run<3, 2, 1>("3 four dwords, odd column offset", a, d, frames, sh);
     run<5, 2, 1>("5 four dwords + the dword at +4 bytes", a, d, frames, sh);
+    run<6, 2, 1, 0>("6 no reads: the store stream alone, plain stores", a, d, frames, sh);
+    run<6, 2, 1, 2>("6 no reads: the store stream alone, plain on partial lines", a, d, frames, sh);
+    run<3, 2, 1, 0>("3 four dwords, odd column offset, plain stores", a, d, frames, sh);
+    run<3, 2, 1, 2>("3 four dwords, odd column offset, plain on partial lines", a, d, frames, sh);
+    run<3, 2, 0, 0>("3 four dwords, odd column offset, plain stores", a, d, frames, sh);
+    run<6, 2, 0, 0>("6 no reads: the store stream alone, plain stores", a, d, frames, sh);
     run<6, 2>("6 no reads, 144-row strips", a, d, frames, 144);
     run<6, 2, 1>("6 no reads, 144-row strips", a, d, frames, 144);
     run<3, 2>("3 four dwords, odd column offset, 144-row strips", a, d, frames, 144);
