@@ -346,7 +346,12 @@ template <typename Coord, int K> struct pipe_unshared<SampleRowSrc<float, kLinea
 // vector-memory instructions, and an instruction costs the CU's vector-memory path ~4.6 clocks
 // WHATEVER its EXEC mask is, EXEC = 0 included (tools/pipe_micro.hip) - 1.30 -> 1.42 ms on the
 // unshared loop, 0.969 -> 1.015 ms on the shared-record loop (same bits; IPA_HALO_SAMPLE=1
-// builds both)
+// builds both).  Round 5 rebuilt the shared-record loop's halo as ONE gather per row for all
+// halo pixels (quads of lanes, see wave_run_strip_shared) - 128 registers instead of 128 + 5
+// spilled, same bits - and measured it as a flavour of its own on batches: 1.08 against 0.98 ms,
+// 0.974 even with the halo work left out (the aligned geometry streams 15 - 20 % faster as a
+// plain copy, but this loop's compute floor is too close under it; profiles/r05_micro.txt).
+// The sampling kernels keep the overlapping 248-px strips.
 #ifndef IPA_HALO_SAMPLE
 #define IPA_HALO_SAMPLE 0
 #endif
