@@ -331,3 +331,49 @@ def test_maps_that_need_more_than_the_reserve(ia):
         for call in range(3):
             same_bits(ops.remap(d, dmx, dmy, interp, 'reflect').get(), ref, '%s default, call %d' % (interp, call))
             ctx.synchronize()
+
+
+def test_more_homographies_in_turn_than_the_plan_table_holds(ia):
+    """round 5: the host-side boxes of the last FOUR homographies are kept (least recently used
+    replaced); six matrices used in turn - every one evicted and rebuilt - keep the gather kernel's
+    bits on every call, on the default policy too"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 170, 260
+    src = frames(8, h, w)
+    d = ctx.to_device(src)
+    mats = [rot_persp(h, w, deg, zoom=z) for deg, z in ((3, 1.0), (21, 0.9), (44, 1.1), (77, 1.0), (130, 0.8), (200, 1.2))]
+    refs = [both(ia, src, M, (h, w), 'lanczos4')[0] for M in mats]
+    for turn in range(3):
+        for M, ref in zip(mats, refs):
+            same_bits(ops.warp_perspective(d, M, (h, w), 'lanczos4', 'constant', border_value=0.25).get(), ref,
+                      'turn %d' % turn)
+
+
+def test_more_map_pairs_in_turn_than_the_hint_table_holds(ia):
+    """round 5: the slow-pixel hints of map remaps on the tile kernel live in a table of four
+    (map pair, geometry) entries, each with its own device / page-locked word and the event behind
+    its read-back.  Five map pairs in turn - among them one that shrinks the picture 2.5 times,
+    whose hint sends it to the gather kernel - give the gather kernel's bits on every call"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    n, h, w = 8, 700, 1210
+    rng = np.random.default_rng(9)
+    d = ctx.to_device(rng.random((n, h, w), dtype=np.float32))
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    pairs = []
+    for k, zoom in enumerate((1.0, 2.5, 0.8, 1.3, 1.05)):
+        mx = ((xx - w / 2) * zoom + w / 2 + 3 * np.sin(yy / 37 + k)).astype(np.float32)
+        my = ((yy - h / 2) * zoom + h / 2 + 2 * np.cos(xx / 53 + k)).astype(np.float32)
+        pairs.append((ctx.to_device(mx), ctx.to_device(my)))
+    refs = []
+    try:
+        ctx.set_tuning(tile_warp=0)
+        for dmx, dmy in pairs:
+            refs.append(ops.remap(d, dmx, dmy, 'lanczos4', 'reflect').get())
+    finally:
+        ctx.set_tuning(tile_warp=1)
+    for turn in range(4):
+        for (dmx, dmy), ref in zip(pairs, refs):
+            same_bits(ops.remap(d, dmx, dmy, 'lanczos4', 'reflect').get(), ref, 'turn %d' % turn)
+        ctx.synchronize()
