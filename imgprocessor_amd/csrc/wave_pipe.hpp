@@ -130,8 +130,11 @@ template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, uns
                                                                float* sbase) {
   // (the s_nop: a VALU write of the data registers directly behind a 128-bit store needs one
   // wait state the compiler's hazard pass cannot see through the asm)
+#ifndef IPA_STORE_FLAVOUR
+#define IPA_STORE_FLAVOUR "nt"   // cache policy of the sampling kernels' output stores (A/B: "", "sc1", "sc0 sc1", "nt sc1")
+#endif
   if constexpr (NT)
-    asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
+    asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2 " IPA_STORE_FLAVOUR "\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
   else
     asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
 }
