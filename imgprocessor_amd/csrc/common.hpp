@@ -32,6 +32,8 @@ struct ipa_tuning {
   int pipe = 1;           // 0: no strip on the hand-scheduled loops of wave_pipe.hpp (hand-counted vmcnt
                           // waits) - the compiler-scheduled chunked loops everywhere: the fallback
                           // and cross-check of that scheme (same bits, slower)
+  int group_chunk = -1;   // batches on the shared-record loop: frame groups walked this many at a time (-1: a
+                          // quarter of them, 0: all groups of a strip together); see wave_grid
   int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
   int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
                           // XCD streaming through frames of its own

@@ -70,6 +70,7 @@ const TuneName kTuneNames[] = {
     {"frames_wg", "IPA_FRAMES_WG", &ipa_tuning::frames_wg},
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
+    {"group_chunk", "IPA_GROUP_CHUNK", &ipa_tuning::group_chunk},
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };
@@ -82,6 +83,7 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "ring_remap") == 0) return v >= 0 && v <= 2;
   if (strcmp(name, "tile_warp") == 0) return v >= 0 && v <= 2;
   if (strcmp(name, "stored_coords") == 0) return v >= 0;
+  if (strcmp(name, "group_chunk") == 0) return v >= -1 && v <= 4096;
   return v == 0 || v == 1;
 }
 

@@ -214,8 +214,15 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   if (p.frames_wg) {  // the waves of a workgroup are 4 frames of one strip (WaveParams::frames_wg)
     const unsigned groups = (unsigned)p.frames_inner / 4u;
     b = xcd_swizzle(blockIdx.x, gridDim.x);
-    frame = (b % groups) * 4u + wave;
-    sid = b / groups;
+    if (p.group_chunk) {   // (wave_stencil.hpp: the frame groups a chunk at a time)
+      const unsigned gc = (unsigned)p.group_chunk, per = gc * p.strips;
+      const unsigned chunk = b / per, r = b - chunk * per;
+      frame = (chunk * gc + r % gc) * 4u + wave;
+      sid = r / gc;
+    } else {
+      frame = (b % groups) * 4u + wave;
+      sid = b / groups;
+    }
   }
   float* xp = xpose + (kRegs ? 0 : wave * kRowStride * D);
   constexpr bool kShared = sep_shared<Src, K>::value;

@@ -141,6 +141,9 @@ struct WaveParams {
                        // wave_pipe.hpp - every strip runs the compiler-scheduled chunked loop with
                        // its columns and rows resolved (the fallback and cross-check of the
                        // hand-counted waits; same bits, slower)
+  int group_chunk = 0; // frames_wg launches: n > 0 = the frame groups are walked n at a time - all strips of n
+                       // groups (4 n frames), then the next n groups - instead of all groups of a strip
+                       // together (set by wave_grid; knob group_chunk)
   int frames_wg = 0;   // 1: the waves of a workgroup are consecutive FRAMES of one strip - the strip's
                        // map rows then reach the CU's L1 once per workgroup instead of once per
                        // frame (64 x 4K fused 5x5: 1.361 -> 1.335 ms); set by wave_grid
@@ -167,7 +170,19 @@ static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, in
       (unsigned long)p.strips * n_frames < (1ul << 31)) {
     p.frames_inner = n_frames;
     p.frames_wg = 1;
-    return dim3(p.strips * (unsigned)(n_frames / waves_per_block), 1);
+    const int groups = n_frames / waves_per_block;
+    // the frame groups a quarter at a time (knob group_chunk: -1 = this rule, 0 = all groups of a strip
+    // together as in rounds 2 - 4, n = chunks of n groups).  Measured, same bits (profiles/r05_micro.txt):
+    // 64 x 4K undistort + 5x5 1.097 -> 1.044 ms with chunks of 4 of the 16 groups (2: 1.064, 8: 1.077, 1:
+    // 1.068), 128 frames 2.01 -> 1.90 with 8 of 32, 16 frames 0.297 -> 0.284 with 1 of 4; the strip-shaped
+    // STORE stream is what the slow regions of the device memory punish (loads and linear stores are level
+    // everywhere, tools/region_micro.hip), and it is the denser the fewer frames a launch writes at a time
+    {
+      int gc = ctx->tune.group_chunk;
+      if (gc < 0) gc = groups >= 4 ? groups / 4 : 0;
+      p.group_chunk = (gc > 0 && gc < groups && groups % gc == 0) ? gc : 0;
+    }
+    return dim3(p.strips * (unsigned)groups, 1);
   }
   if (frames_inner && n_frames > 1 && (unsigned long)blocks * n_frames < (1ul << 31)) {
     p.frames_inner = n_frames;
@@ -665,8 +680,15 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   if (p.frames_wg) {  // b = (strip, group of IPA_WPB frames), groups fastest
     const unsigned groups = (unsigned)p.frames_inner / IPA_WPB;
     b = xcd_swizzle(blockIdx.x, gridDim.x);
-    frame = (b % groups) * IPA_WPB + wave;
-    sid = b / groups;
+    if (p.group_chunk) {   // the groups a chunk at a time: (chunk, strip, group of the chunk)
+      const unsigned gc = (unsigned)p.group_chunk, per = gc * p.strips;
+      const unsigned chunk = b / per, r = b - chunk * per;
+      frame = (chunk * gc + r % gc) * IPA_WPB + wave;
+      sid = r / gc;
+    } else {
+      frame = (b % groups) * IPA_WPB + wave;
+      sid = b / groups;
+    }
   }
   constexpr int kXp = kRowStride * D;  // LDS floats per wave
   // the windows of lane 0 start H px left of the row: H - kRowPad floats of lead-in for K = 11
