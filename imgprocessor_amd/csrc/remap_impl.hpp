@@ -568,6 +568,11 @@ static int tile_warp_launch(ipa_ctx* ctx, const RemapParams& p, const Homography
   t.dst_bytes = (unsigned)dbytes;
   const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
   if ((unsigned long)t.tiles * groups >= (1ul << 31)) return 1;
+  {   // (wave_grid's rule for the frame groups of a launch: a quarter of them at a time)
+    int gc = ctx->tune.group_chunk;
+    if (gc < 0) gc = groups >= 4 ? (int)groups / 4 : 0;
+    t.group_chunk = (gc > 0 && gc < (int)groups && groups % (unsigned)gc == 0) ? gc : 0;
+  }
   const size_t lds = (size_t)tile_warp_lds_bytes<NT>(t.pitch, t.rows);
   if (shape == 0) tile_warp_run_a(ctx->stream, t, coord, INTERP, kU16, shape, (unsigned)t.tiles * groups, lds);
   else tile_warp_run_b(ctx->stream, t, coord, INTERP, kU16, shape, (unsigned)t.tiles * groups, lds);
@@ -651,6 +656,11 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
   t.dst_bytes = (unsigned)dbytes;
   const unsigned groups = ((unsigned)n_frames + t.frames_wg - 1) / (unsigned)t.frames_wg;
   if ((unsigned long)t.tiles * groups >= (1ul << 31)) return 1;
+  {   // (wave_grid's rule for the frame groups of a launch: a quarter of them at a time)
+    int gc = ctx->tune.group_chunk;
+    if (gc < 0) gc = groups >= 4 ? (int)groups / 4 : 0;
+    t.group_chunk = (gc > 0 && gc < (int)groups && groups % (unsigned)gc == 0) ? gc : 0;
+  }
   tile_warp_run_map(ctx->stream, t, coord, INTERP, (unsigned)t.tiles * groups,
                     (size_t)tile_warp_lds_bytes<NT>(t.pitch, t.rows));
   IPA_HIP(ctx, hipMemcpyAsync(ctx->tile_slow_host + hslot, ctx->tile_slow_dev + hslot, sizeof(unsigned),

@@ -45,6 +45,7 @@ struct TileWarpArgs {
   unsigned src_bytes, dst_bytes;   // of one frame (descriptor ranges)
   int sh, sw, spitch, dh, dw;
   int n_frames, frames_wg;
+  int group_chunk;   // frame groups walked this many at a time (0: all groups of a tile together), as WaveParams::group_chunk
   int border, q5;
   float cubic_a;
   const float* lanczos;
@@ -171,7 +172,13 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
 
   const unsigned groups = ((unsigned)a.n_frames + a.frames_wg - 1) / (unsigned)a.frames_wg;
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
-  const unsigned grp = b % groups, tile = b / groups;
+  unsigned grp = b % groups, tile = b / groups;
+  if (a.group_chunk) {
+    const unsigned gc = (unsigned)a.group_chunk, per = gc * (unsigned)a.tiles;
+    const unsigned chunk = b / per, r = b - chunk * per;
+    grp = chunk * gc + r % gc;
+    tile = r / gc;
+  }
   const int tyi = (int)(tile / (unsigned)a.tiles_x), txi = (int)tile - tyi * a.tiles_x;
   const int x0 = txi * kWarpTileW, y0 = tyi * kWarpTileH;
   const int x1 = x0 + kWarpTileW - 1 < a.dw ? x0 + kWarpTileW - 1 : a.dw - 1;

@@ -42,11 +42,12 @@ __global__ void __launch_bounds__(256) linear_k(float* p, float* sink, long n4) 
 template <bool LOAD, int GEO, int ORDER>
 __global__ void __launch_bounds__(256) strips_k(float* p, float* sink, int sh, int strips_y) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
+  // ORDER 2 / 3: orders 1 / 0 WITHOUT the XCD-contiguous block order (consecutive blocks on different XCDs)
+  const unsigned b = ORDER >= 2 ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
   constexpr unsigned SX = GEO ? 16 : 15;
   const unsigned strips = SX * strips_y;
   unsigned frame, sid;
-  if constexpr (ORDER == 0) {
+  if constexpr (ORDER == 0 || ORDER == 3) {
     const unsigned groups = F / 4;
     frame = (b % groups) * 4 + wave;
     sid = b / groups;
@@ -119,7 +120,11 @@ int main(int argc, char** argv) {
     row("store linear plain", [&](float* p) { return timeit([&] { hipLaunchKernelGGL((linear_k<false, false>), dim3((n4 + 255) / 256), dim3(256), 0, 0, p, sink, n4); }); });
     row("store strips aligned, order 0", [&](float* p) { return st(p, strips_k<false, 0, 0>, 15); });
     row("store strips aligned, order 1", [&](float* p) { return st(p, strips_k<false, 0, 1>, 15); });
+    row("store strips aligned, order 1, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 0, 2>, 15); });
+    row("store strips aligned, order 0, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 0, 3>, 15); });
     row("store strips 248-step, order 0", [&](float* p) { return st(p, strips_k<false, 1, 0>, 16) * g1; });
+    row("store strips 248-step, order 0, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 1, 3>, 16) * g1; });
+    row("store strips 248-step, order 1, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 1, 2>, 16) * g1; });
     row("store strips 248-step, order 1", [&](float* p) { return st(p, strips_k<false, 1, 1>, 16) * g1; });
     row("load linear", [&](float* p) { return timeit([&] { hipLaunchKernelGGL((linear_k<true, false>), dim3((n4 + 255) / 256), dim3(256), 0, 0, p, sink, n4); }); });
     row("load strips aligned, order 0", [&](float* p) { return st(p, strips_k<true, 0, 0>, 15); });
