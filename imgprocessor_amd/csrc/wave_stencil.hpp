@@ -174,9 +174,11 @@ static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, in
     // the frame groups a quarter at a time (knob group_chunk: -1 = this rule, 0 = all groups of a strip
     // together as in rounds 2 - 4, n = chunks of n groups).  Measured, same bits (profiles/r05_micro.txt):
     // 64 x 4K undistort + 5x5 1.097 -> 1.044 ms with chunks of 4 of the 16 groups (2: 1.064, 8: 1.077, 1:
-    // 1.068), 128 frames 2.01 -> 1.90 with 8 of 32, 16 frames 0.297 -> 0.284 with 1 of 4; the strip-shaped
-    // STORE stream is what the slow regions of the device memory punish (loads and linear stores are level
-    // everywhere, tools/region_micro.hip), and it is the denser the fewer frames a launch writes at a time
+    // 1.068), 128 frames 2.01 -> 1.90 with 8 of 32, 16 frames 0.297 -> 0.284 with 1 of 4.  (Tried because
+    // the strip-shaped STORE stream is what the slow regions of the device memory punish - loads and
+    // linear stores are level everywhere, tools/region_micro.hip -; a store-only probe does not gain from
+    // this order, the whole kernel does on every box: reads, shared map rows and stores of a chunk meet
+    // in the same L2s)
     {
       int gc = ctx->tune.group_chunk;
       if (gc < 0) gc = groups >= 4 ? groups / 4 : 0;

@@ -39,8 +39,11 @@ __global__ void __launch_bounds__(256) linear_k(float* p, float* sink, long n4) 
 }
 
 // GEO 0 aligned / 1 = 248 step; ORDER 0 frames of a strip / 1 strips of a frame
+// ORDER 4: workgroup of 16 waves = 4 frames x 4 consecutive strips, frame groups fastest
+// ORDER 5: order 0 with the frame groups a quarter at a time (the product's fused kernels since round 5)
+// ORDER 6: order 4 with the frame groups a quarter at a time
 template <bool LOAD, int GEO, int ORDER>
-__global__ void __launch_bounds__(256) strips_k(float* p, float* sink, int sh, int strips_y) {
+__global__ void __launch_bounds__(ORDER == 4 || ORDER == 6 ? 1024 : 256) strips_k(float* p, float* sink, int sh, int strips_y) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // ORDER 2 / 3: orders 1 / 0 WITHOUT the XCD-contiguous block order (consecutive blocks on different XCDs)
   const unsigned b = ORDER >= 2 ? blockIdx.x : xcd_swizzle(blockIdx.x, gridDim.x);
@@ -51,6 +54,17 @@ __global__ void __launch_bounds__(256) strips_k(float* p, float* sink, int sh, i
     const unsigned groups = F / 4;
     frame = (b % groups) * 4 + wave;
     sid = b / groups;
+  } else if constexpr (ORDER == 5) {
+    const unsigned gc = F / 16, per = gc * strips, chunk = b / per, r = b - chunk * per;
+    frame = (chunk * gc + r % gc) * 4 + wave;
+    sid = r / gc;
+  } else if constexpr (ORDER == 4 || ORDER == 6) {
+    const unsigned groups = F / 4, quads = (strips + 3) / 4;
+    unsigned g, q;
+    if constexpr (ORDER == 4) { g = b % groups; q = b / groups; }
+    else { const unsigned gc = F / 16, per = gc * quads, chunk = b / per, r = b - chunk * per; g = chunk * gc + r % gc; q = r / gc; }
+    frame = g * 4 + (wave & 3u);
+    sid = q * 4 + (wave >> 2);
   } else {
     const unsigned g = b * 4 + wave;
     frame = g / strips;
@@ -96,6 +110,7 @@ int main(int argc, char** argv) {
   for (auto& b : blk) { CK(hipMalloc(&b, bytes)); CK(hipMemset(b, 0, bytes)); }
   CK(hipDeviceSynchronize());
   auto st = [&](float* p, auto kern, unsigned sx) { return timeit([&] { hipLaunchKernelGGL(kern, dim3(sx * sy * (F / 4)), dim3(256), 0, 0, p, sink, sh, sy); }); };
+  auto st16 = [&](float* p, auto kern, unsigned sx) { return timeit([&] { hipLaunchKernelGGL(kern, dim3((sx * sy + 3) / 4 * (F / 4)), dim3(1024), 0, 0, p, sink, sh, sy); }); };
   // settle the clocks, then class the blocks: store-only, aligned strips, order 0
   for (int i = 0; i < 200; i++) hipLaunchKernelGGL((strips_k<false, 0, 0>), dim3(15 * sy * (F / 4)), dim3(256), 0, 0, blk[0], sink, sh, sy);
   std::vector<std::pair<double, int>> cls;
@@ -126,6 +141,11 @@ int main(int argc, char** argv) {
     row("store strips 248-step, order 0, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 1, 3>, 16) * g1; });
     row("store strips 248-step, order 1, no XCD swizzle", [&](float* p) { return st(p, strips_k<false, 1, 2>, 16) * g1; });
     row("store strips 248-step, order 1", [&](float* p) { return st(p, strips_k<false, 1, 1>, 16) * g1; });
+    row("store strips 248-step, order 0, groups a quarter at a time", [&](float* p) { return st(p, strips_k<false, 1, 5>, 16) * g1; });
+    row("store strips 248-step, 4 frames x 4 strips per WG", [&](float* p) { return st16(p, strips_k<false, 1, 4>, 16) * g1; });
+    row("store strips 248-step, 4 x 4 per WG, a quarter at a time", [&](float* p) { return st16(p, strips_k<false, 1, 6>, 16) * g1; });
+    row("store strips aligned, order 0, a quarter at a time", [&](float* p) { return st(p, strips_k<false, 0, 5>, 15); });
+    row("store strips aligned, 4 x 4 per WG, a quarter at a time", [&](float* p) { return st16(p, strips_k<false, 0, 6>, 15); });
     row("load linear", [&](float* p) { return timeit([&] { hipLaunchKernelGGL((linear_k<true, false>), dim3((n4 + 255) / 256), dim3(256), 0, 0, p, sink, n4); }); });
     row("load strips aligned, order 0", [&](float* p) { return st(p, strips_k<true, 0, 0>, 15); });
     row("load strips aligned, order 1", [&](float* p) { return st(p, strips_k<true, 0, 1>, 15); });
