@@ -325,3 +325,35 @@ def test_footprints_on_the_source_rim_in_every_row(ia, oracle, dtype, n):
                                                       out_dtype=np.float32), k)
                     assert_close(got[f], want, 1e-5, 1e-5 * np.abs(want).max(),
                                  '%s, %dx%d, %s, frame %d of %d %s' % (name, K, K, border, f, n, np.dtype(dtype).name))
+
+
+@pytest.mark.parametrize('n', [8, 16, 24, 32])
+def test_frame_groups_walked_a_chunk_at_a_time_have_the_same_bits(ia, n):
+    """round 5: a fused batch walks its frame groups a quarter at a time (wave_stencil.hpp::wave_grid,
+    knob group_chunk; the tile kernel's groups the same way) - an order of the workgroups, nothing
+    else: every chunk size gives the bits of all groups together (group_chunk = 0), for the dense
+    and the separable filter, map remaps on the tile kernel and homography warps"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 170, 610
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    k5, g = kern(5), ops.gaussian_kernel1d(1.0)
+    a = np.deg2rad(11.0)
+    M = np.array([[np.cos(a), -np.sin(a), 40.0], [np.sin(a), np.cos(a), -30.0], [2e-5, 1e-5, 1.0]])
+    calls = {
+        'remap + 5x5': lambda: ops.remap_conv2d(d, dmx, dmy, k5).get(),
+        'remap + separable 9+9': lambda: ops.remap_sepconv2d(d, dmx, dmy, g, g).get(),
+        'map remap, Lanczos4': lambda: ops.remap(d, dmx, dmy, 'lanczos4').get(),
+        'warp, bicubic': lambda: ops.warp_perspective(d, M, (h, w), 'cubic').get(),
+    }
+    old = ctx.set_tuning(group_chunk=0, tile_warp=2)
+    try:
+        ref = {name: fn() for name, fn in calls.items()}
+        for gc in (-1, 1, 2, 3, 4):
+            ctx.set_tuning(group_chunk=gc)
+            for name, fn in calls.items():
+                same_bits(fn(), ref[name], '%s, %d frames, group_chunk %d' % (name, n, gc))
+    finally:
+        ctx.set_tuning(**old)
