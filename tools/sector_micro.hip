@@ -31,12 +31,18 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned n) {
 // the product's sampling kernels (16 strips per row, lanes 1 .. 62 store: 992-byte rows that start
 // 16 bytes into a line); MODE 6: no reads at all (the store stream alone)
 template <int MODE, int D, int GEO = 0, int NT = 1>
-__global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, int strips_y, int frames) {
+__global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, int strips_y, int frames, int gchunk = 0) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned b = xcd_swizzle(blockIdx.x, gridDim.x);
   const unsigned groups = frames / 4;
-  const unsigned frame = (b % groups) * 4 + wave;
-  const unsigned sid = b / groups;
+  unsigned frame = (b % groups) * 4 + wave;
+  unsigned sid = b / groups;
+  if (gchunk) {   // the frame groups gchunk at a time (the product's fused kernels since round 5)
+    const unsigned nstr = (GEO ? 16u : 15u) * (unsigned)strips_y, per = (unsigned)gchunk * nstr;
+    const unsigned chunk = b / per, r = b - chunk * per;
+    frame = (chunk * gchunk + r % gchunk) * 4 + wave;
+    sid = r / gchunk;
+  }
   constexpr unsigned SX = GEO ? 16 : 15;
   const unsigned syi = sid / SX, sxi = sid % SX;
   if (syi >= (unsigned)strips_y) return;
@@ -112,15 +118,16 @@ __global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, 
   }
 }
 
+static int g_chunk = 0;
 template <int MODE, int D, int GEO = 0, int NT = 1> static void run(const char* name, const float* a, float* d, int frames, int sh) {
   const int strips_y = H / sh;
   dim3 grid((GEO ? 16 : 15) * strips_y * (frames / 4)), block(256);
-  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames);
+  for (int i = 0; i < 3; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames, g_chunk);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipEventRecord(e0));
   const int reps = 20;
-  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames);
+  for (int i = 0; i < reps; i++) hipLaunchKernelGGL((strips<MODE, D, GEO, NT>), grid, block, 0, 0, a, d, sh, strips_y, frames, g_chunk);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
@@ -143,6 +150,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill, dim3((n + 255) / 256), dim3(256), 0, 0, a, n);
   CK(hipDeviceSynchronize());
   const bool one = argc > 1;   // counter mode: one pass
+  if (argc > 2) {   // chunk sweep: gather copy in both geometries by the chunk of frame groups
+    for (int rep = 0; rep < 2; rep++)
+      for (int gc : {0, 8, 4, 2, 1}) {
+        g_chunk = gc;
+        char nm[96];
+        snprintf(nm, sizeof nm, "3 four dwords, odd offset, groups %d at a time", gc ? gc : 16);
+        run<3, 2, 1>(nm, a, d, frames, 144);
+        run<3, 2, 0>(nm, a, d, frames, 144);
+        run<6, 2, 1>("6 store stream alone, same order", a, d, frames, 144);
+      }
+    return 0;
+  }
   for (int rep = 0; rep < (one ? 1 : 2); rep++) {
     run<0, 2>("0 one dwordx4 per lane", a, d, frames, sh);
     run<1, 2>("1 four dwords per lane, interleaved", a, d, frames, sh);
