@@ -12,6 +12,11 @@ int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
+// tile_chain.hip: 0 = launched, 1 = not a chain for that kernel
+int ipa_tile_chain_launch(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const double* M,
+                          const double* ky, const double* kx, int K, void* d_dst, int dh, int dw,
+                          long dst_pitch, int n_frames, long src_frame_stride, long dst_frame_stride,
+                          int interp, int border_mode, double border_value, int cby, int cbx);
 
 static int inv3f(const double* m, double* o) {
   double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
@@ -257,6 +262,44 @@ int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_
   };
   const bool rotated = dh > 0 && dw > 0 &&
                        rotated_warp_in_two_launches(ctx, M, src_dtype, dst_dtype, interp, dh, dw, n_frames);
+  // knob tile_chain = 1: the chains that take two launches - bicubic warps, bilinear warps that rotate
+  // the picture - in ONE launch on the tile skeleton (tile_chain.hpp).  Built for the review of round
+  // 4, bit-identical, and slower than the two launches (16 x 4K + 9 + 9: bicubic 0.80 against 0.55 ms,
+  // rotated bilinear 0.87 against 0.56): the warp kernel is bound by its vector work, not by the 8 B/px
+  // of workspace traffic the fusion saves, and the filter passes join it in the same waves instead of
+  // running at stream rate in a kernel of their own.  Off by default; only calls the two launches
+  // would accept go there (anything else falls through to their checks).
+  {
+    const int base = interp & 0xff;
+    const bool cubic = base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS;
+    auto mode_ok = [](int b) { return b >= IPA_BORDER_CONSTANT && b <= IPA_BORDER_REFLECT101; };
+    const bool valid = d_src && d_dst && d_src != d_dst && ky && kx && nky == nkx && src_dtype == IPA_F32 &&
+                       dst_dtype == IPA_F32 && sh > 0 && sw > 0 && dh > 0 && dw > 0 && src_pitch >= sw &&
+                       dst_pitch >= dw && src_pitch < (1l << 23) && n_frames >= 1 && n_frames <= 65535 &&
+                       (interp & ~(0xff | IPA_INTER_Q5)) == 0 && mode_ok(border_mode) &&
+                       mode_ok(conv_border_y) && mode_ok(conv_border_x);
+    // (the two launches may write over their source - the warp has read it all by then; one launch may not)
+    auto span = [](const void* p0, long frames, long stride, long pitch, int h, int w) {
+      const char* lo = (const char*)p0;
+      return std::pair<const char*, const char*>(lo, lo + ((frames - 1) * stride + (long)(h - 1) * pitch + w) * 4);
+    };
+    bool apart = false;
+    if (valid && src_frame_stride >= 0 && dst_frame_stride >= 0) {
+      const auto a = span(d_src, n_frames, src_frame_stride, src_pitch, sh, sw);
+      const auto b = span(d_dst, n_frames, dst_frame_stride, dst_pitch, dh, dw);
+      apart = a.second <= b.first || b.second <= a.first;
+    }
+    if (ctx->tune.tile_chain && valid && apart && (cubic || base == IPA_INTER_LINEAR)) {
+      const int rc = ipa_tile_chain_launch(ctx, d_src, sh, sw, src_pitch, M, ky, kx, nky, d_dst, dh, dw,
+                                           dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
+                                           border_mode, border_value, conv_border_y, conv_border_x);
+      if (rc < 0) return rc;
+      if (rc == 0) {
+        IPA_HIP(ctx, hipGetLastError());
+        return IPA_OK;
+      }
+    }
+  }
   return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
                           dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
                           dst_frame_stride, interp, border_mode, border_value, conv_border_y,

@@ -71,6 +71,9 @@ const TuneName kTuneNames[] = {
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
     {"group_chunk", "IPA_GROUP_CHUNK", &ipa_tuning::group_chunk},
+    {"tile_chain", "IPA_TILE_CHAIN", &ipa_tuning::tile_chain},
+    {"chain_steps", "IPA_CHAIN_STEPS", &ipa_tuning::chain_steps},
+    {"chain_frames", "IPA_CHAIN_FRAMES", &ipa_tuning::chain_frames},
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
 };
@@ -84,6 +87,8 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "tile_warp") == 0) return v >= 0 && v <= 2;
   if (strcmp(name, "stored_coords") == 0) return v >= 0;
   if (strcmp(name, "group_chunk") == 0) return v >= -1 && v <= 4096;
+  if (strcmp(name, "chain_steps") == 0) return v >= 0 && v <= 64;
+  if (strcmp(name, "chain_frames") == 0) return v >= 0 && v <= 8;
   return v == 0 || v == 1;
 }
 
@@ -104,6 +109,10 @@ int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
 
 int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
+  if (strcmp(name, "chain_launches") == 0) {   // read-only counter, not a knob
+    *value = (int)(ctx->chain_launches & 0x7fffffff);
+    return IPA_OK;
+  }
   for (const TuneName& t : kTuneNames)
     if (strcmp(t.name, name) == 0) {
       *value = ctx->tune.*(t.field);

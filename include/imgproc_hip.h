@@ -87,6 +87,10 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   "stored_coords" (smallest batch whose homography / lens coordinates are evaluated once
  *   for all frames, 0 = never), "pipe", "tile_warp" (perspective warps of float32 frames with an
  *   output tile's source box in LDS: 0 never, 1 where it pays, 2 whenever the homography fits).
+ *   "tile_chain" (1: perspective warp + separable filter in one launch on the tile skeleton instead of
+ *   two launches through the workspace - same bits, slower, off by default; with "chain_steps" /
+ *   "chain_frames" = steps of 32 rows / frames per workgroup, 0 = the library's choice).
+ *   ipa_ctx_get_tuning also answers the read-only name "chain_launches" (launches of that kernel so far).
  * Values are range-checked (IPA_ERR_BAD_ARG).  ipa_ctx_create reads the IPA_* environment
  * defaults once; no launch path consults the environment.  The reference has no counterpart
  * (its numba / cv2 calls take no launch parameters). */
