@@ -23,6 +23,15 @@
 
 namespace ipa {
 
+// strip geometry of the separable kernels: as wave_geom (the 240-px step of the short kernels)
+#ifndef IPA_SEP_MIN_HL
+#define IPA_SEP_MIN_HL 2
+#endif
+template <int K> struct sep_geom {
+  static constexpr int HL = (K / 2 + 3) / 4 > IPA_SEP_MIN_HL ? (K / 2 + 3) / 4 : IPA_SEP_MIN_HL;
+  static constexpr int OW = 256 - 8 * HL;
+};
+
 template <int K> struct SepTaps {
   float ky[K], kx[K];
 };
@@ -199,10 +208,10 @@ struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> {
 template <typename Src, int K>
 __global__ void __launch_bounds__(256)
 wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
-  constexpr int H = K / 2, D = sep_depth<Src, K>::value, OW = 256 - 8;
+  constexpr int H = K / 2, D = sep_depth<Src, K>::value, HL = sep_geom<K>::HL, OW = sep_geom<K>::OW;
   constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;
   __shared__ __attribute__((aligned(16))) float xpose[kRegs ? 1 : 4 * kRowStride * D];
-  static_assert(H <= 4, "one halo lane per side");
+  static_assert(H <= 4 * HL, "the halo lanes hold the x pass's neighbours");
   const int lane = threadIdx.x & 63;
   unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
   if (p.frames_inner) {  // dispatch order of wave_stencil_kernel
@@ -231,13 +240,13 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   if (sid >= p.strips) return;
   const int syi = (int)(sid / (unsigned)p.strips_x), sxi = (int)sid - syi * p.strips_x;
   src.set_frame(frame);
-  const int xs = sxi * OW - 4;
+  const int xs = sxi * OW - 4 * HL;
   Cols c;
   c.xs = xs;
   c.xo = xs + lane * 4;
   const int y0 = syi * p.strip_h;
   const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
-  const bool writer = lane >= 1 && lane < 63 && c.xo < p.dw;
+  const bool writer = lane >= HL && lane < 64 - HL && c.xo < p.dw;
   float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
   const bool fast = !p.no_pipe && src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
@@ -285,7 +294,7 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
     w.ky[i] = (float)ky[i];
     w.kx[i] = (float)kx[i];
   }
-  p.strips_x = (p.dw + 247) / 248;
+  p.strips_x = (p.dw + sep_geom<K>::OW - 1) / sep_geom<K>::OW;
   // (the tall strips of the shared-record loop only where that loop runs, see fused_strip_piped)
   const bool shared_run = sep_shared<Src, K>::value && sep_shares_maps<Src>::value &&
                           ctx->tune.frames_wg != 0 && ctx->tune.frames_inner != 0 && n_frames % 4 == 0;

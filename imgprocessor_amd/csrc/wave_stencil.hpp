@@ -109,10 +109,20 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 //                 partial lines shared with the neighbour strip) and a 4K row takes 15 strips,
 //                 not 16: the plain 5x5 ran 1.01 -> 0.85 ms per 64 x 4K with this geometry,
 //                 the fused undistort + 5x5 1.22 -> 1.12 (tools/ab_libs.py, one box).
+#ifndef IPA_MIN_HL
+#define IPA_MIN_HL 2   // (1: the 248-px step of rounds 1 - 4)
+#endif
 template <int K, bool HALO = false> struct wave_geom {
   static constexpr int H = K / 2;
   static constexpr bool kHalo = HALO;
-  static constexpr int HL = HALO ? 0 : (H + 3) / 4;  // halo lanes per side
+  // halo lanes per side: what the window needs, and two for the short kernels (IPA_MIN_HL): their
+  // strips then step 240 px and a strip row is 960 bytes that start and end on a 64-byte sector -
+  // no sector of the result is written by two waves (the 992-byte rows of a 248-px step start 16
+  // bytes into a line).  64 x 4K undistort + 5x5: -1.2 % on a box of the fast memory class, -2.7 /
+  // -3.9 % on slow ones, same bits; the 7x7 kernels are bound by their vector work and pay 1 % for
+  // the 3 % more samples (profiles/r05_micro.txt)
+  static constexpr int kMinHL = K <= 5 ? IPA_MIN_HL : 1;
+  static constexpr int HL = HALO ? 0 : ((H + 3) / 4 > kMinHL ? (H + 3) / 4 : kMinHL);
   static constexpr int OW = 256 - 8 * HL;            // output pixels per strip row
   static constexpr int NW = 4 + 2 * H;               // window a lane needs per row
 };

@@ -130,6 +130,11 @@ def main():
             'conv5': lambda o=ops, m=mod: o.conv2d(m.src, k5, out=m.dst),
             'cubic': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'cubic', out=m.dst),
             'c3cubic': lambda o=ops, m=mod: o.warp_perspective_sepconv2d(m.src, Hq, (h, w), g9, g9, 'cubic', out=m.dst),
+            'c3lin': lambda o=ops, m=mod: o.warp_perspective_sepconv2d(m.src, Hq, (h, w), g9, g9, 'linear', out=m.dst),
+            'sepmap9': lambda o=ops, m=mod: o.remap_sepconv2d(m.src, m.dmx, m.dmy, g9, g9, out=m.dst),
+            'sepmap5': lambda o=ops, m=mod: o.remap_sepconv2d(m.src, m.dmx, m.dmy, g9[2:7] / g9[2:7].sum(), g9[2:7] / g9[2:7].sum(), out=m.dst),
+            'sep9': lambda o=ops, m=mod: o.sepconv2d(m.src, g9, g9, out=m.dst),
+            'fused3': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k5[1:4, 1:4] / k5[1:4, 1:4].sum(), out=m.dst),
             'lz4': lambda o=ops, m=mod: o.warp_perspective(m.src, Hq, (h, w), 'lanczos4', out=m.dst),
             'conv9': lambda o=ops, m=mod: o.conv2d(m.src, k9, out=m.dst),
             'conv11': lambda o=ops, m=mod: o.conv2d(m.src, k11, out=m.dst),

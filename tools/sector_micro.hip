@@ -29,7 +29,9 @@ __device__ __forceinline__ unsigned xcd_swizzle(unsigned b, unsigned n) {
 
 // GEO 0: 256-px aligned strips (15 per 4K row, all lanes store whole lines); GEO 1: the 248-px step of
 // the product's sampling kernels (16 strips per row, lanes 1 .. 62 store: 992-byte rows that start
-// 16 bytes into a line); MODE 6: no reads at all (the store stream alone)
+// 16 bytes into a line); GEO 2: a 240-px step (16 strips per row, lanes 2 .. 61 store: 960-byte rows that
+// start on a 64-byte sector and end on one - no sector of the result is written by two waves);
+// MODE 6: no reads at all (the store stream alone)
 template <int MODE, int D, int GEO = 0, int NT = 1>
 __global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, int strips_y, int frames, int gchunk = 0) {
   const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -47,10 +49,10 @@ __global__ void __launch_bounds__(256) strips(const float* a, float* d, int sh, 
   const unsigned syi = sid / SX, sxi = sid % SX;
   if (syi >= (unsigned)strips_y) return;
   const unsigned lane = threadIdx.x & 63;
-  const int xs = GEO ? (int)sxi * 248 - 4 : (int)sxi * 256;
+  const int xs = GEO == 1 ? (int)sxi * 248 - 4 : (GEO == 2 ? (int)sxi * 240 - 8 : (int)sxi * 256);
   const bool inside = xs >= 0 && xs + 256 + 16 <= W;   // (rim strips of GEO 1: skipped, 2 of 16)
   if (!inside) return;
-  const bool writer = GEO ? (lane >= 1 && lane < 63) : true;
+  const bool writer = GEO == 1 ? (lane >= 1 && lane < 63) : (GEO == 2 ? (lane >= 2 && lane < 62) : true);
   const long base = (long)frame * W * H + (long)syi * sh * W + xs;
   constexpr int OFF = (MODE == 3 || MODE == 4) ? 13 : 0;
   const float* ap = a + base + OFF;
@@ -132,7 +134,7 @@ template <int MODE, int D, int GEO = 0, int NT = 1> static void run(const char* 
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   ms /= reps;
   // (GEO 1 skips its two rim strips of 16: the time is scaled to the whole frame)
-  if (GEO) ms *= 3840.0 / (14 * 248);
+  if (GEO) ms *= 3840.0 / (14 * (GEO == 2 ? 240 : 248));
   printf("%-56s D=%d geo %d nt %d  %8.1f us  %6.0f GB/s\n", name, D, GEO, NT, ms * 1e3, (MODE == 6 ? 1.0 : 2.0) * frames * W * H * 4 / (ms * 1e-3) / 1e9);
   fflush(stdout);
 }
@@ -150,6 +152,18 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill, dim3((n + 255) / 256), dim3(256), 0, 0, a, n);
   CK(hipDeviceSynchronize());
   const bool one = argc > 1;   // counter mode: one pass
+  if (argc > 3) {   // the three geometries under the product's dispatch order (frame groups 4 at a time), 144-row strips
+    g_chunk = 4;
+    for (int rep = 0; rep < 3; rep++) {
+      run<3, 2, 0>("3 gather copy", a, d, frames, 144);
+      run<3, 2, 1>("3 gather copy", a, d, frames, 144);
+      run<3, 2, 2>("3 gather copy", a, d, frames, 144);
+      run<6, 2, 0>("6 store stream alone", a, d, frames, 144);
+      run<6, 2, 1>("6 store stream alone", a, d, frames, 144);
+      run<6, 2, 2>("6 store stream alone", a, d, frames, 144);
+    }
+    return 0;
+  }
   if (argc > 2) {   // chunk sweep: gather copy in both geometries by the chunk of frame groups
     for (int rep = 0; rep < 2; rep++)
       for (int gc : {0, 8, 4, 2, 1}) {
