@@ -627,13 +627,14 @@ def main():
                          'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
                          'compulsory_bytes_per_step': compulsory,
-                         'limiter': 'the stream rate of the marching-strip shape in the 248-px geometry of the '
-                                    'sampling kernels (a gather COPY in that shape - same strips, same order, same '
-                                    'stores, no arithmetic - runs 0.80 - 0.97 ms by the box, tools/sector_micro.hip: '
-                                    '992-byte rows that start 16 bytes into a line) with the vector work (0.47 ms '
-                                    'of issue time) next to it; the aligned geometry streams 15 - 20 % faster but '
-                                    'its halo samples cost more than that (profiles/r05_micro.txt); HBM is the '
-                                    'roofline the compulsory bytes are priced against, not what saturates',
+                         'limiter': 'the stream rate of the marching-strip shape of the sampling kernels (a gather '
+                                    'COPY in that shape - same strips, same order, same stores, no arithmetic - runs '
+                                    '0.93 ms on a slow-class box with the 240-px strip step of the library, 0.99 with '
+                                    'the 248-px step of rounds 1 - 4, 0.82 on 256-px aligned strips: '
+                                    'tools/sector_micro.hip) with the vector work (0.47 ms of issue time) next to it; '
+                                    'the aligned geometry streams faster still but its halo samples cost more than '
+                                    'that (profiles/r05_micro.txt); HBM is the roofline the compulsory bytes are '
+                                    'priced against, not what saturates',
                          'kernel': kname, 'launches_per_step': launches,
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
                          'literal_survey_8d': {
