@@ -112,6 +112,12 @@ template <int I, int N, typename F> __device__ __forceinline__ void static_for(F
 #ifndef IPA_MIN_HL
 #define IPA_MIN_HL 2   // (1: the 248-px step of rounds 1 - 4)
 #endif
+#ifndef IPA_MIN_HL_K7
+#define IPA_MIN_HL_K7 1
+#endif
+#ifndef IPA_MIN_HL_K9
+#define IPA_MIN_HL_K9 2
+#endif
 template <int K, bool HALO = false> struct wave_geom {
   static constexpr int H = K / 2;
   static constexpr bool kHalo = HALO;
@@ -120,8 +126,8 @@ template <int K, bool HALO = false> struct wave_geom {
   // no sector of the result is written by two waves (the 992-byte rows of a 248-px step start 16
   // bytes into a line).  64 x 4K undistort + 5x5: -1.2 % on a box of the fast memory class, -2.7 /
   // -3.9 % on slow ones, same bits; the 7x7 kernels are bound by their vector work and pay 1 % for
-  // the 3 % more samples (profiles/r05_micro.txt)
-  static constexpr int kMinHL = K <= 5 ? IPA_MIN_HL : 1;
+  // the 3 % more samples; 9x9: -1.6 % fused, -0.8 % plain (profiles/r05_micro.txt)
+  static constexpr int kMinHL = K <= 5 ? IPA_MIN_HL : (K == 7 ? IPA_MIN_HL_K7 : (K == 9 ? IPA_MIN_HL_K9 : 1));
   static constexpr int HL = HALO ? 0 : ((H + 3) / 4 > kMinHL ? (H + 3) / 4 : kMinHL);
   static constexpr int OW = 256 - 8 * HL;            // output pixels per strip row
   static constexpr int NW = 4 + 2 * H;               // window a lane needs per row
