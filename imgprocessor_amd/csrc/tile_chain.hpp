@@ -24,7 +24,12 @@
 // resolved index (reflect, mirror, nearest, wrap), or the filter's cval.  Arithmetic and order are
 // those of the two launches - sample() of sampler.hpp, then wave_sep.hpp's ascending fma chains
 // with the intermediate rounded to float32 - so the results have the same bits
-// (tests/test_gpu_tile_chain.py).
+// (tests/test_gpu_tile_chain.py, tools/fuzz_chain.py).
+//
+// Status (round 5): behind the knob tile_chain, OFF.  16 x 4K + 9 + 9: bicubic 0.80 ms against 0.55
+// for the two launches, bilinear under 15 degrees 0.87 against 0.56 - the tile warp is bound by its
+// vector work, not by the workspace traffic this kernel saves, and the filter passes run in the same
+// waves at 3 workgroups per CU instead of at stream rate in wave_sep.hpp (profiles/r05_micro.txt).
 #pragma once
 
 #include "tile_warp.hpp"
