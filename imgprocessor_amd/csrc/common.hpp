@@ -35,8 +35,9 @@ struct ipa_tuning {
   int group_chunk = -1;   // batches on the shared-record loop: frame groups walked this many at a time (-1: a
                           // quarter of them, 0: all groups of a strip together); see wave_grid
   int tile_chain = 0;     // 1: perspective warp + separable filter in ONE launch on the tile skeleton (tile_chain.hpp)
-                          // wherever that kernel covers the chain.  Off: built, bit-identical to the two launches
-                          // through the workspace, and 25 - 50 % slower (profiles/r05_micro.txt)
+                          // for the chains that take two launches (bicubic; bilinear under a rotation); 2: wherever
+                          // that kernel covers the chain.  Off: built, bit-identical to the two launches through the
+                          // workspace, and 25 - 50 % slower (profiles/r05_micro.txt)
   int chain_steps = 0;    // ... steps of 32 rows a workgroup walks down its column (0: 4)
   int chain_frames = 0;   // ... frames per workgroup (0: up to 8, by launch size)
   int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
@@ -51,6 +52,9 @@ struct ipa_tuning {
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
   int tile_warp = 1;      // perspective warps of float32 frames with the tile's source box in LDS (tile_warp.hpp):
                           // 0 never, 1 where it pays, 2 whenever the homography is covered
+  int rank1_sep = 3;      // dense K x K kernels that are an exact outer product ky (x) kx (how the reference obtains its
+                          // Gaussians: scipy.ndimage.gaussian_filter, filters/fastFilter.py:42) run on the separable K + K
+                          // loops wherever those cover the call: bit 0 the remap -> filter chains, bit 1 the plain filter
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates
                           // are evaluated ONCE into the plan buffer and the gather kernel reads them (0: never)
@@ -94,6 +98,8 @@ struct ipa_ctx {
     unsigned long used = 0;
   } tile_warp_plans[kTileWarpPlans];
   unsigned long tile_warp_clock = 0;
+  unsigned long rank1_routed = 0;     // dense calls sent to the separable loops so far (read through ipa_ctx_get_tuning)
+  int group_chunk_used = 0;           // groups per chunk of the last launch on the shared-record loop (0: all together)
   unsigned long chain_launches = 0;   // launches of tile_chain.hpp's kernel (read through ipa_ctx_get_tuning: the tests' evidence of the path taken)
   // map remaps on the tile kernel: per (map pair, geometry) - least recently used of kTileSlowHints
   // replaced - a device word the kernel counts its tap-by-tap pixels in, the page-locked word it is
@@ -162,6 +168,30 @@ int ipa_tab_upload(ipa_ctx* ctx, const void* host, size_t bytes, void** d);  // 
     ipa_set_error(ctx, __VA_ARGS__);         \
     return IPA_ERR_UNSUPPORTED;              \
   } while (0)
+
+// Is the kh x kw kernel an outer product ky (x) kx to within 1e-12 of its largest entry (five orders below what a
+// float32 coefficient resolves)?  Pivot on that entry: ky = its column, kx = its row / pivot.  Zero and non-finite
+// kernels are not.  Host code; the dense and the separable loops then differ by summation order only.
+static inline bool ipa_rank1_factor(const double* k, int kh, int kw, double* ky, double* kx) {
+  int i0 = 0, j0 = 0;
+  double piv = 0.0;
+  for (int i = 0; i < kh; i++)
+    for (int j = 0; j < kw; j++) {
+      const double v = k[i * kw + j];
+      if (!(v - v == 0.0)) return false;  // inf / nan
+      if ((v < 0 ? -v : v) > (piv < 0 ? -piv : piv)) { piv = v; i0 = i; j0 = j; }
+    }
+  if (piv == 0.0) return false;
+  for (int i = 0; i < kh; i++) ky[i] = k[i * kw + j0];
+  for (int j = 0; j < kw; j++) kx[j] = k[i0 * kw + j] / piv;
+  const double tol = 1e-12 * (piv < 0 ? -piv : piv);
+  for (int i = 0; i < kh; i++)
+    for (int j = 0; j < kw; j++) {
+      const double d = ky[i] * kx[j] - k[i * kw + j];
+      if ((d < 0 ? -d : d) > tol) return false;
+    }
+  return true;
+}
 
 static inline size_t ipa_dtype_size(int dt) {
   switch (dt) {

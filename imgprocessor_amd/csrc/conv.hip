@@ -42,6 +42,10 @@ struct ConvParams {
 };
 
 // stage rows [y0-KH/2, ...) x cols [x0-HX, x0+128+HX) of the frame into LDS
+#ifndef IPA_RANK1_PLAIN_MIN
+#define IPA_RANK1_PLAIN_MIN 9
+#endif
+
 template <typename T, int KH, int KW>
 __device__ __forceinline__ void fill_tile_global(T* __restrict__ tile, const T* __restrict__ src,
                                                  const ConvParams& p, int x0, int y0) {
@@ -482,6 +486,21 @@ int ipa_conv2d_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w, lon
   if (rc) return rc;
   if (dtype != IPA_F32 && dtype != IPA_F64)
     IPA_UNSUPPORTED(ctx, "conv2d supports float32/float64 images (got dtype %d)", dtype);
+  // an outer product ky (x) kx on the separable K + K loop (wave_sep.hpp) - knob rank1_sep bit 1.  A constant
+  // border with a non-zero value does not factor (the second pass would pad the first pass's output with
+  // cval instead of cval * sum(ky)): those calls stay dense.
+  // (measured, 64 x 4K, ms dense / separable: 3 taps 0.82 / 1.02, 5: 0.82 / 1.00, 7: 0.94 / 0.99, 9: 1.14 / 0.97 -
+  // the dense loops keep their rows in registers at stream rate up to 7 x 7: only 9 x 9 goes)
+  if ((ctx->tune.rank1_sep & 2) && dtype == IPA_F32 && !d_mask && kh == kw && kh >= IPA_RANK1_PLAIN_MIN &&
+      (kh == 3 || kh == 5 || kh == 7 || kh == 9) &&
+      (border_value == 0.0 || (border_x != IPA_BORDER_CONSTANT && border_y != IPA_BORDER_CONSTANT))) {
+    double ky[9], kx[9];
+    if (ipa_rank1_factor(kernel, kh, kw, ky, kx)) {
+      ctx->rank1_routed++;
+      return ipa_sepconv2d_dev(ctx, d_src, dtype, h, w, src_pitch, ky, kh, kx, kw, d_dst, dst_pitch, n_frames,
+                               src_frame_stride, dst_frame_stride, border_y, border_x, border_value);
+    }
+  }
   size_t es = ipa_dtype_size(dtype);
   ConvParams p;
   p.src = (const char*)d_src; p.dst = (char*)d_dst;

@@ -30,6 +30,20 @@ static int inv3f(const double* m, double* o) {
   return 0;
 }
 
+// Dense K x K kernels that are an outer product ky (x) kx - the bench's 5x5 is outer(g, g), and the reference itself
+// obtains its Gaussians separably (scipy.ndimage.gaussian_filter: filters/standardDeviation.py:23,
+// filters/fastFilter.py:42) - run on the separable K + K chain when that chain is ONE kernel for the call
+// (fused_sep_common's one_kernel: float32 frames, bilinear taps, 3 / 5 / 7 / 9 taps).  64 x 4K maps + 5x5: K + K
+// = 10 instead of K * K = 25 multiply-adds per pixel on the same strips.  Knob rank1_sep bit 0; the two loops
+// differ by the order of a float32 sum only (both within 1e-5 of the oracle's double sum).
+static bool rank1_chain(ipa_ctx* ctx, const double* kernel, int kh, int kw, int src_dtype, int dst_dtype,
+                        int interp, double* ky, double* kx) {
+  if (!(ctx->tune.rank1_sep & 1) || !kernel || kh != kw) return false;
+  if (!(kh == 3 || kh == 5 || kh == 7 || kh == 9)) return false;
+  if (src_dtype != IPA_F32 || dst_dtype != IPA_F32 || (interp & 0xff) != IPA_INTER_LINEAR) return false;
+  return ipa_rank1_factor(kernel, kh, kw, ky, kx);
+}
+
 // K = 9, 11: map-based bilinear remaps of float32 frames run in one kernel (fused_big.hip);
 // for the rest (bicubic, analytic coordinates, uint16 frames) the sampling source plus 9 / 11
 // running rows exceed the VGPR budget that pays: the chain runs as two launches through the
@@ -289,7 +303,10 @@ int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_
       const auto b = span(d_dst, n_frames, dst_frame_stride, dst_pitch, dh, dw);
       apart = a.second <= b.first || b.second <= a.first;
     }
-    if (ctx->tune.tile_chain && valid && apart && (cubic || base == IPA_INTER_LINEAR)) {
+    // (1: the chains that take two launches - bicubic, rotated bilinear; 2: every chain the kernel covers, upright
+    // bilinear ones included, which the fused strip kernel already runs in one launch - the tests' value)
+    if (ctx->tune.tile_chain && valid && apart &&
+        (cubic || (base == IPA_INTER_LINEAR && (rotated || ctx->tune.tile_chain >= 2)))) {
       const int rc = ipa_tile_chain_launch(ctx, d_src, sh, sw, src_pitch, M, ky, kx, nky, d_dst, dh, dw,
                                            dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp,
                                            border_mode, border_value, conv_border_y, conv_border_x);
@@ -314,6 +331,16 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
                          int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  {
+    double ky[9], kx[9];
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx)) {
+      ctx->rank1_routed++;
+      return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, ky, kh,
+                                     kx, kw, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                     dst_frame_stride, interp, border_mode, border_value, conv_border_y,
+                                     conv_border_x);
+    }
+  }
   // 9x9 / 11x11 on float32 frames: one kernel (fused_big.hip); big_fused = 0 is the tuning
   // knob that sends them through the two launches below instead
   const bool big_fused = ctx->tune.big_fused != 0;
@@ -380,6 +407,16 @@ int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                              int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
+  {
+    double ky[9], kx[9];
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx)) {
+      ctx->rank1_routed++;
+      return ipa_undistort_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, ky, kh, kx, kw,
+                                         d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                         dst_frame_stride, interp, border_mode, border_value, conv_border_y,
+                                         conv_border_x);
+    }
+  }
   if (ctx->tune.lens_cache) {
     // the model's float32 coordinates are the same for every frame and every call with these
     // parameters: evaluate them once (bit for bit what the per-pixel evaluation gives) and run
@@ -424,6 +461,16 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
                                     double border_value, int conv_border_x, int conv_border_y) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, M, "null matrix");
+  {
+    double ky[9], kx[9];
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx)) {
+      ctx->rank1_routed++;
+      return ipa_warp_perspective_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, ky, kh, kx, kw, d_dst,
+                                                dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                                dst_frame_stride, interp, border_mode, border_value,
+                                                conv_border_y, conv_border_x);
+    }
+  }
   void* tmp = nullptr;
   int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;

@@ -113,7 +113,7 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   using G = wave_geom<K, geom_halo<Src, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, f.n_frames, K, false,
-                                fused_strip_piped<Src, K>(ctx, f.n_frames));
+                                fused_strip_piped<Src, K>(ctx, f.n_frames), p.strips_x);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   // frames of one strip block run together: map-based remaps share their map rows between
   // frames (L2 fetch traffic -62 % on 16 x 4K), and even without shared rows the order measured
@@ -183,7 +183,7 @@ int IPA_CAT(ipa_wave_conv_launch_k, IPA_FUSED_K)(ipa_ctx* ctx, const ipa::WavePa
   using G = wave_geom<K, geom_halo<LoadRowSrc, K, false>::value>;
   p.strips_x = (p.dw + G::OW - 1) / G::OW;
   p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false,
-                                pipe_capable<LoadRowSrc, K>::value && IPA_PIPE ? 1 : 0);
+                                pipe_capable<LoadRowSrc, K>::value && IPA_PIPE ? 1 : 0, p.strips_x);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
   dim3 grid = wave_grid(ctx, p, n_frames, IPA_WPB, true, false, true), block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_kernel<LoadRowSrc, K>), grid, block, 0, ctx->stream, p, src, w);

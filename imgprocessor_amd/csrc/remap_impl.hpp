@@ -607,12 +607,29 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
                       (double)p.dh, (double)p.dw, (double)p.sh, (double)p.sw, (double)INTERP,
                       (double)p.border, (double)p.q5};
     if (!ctx->tile_slow_dev) {
-      IPA_HIP(ctx, hipMalloc((void**)&ctx->tile_slow_dev, ipa_ctx::kTileSlowHints * sizeof(unsigned)));
-      IPA_HIP(ctx, hipHostMalloc((void**)&ctx->tile_slow_host, ipa_ctx::kTileSlowHints * sizeof(unsigned)));
-      for (int k = 0; k < ipa_ctx::kTileSlowHints; k++) {
-        ctx->tile_slow_host[k] = 0;
-        IPA_HIP(ctx, hipEventCreateWithFlags(&ctx->tile_slow[k].copied, hipEventDisableTiming));
+      // all or nothing: the words and the events are published to the context only once every one of them
+      // exists - a failure half way frees what it made and leaves the hint state absent, so that the next
+      // call tries again; this call goes to the ring / gather kernels (return 1: "not taken")
+      unsigned *dev = nullptr, *host = nullptr;
+      hipEvent_t evs[ipa_ctx::kTileSlowHints] = {};
+      bool ok = hipMalloc((void**)&dev, ipa_ctx::kTileSlowHints * sizeof(unsigned)) == hipSuccess &&
+                hipHostMalloc((void**)&host, ipa_ctx::kTileSlowHints * sizeof(unsigned)) == hipSuccess;
+      for (int k = 0; ok && k < ipa_ctx::kTileSlowHints; k++)
+        ok = hipEventCreateWithFlags(&evs[k], hipEventDisableTiming) == hipSuccess;
+      if (!ok) {
+        for (hipEvent_t e : evs)
+          if (e) (void)hipEventDestroy(e);
+        if (host) (void)hipHostFree(host);
+        if (dev) (void)hipFree(dev);
+        (void)hipGetLastError();
+        return 1;
       }
+      for (int k = 0; k < ipa_ctx::kTileSlowHints; k++) {
+        host[k] = 0;
+        ctx->tile_slow[k].copied = evs[k];
+      }
+      ctx->tile_slow_host = host;
+      ctx->tile_slow_dev = dev;
     }
     for (int k = 0; k < ipa_ctx::kTileSlowHints; k++)
       if (ctx->tile_slow[k].valid && memcmp(key, ctx->tile_slow[k].key, sizeof key) == 0) { hint = &ctx->tile_slow[k]; hslot = k; }

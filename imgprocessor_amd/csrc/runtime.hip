@@ -76,6 +76,7 @@ const TuneName kTuneNames[] = {
     {"chain_frames", "IPA_CHAIN_FRAMES", &ipa_tuning::chain_frames},
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
+    {"rank1_sep", "IPA_RANK1_SEP", &ipa_tuning::rank1_sep},
 };
 }  // namespace
 
@@ -89,6 +90,8 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "group_chunk") == 0) return v >= -1 && v <= 4096;
   if (strcmp(name, "chain_steps") == 0) return v >= 0 && v <= 64;
   if (strcmp(name, "chain_frames") == 0) return v >= 0 && v <= 8;
+  if (strcmp(name, "rank1_sep") == 0) return v >= 0 && v <= 3;
+  if (strcmp(name, "tile_chain") == 0) return v >= 0 && v <= 2;
   return v == 0 || v == 1;
 }
 
@@ -111,6 +114,14 @@ int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
   if (strcmp(name, "chain_launches") == 0) {   // read-only counter, not a knob
     *value = (int)(ctx->chain_launches & 0x7fffffff);
+    return IPA_OK;
+  }
+  if (strcmp(name, "rank1_routed") == 0) {
+    *value = (int)(ctx->rank1_routed & 0x7fffffff);
+    return IPA_OK;
+  }
+  if (strcmp(name, "group_chunk_used") == 0) {
+    *value = ctx->group_chunk_used;
     return IPA_OK;
   }
   for (const TuneName& t : kTuneNames)

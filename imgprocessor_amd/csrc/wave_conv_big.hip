@@ -16,7 +16,7 @@ static int launch_wave_conv_big(ipa_ctx* ctx, const WaveParams& p0, const LoadRo
     for (int j = 0; j < 12; j++) a.wrows[i][j] = j < K ? (float)kernel[i * K + j] : 0.f;
   using G = wave_geom<K>;
   a.p.strips_x = (a.p.dw + G::OW - 1) / G::OW;
-  a.p.strip_h = wave_strip_height(ctx, a.p.dh, a.p.dw, n_frames, K, true);
+  a.p.strip_h = wave_strip_height(ctx, a.p.dh, a.p.dw, n_frames, K, true, 0, a.p.strips_x);
   a.p.strips = (unsigned)a.p.strips_x * (unsigned)((a.p.dh + a.p.strip_h - 1) / a.p.strip_h);
   dim3 grid = wave_grid(ctx, a.p, n_frames, IPA_WPB, true, false, true), block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_big_kernel<LoadRowSrc, K>), grid, block, 0, ctx->stream, a);

@@ -203,12 +203,8 @@ template <int K>
 __device__ __forceinline__ v4f pipe_filter_row(const Weights<float, K * K>& wts, const float* xp,
                                                unsigned lane, unsigned lane4_opaque,
                                                v2f (&acc)[K][2]) {
-  using G = wave_geom<K>;
-  const float* wp = xp + kRowPad - G::H + 4u * lane;
-  const float* wq = xp + kRowPad - G::H + lane4_opaque;
   v2f pair[K + 2];
-#pragma unroll
-  for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+  window_pairs<K>(xp, lane, lane4_opaque, pair);
   // coefficient n = i K + j is one half of the SGPR pair {w[n & ~1], w[(n & ~1) + 1]}, broadcast
   // by op_sel: K K / 2 scalar pairs instead of the K K {w, w} pairs the compiler forms (which
   // spill to VGPR lanes: 45 v_readlane per row in the first build of this loop)

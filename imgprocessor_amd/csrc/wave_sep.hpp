@@ -44,6 +44,61 @@ template <typename Src, int K> struct sep_depth {
 };
 template <int K> struct sep_depth<LoadRowSrc, K> { static constexpr int value = 4; };
 
+// The two passes in packed float32 (round 6): a lane's four pixels are two register pairs, one v_pk_fma_f32 per tap
+// advances a pair - K + K packed fmas per row and lane instead of 4 K + 4 K scalar ones (the taps are halves of SGPR
+// pairs broadcast by op_sel, as in the dense loops).  Each half of a packed fma is the scalar fma of the same
+// operands in the same order: same bits as the scalar form (IPA_SEP_PACKED = 0 builds that one).
+#ifndef IPA_SEP_PACKED
+#define IPA_SEP_PACKED 1
+#endif
+template <int K, int I> __device__ __forceinline__ v2f sep_tap_pair(const float (&k)[K]) {
+  constexpr int n0 = I & ~1, n1 = n0 + 1 < K ? n0 + 1 : n0;
+  return v2f{k[n0], k[n1]};
+}
+// y pass: the arriving row (c0, c1 = pixel pairs) feeds the K running intermediate rows; acc[K - 1] completes
+template <int K>
+__device__ __forceinline__ void sep_y_pass(const SepTaps<K>& w, v2f (&acc)[K][2], v2f c0, v2f c1) {
+  static_for<0, K>([&](auto Ii) {
+    constexpr int i = K - 1 - decltype(Ii)::value;
+    const v2f t = sep_tap_pair<K, i>(w.ky);
+    if constexpr (i == 0) {
+      acc[0][0] = pk_mul_coef<(i & 1)>(t, c0);
+      acc[0][1] = pk_mul_coef<(i & 1)>(t, c1);
+    } else {
+      acc[i][0] = pk_fma_coef<(i & 1)>(t, c0, acc[i - 1][0]);
+      acc[i][1] = pk_fma_coef<(i & 1)>(t, c1, acc[i - 1][1]);
+    }
+  });
+}
+// x pass on a completed intermediate row: K / 2 neighbours per side from the adjacent lanes (DPP wave shifts)
+template <int K>
+__device__ __forceinline__ v4f sep_x_pass(const SepTaps<K>& w, const float (&mid)[4]) {
+  constexpr int H = K / 2;
+  static_assert(H >= 1 && H <= 4, "3 .. 9 taps");
+  // win[m] = intermediate pixel 4 L - H + m, m = 0 .. 3 + 2 H, held as the pairs (2 n, 2 n + 1) when H is even and
+  // (2 n - 1, 2 n) when it is odd, so that the lane's own four pixels are its own two register pairs either way
+  float win[4 + 2 * H];
+#pragma unroll
+  for (int k = 0; k < 4; k++) win[H + k] = mid[k];
+#pragma unroll
+  for (int m = 0; m < H; m++) {
+    win[H - 1 - m] = from_lane_below(mid[3 - m]);
+    win[H + 4 + m] = from_lane_above(mid[m]);
+  }
+  v2f out[2];
+  static_for<0, K>([&](auto Jj) {
+    constexpr int j = decltype(Jj)::value;
+    const v2f t = sep_tap_pair<K, j>(w.kx);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const v2f x = v2f{win[2 * h + j], win[2 * h + j + 1]};
+      if constexpr (j == 0) out[h] = pk_mul_coef<(j & 1)>(t, x);
+      else out[h] = pk_fma_coef<(j & 1)>(t, x, out[h]);
+    }
+  });
+  return v4f{out[0].x, out[0].y, out[1].x, out[1].y};
+}
+
 template <bool FAST, typename Src, int K, int QM = -1>
 __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& src,
                                                const SepTaps<K>& w, float* xp, const Cols& c,
@@ -54,6 +109,7 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& s
   constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;  // rows stay in registers
   const int T = nrows + K - 1;
   float acc[K][4];  // acc[i] = y-sum of intermediate row (t - i)
+  v2f acc2[K][2];   // ... as pixel pairs (IPA_SEP_PACKED; only one of the two forms is live)
 #pragma unroll 1
   for (int tb = 0; tb < T; tb += D) {
     int vv[D];
@@ -83,41 +139,55 @@ __device__ __forceinline__ void wave_sep_strip(const WaveParams& p, const Src& s
       }
 
       // y pass: the arriving row feeds K intermediate rows
-      static_for<0, K>([&](auto Ii) {
-        constexpr int i = K - 1 - decltype(Ii)::value;
+      if constexpr (IPA_SEP_PACKED != 0) {
+        sep_y_pass<K>(w, acc2, v2f{cur[0], cur[1]}, v2f{cur[2], cur[3]});
+      } else {
+        static_for<0, K>([&](auto Ii) {
+          constexpr int i = K - 1 - decltype(Ii)::value;
 #pragma unroll
-        for (int ox = 0; ox < 4; ox++) {
-          if constexpr (i == 0) acc[0][ox] = w.ky[0] * cur[ox];
-          else acc[i][ox] = fmaf(w.ky[i], cur[ox], acc[i - 1][ox]);
-        }
-      });
+          for (int ox = 0; ox < 4; ox++) {
+            if constexpr (i == 0) acc[0][ox] = w.ky[0] * cur[ox];
+            else acc[i][ox] = fmaf(w.ky[i], cur[ox], acc[i - 1][ox]);
+          }
+        });
+      }
 
       const int o = t - (K - 1);
       if (o >= 0 && o < nrows) {  // wave-uniform: intermediate row o is complete
         float mid[4];
+        if constexpr (IPA_SEP_PACKED != 0) {
+          mid[0] = acc2[K - 1][0].x; mid[1] = acc2[K - 1][0].y;
+          mid[2] = acc2[K - 1][1].x; mid[3] = acc2[K - 1][1].y;
+        } else {
 #pragma unroll
-        for (int k = 0; k < 4; k++) mid[k] = acc[K - 1][k];
+          for (int k = 0; k < 4; k++) mid[k] = acc[K - 1][k];
+        }
         if constexpr (!FAST) {
           // constant x border: scipy pads the INTERMEDIATE with cval
 #pragma unroll
           for (int k = 0; k < 4; k++)
             if (c.uu[k] < 0) mid[k] = xcval;
         }
-        float win[4 + 2 * H];
-#pragma unroll
-        for (int k = 0; k < 4; k++) win[H + k] = mid[k];
-#pragma unroll
-        for (int m = 0; m < H; m++) {
-          win[H - 1 - m] = from_lane_below(mid[3 - m]);
-          win[H + 4 + m] = from_lane_above(mid[m]);
-        }
         float out[4];
+        if constexpr (IPA_SEP_PACKED != 0) {
+          const v4f q = sep_x_pass<K>(w, mid);
+          out[0] = q.x; out[1] = q.y; out[2] = q.z; out[3] = q.w;
+        } else {
+          float win[4 + 2 * H];
 #pragma unroll
-        for (int ox = 0; ox < 4; ox++) {
-          float a = w.kx[0] * win[ox];
+          for (int k = 0; k < 4; k++) win[H + k] = mid[k];
 #pragma unroll
-          for (int j = 1; j < K; j++) a = fmaf(w.kx[j], win[ox + j], a);
-          out[ox] = a;
+          for (int m = 0; m < H; m++) {
+            win[H - 1 - m] = from_lane_below(mid[3 - m]);
+            win[H + 4 + m] = from_lane_above(mid[m]);
+          }
+#pragma unroll
+          for (int ox = 0; ox < 4; ox++) {
+            float a = w.kx[0] * win[ox];
+#pragma unroll
+            for (int j = 1; j < K; j++) a = fmaf(w.kx[j], win[ox + j], a);
+            out[ox] = a;
+          }
         }
         if (writer) {
           float* row = dst + (long)(y0 + o) * p.dpitch + c.xo;
@@ -147,11 +217,23 @@ template <int K> struct SepFilter {
   const SepTaps<K>& w;
   float xcval;
   float acc[K][4];
+  v2f acc2[K][2];   // (IPA_SEP_PACKED: the running rows as pixel pairs; only one of the two forms is live)
   __device__ __forceinline__ SepFilter(const SepTaps<K>& taps, float xc) : w(taps), xcval(xc) {}
   template <bool EDGE> __device__ __forceinline__ v4f row(const float* xp, unsigned lane, const Cols& c) {
     constexpr int H = K / 2;
     const float4 q = *reinterpret_cast<const float4*>(xp + kRowPad + 4u * lane);
     const float cur[4] = {q.x, q.y, q.z, q.w};
+    if constexpr (IPA_SEP_PACKED != 0) {
+      sep_y_pass<K>(w, acc2, v2f{cur[0], cur[1]}, v2f{cur[2], cur[3]});
+      float mid[4] = {acc2[K - 1][0].x, acc2[K - 1][0].y, acc2[K - 1][1].x, acc2[K - 1][1].y};
+      if constexpr (EDGE) {
+        // constant x border: scipy pads the INTERMEDIATE with cval
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (c.uu[k] < 0) mid[k] = xcval;
+      }
+      return sep_x_pass<K>(w, mid);
+    }
     static_for<0, K>([&](auto Ii) {
       constexpr int i = K - 1 - decltype(Ii)::value;
 #pragma unroll
@@ -214,7 +296,10 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   static_assert(H <= 4 * HL, "the halo lanes hold the x pass's neighbours");
   const int lane = threadIdx.x & 63;
   unsigned b = xcd_swizzle(blockIdx.x, gridDim.x), frame = blockIdx.y;
-  if (p.frames_inner) {  // dispatch order of wave_stencil_kernel
+  if (p.frame_major) {   // dispatch orders of wave_stencil_kernel
+    frame = b / p.frame_major;
+    b -= frame * p.frame_major;
+  } else if (p.frames_inner) {
     frame = b % (unsigned)p.frames_inner;
     b /= (unsigned)p.frames_inner;
   }
@@ -298,9 +383,14 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
   // (the tall strips of the shared-record loop only where that loop runs, see fused_strip_piped)
   const bool shared_run = sep_shared<Src, K>::value && sep_shares_maps<Src>::value &&
                           ctx->tune.frames_wg != 0 && ctx->tune.frames_inner != 0 && n_frames % 4 == 0;
-  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false, shared_run ? 2 : 0);
+  // plain rows: the short strips of the plain dense filters (64 x 4K, 9 + 9 taps: 72 rows 0.906, 24 rows 0.882 ms)
+  p.strip_h = wave_strip_height(ctx, p.dh, p.dw, n_frames, K, false,
+                                shared_run ? 2 : (std::is_same<Src, LoadRowSrc>::value ? 1 : 0), p.strips_x);
   p.strips = (unsigned)p.strips_x * (unsigned)((p.dh + p.strip_h - 1) / p.strip_h);
-  dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value), block(256);
+  // plain rows (LoadRowSrc): frames share nothing - frame after frame, every XCD streaming through frames of its
+  // own (knob frame_major, as the dense plain filters since round 4)
+  dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value,
+                        std::is_same<Src, LoadRowSrc>::value), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 

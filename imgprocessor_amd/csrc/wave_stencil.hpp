@@ -167,7 +167,7 @@ struct WaveParams {
 
 // grid for a launch over n_frames; fills p.frames_inner
 // share_maps: the row source reads a coordinate table the frames of a batch share (MapCoord)
-static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, int waves_per_block,
+static inline dim3 wave_grid(ipa_ctx* ctx, WaveParams& p, int n_frames, int waves_per_block,
                              bool frames_inner, bool share_maps = false,
                              bool may_frame_major = false) {
   unsigned blocks = (p.strips + waves_per_block - 1) / waves_per_block;
@@ -195,10 +195,18 @@ static inline dim3 wave_grid(const ipa_ctx* ctx, WaveParams& p, int n_frames, in
     // linear stores are level everywhere, tools/region_micro.hip -; a store-only probe does not gain from
     // this order, the whole kernel does on every box: reads, shared map rows and stores of a chunk meet
     // in the same L2s)
+    // A chunk size that does not divide the group count (20, 28, 36 ... frames) goes to the NEAREST divisor
+    // (ties: the smaller) - it fell back to 0 without a trace until round 5; the value chosen is
+    // read back as "group_chunk_used" (ipa_ctx_get_tuning).
     {
       int gc = ctx->tune.group_chunk;
       if (gc < 0) gc = groups >= 4 ? groups / 4 : 0;
-      p.group_chunk = (gc > 0 && gc < groups && groups % gc == 0) ? gc : 0;
+      int best = 0;
+      if (gc > 0 && gc < groups)
+        for (int d = 1; d < groups; d++)
+          if (groups % d == 0 && (best == 0 || abs(d - gc) < abs(best - gc))) best = d;
+      p.group_chunk = best;
+      ctx->group_chunk_used = best;
     }
     return dim3(p.strips * (unsigned)groups, 1);
   }
@@ -521,6 +529,48 @@ template <int HI> __device__ __forceinline__ v2f pk_mul_coef(v2f wp, v2f x) {
   return d;
 }
 
+// The K + 2 overlapping pairs of a lane's window out of its wave's LDS row.
+// Rounds 1 - 5 read every pair with a ds_read_b64 of its own: lanes at a 16-byte stride reading 8 bytes use half
+// of the 64 banks, and lanes L and L + 16 of a 32-lane group meet on the same ones - a 2-way conflict on every
+// read (SQ_LDS_BANK_CONFLICT = 38 % of the C4 launch's cycles, profiles/r05_micro.txt).  IPA_WINDOW_B128 (round
+// 6): the 12 floats 4 L - 4 .. 4 L + 7 that hold every window up to 9 taps arrive as THREE aligned 16-byte reads
+// (ds_read_b128: 16 lanes x 16 bytes cover the 64 banks exactly - conflict-free, 12 LDS cycles per row instead of
+// 4 (K + 2)); the pairs that start on an odd float are formed from two register pairs with one v_pk_mov_b32
+// each.  Same values in the same pairs: same bits.
+#ifndef IPA_WINDOW_B128
+#define IPA_WINDOW_B128 1
+#endif
+// (a.y, b.x): D.lo = src0.hi, D.hi = src1.lo
+__device__ __forceinline__ v2f pk_mov_hi_lo(v2f a, v2f b) {
+  v2f d;
+  asm("v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+// row = the wave's LDS row (float 0 = its left pad); pair[m] = (px 4 L - H + m, px 4 L - H + m + 1)
+template <int K>
+__device__ __forceinline__ void window_pairs(const float* row, unsigned lane, unsigned lane4_opaque,
+                                             v2f (&pair)[K + 2]) {
+  constexpr int H = K / 2;
+  if constexpr (IPA_WINDOW_B128 != 0 && H <= 4 && kRowPad == 4) {
+    const v4f* wv = reinterpret_cast<const v4f*>(row + 4u * lane);
+    const v4f q0 = wv[0], q1 = wv[1], q2 = wv[2];
+    const v2f e[6] = {v2f{q0.x, q0.y}, v2f{q0.z, q0.w}, v2f{q1.x, q1.y},
+                      v2f{q1.z, q1.w}, v2f{q2.x, q2.y}, v2f{q2.z, q2.w}};
+    static_for<0, K + 2>([&](auto M) {
+      constexpr int m = decltype(M)::value, i = 4 - H + m;   // pair[m] = floats i, i + 1 of the twelve
+      if constexpr ((i & 1) == 0) pair[m] = e[i / 2];
+      else pair[m] = pk_mov_hi_lo(e[i / 2], e[i / 2 + 1]);
+    });
+  } else {
+    // Pairs at even and at odd m are read through two offsets the compiler cannot relate:
+    // read once, the odd pairs would straddle register pairs and fall back to scalar fmas.
+    const float* wp = row + kRowPad - H + 4u * lane;
+    const float* wq = row + kRowPad - H + lane4_opaque;
+#pragma unroll
+    for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+  }
+}
+
 template <bool FAST, typename Src, int K, int QM = -1, bool STREAM = false, bool HALO = false>
 __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& src,
                                                    const Weights<float, K * K>& wts, float* xp,
@@ -556,13 +606,8 @@ __device__ __forceinline__ void wave_run_strip(const WaveParams& p, const Src& s
       constexpr int d = decltype(Dd)::value;
       const int t = tb + d;
       // pair[m] = (px 4L-H+m, px 4L-H+m+1), m = 0 .. K+1
-      // Pairs at even and at odd m are read through two offsets the compiler cannot relate:
-      // read once, the odd pairs would straddle register pairs and fall back to scalar fmas.
-      const float* wp = xp + d * kRowStride + kRowPad - G::H + 4u * lane;
-      const float* wq = xp + d * kRowStride + kRowPad - G::H + lane4_opaque;
       v2f pair[K + 2];
-#pragma unroll
-      for (int m = 0; m < K + 2; m++) pair[m] = (m & 1) ? v2f{wq[m], wq[m + 1]} : v2f{wp[m], wp[m + 1]};
+      window_pairs<K>(xp + d * kRowStride, lane, lane4_opaque, pair);
 
       // STREAM: kernel row i (padded to 12 floats, 16-byte aligned) arrives in 12 SGPRs while
       // row i + 1 is being accumulated: load(i - 1) is issued before the fmas of row i, the
@@ -828,8 +873,9 @@ wave_stencil_big_kernel(WaveBigArgs<Src, K> a) {
 
 // strip height: tall strips amortise the K-1 halo rows, short ones give small
 // problems enough waves to fill 256 CUs
+// strips_x: the strips per row of the caller's geometry (wave_geom / sep_geom: 240- or 248-px steps); 0 = estimated
 static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_frames, int K,
-                                    bool fma_bound = false, int piped = 0) {
+                                    bool fma_bound = false, int piped = 0, int strips_x = 0) {
   if (ctx->tune.strip_h > 0) return ctx->tune.strip_h;  // tuning knob
   // the hand-scheduled kernels of round 3 (wave_pipe.hpp; their rim strips run on the fast loop
   // too).  Plain filters (piped = 1) want many short strips - the tail of the launch's last
@@ -839,7 +885,7 @@ static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_fr
   // prologue of dependent loads): 64 x 4K: 36 rows 1.066, 72 1.042, 108 1.031, 144 1.024 ms;
   // 16 x 4K: 24 0.296, 48 0.286, 72 0.283
   if (piped) {
-    const long sx = (dw + 255) / 256;
+    const long sx = strips_x > 0 ? strips_x : (dw + 255) / 256;
     const int cand2[4] = {144, 72, 48, 32};
     const long need2[4] = {12288, 6144, 4096, 0};
     if (piped == 2) {
@@ -850,7 +896,7 @@ static inline int wave_strip_height(const ipa_ctx* ctx, int dh, int dw, int n_fr
     }
   }
   int ow = 256 - 8 * ((K / 2 + 3) / 4);
-  long sx = (dw + ow - 1) / ow;
+  long sx = strips_x > 0 ? strips_x : (dw + ow - 1) / ow;
   // measured on 4K frames (MI355X, 4096 resident waves): with 16 frames 16-48 rows are within
   // noise of each other and 8 / 128+ clearly slower; with 64-128 frames per launch 48 rows
   // beat 32 by 2.3 % and 72 by 2.9 % (fewer halo rows sampled per output row), 90-135 fall

@@ -135,6 +135,7 @@ class Context(object):
         not placed a second time.)"""
         self._place_tls.active = True
         first = extra = keep = None
+        ok = False
         try:
             first = self._alloc_raw(nbytes)
             times = [self._probe_block(first, nbytes)]
@@ -149,14 +150,21 @@ class Context(object):
                 if times[1] < times[0]:
                     keep = extra
             self.synchronize()
-            self._placed_ptrs.add(keep.value)
+            with self._pool_lock:
+                self._placed_ptrs.add(keep.value)
             self.placement_log.append({'nbytes': int(nbytes), 'ms': [round(t, 4) for t in times],
                                        'kept': 0 if keep is first else 1})
+            ok = True
             return keep
         finally:
             self._place_tls.active = False
+            # on success the candidate that was not chosen goes back to the driver; when anything above
+            # raised (a probe, mem_info, the synchronize) BOTH do - nothing is returned to the caller then
             for p in (first, extra):
-                if p is not None and p is not keep:
+                if p is not None and (not ok or p is not keep):
+                    if not ok:
+                        with self._pool_lock:
+                            self._placed_ptrs.discard(p.value)
                     self._lib.ipa_free(self.handle, p)
 
     def _probe_block(self, ptr, nbytes):
@@ -194,9 +202,9 @@ class Context(object):
                 self._pool.setdefault(nbytes, []).append(ptr)
                 self._pool_bytes += nbytes
                 return
-        if ptr.value in self._placed_ptrs:
-            self._placed_ptrs.discard(ptr.value)
-            self._no_place_sizes.add(nbytes)
+            if ptr.value in self._placed_ptrs:
+                self._placed_ptrs.discard(ptr.value)
+                self._no_place_sizes.add(nbytes)
         self._lib.ipa_free(self.handle, ptr)
 
     def trim(self):
@@ -205,8 +213,12 @@ class Context(object):
             blocks = [p for lst in self._pool.values() for p in lst]
             self._pool.clear()
             self._pool_bytes = 0
+            for p in blocks:
+                self._placed_ptrs.discard(p.value)
+            # a trim is the caller's "start over": sizes whose placed block once went back to the driver may
+            # be placed again
+            self._no_place_sizes.clear()
         for p in blocks:
-            self._placed_ptrs.discard(p.value)
             self._lib.ipa_free(self.handle, p)
 
     def empty(self, shape, dtype):

@@ -41,7 +41,7 @@ def both(ia, src, M, shape, interp, K, border='constant', cval=0.25, conv='refle
     out = []
     try:
         for tc in (0, 1):
-            ctx.set_tuning(tile_chain=tc, **knobs)
+            ctx.set_tuning(tile_chain=2 * tc, **knobs)   # 2: every chain the kernel covers (1: only the two-launch ones)
             before = ctx.get_tuning('chain_launches')
             out.append(ops.warp_perspective_sepconv2d(d, M, shape, ky, kx, interp, border, cval, conv).get())
             took = ctx.get_tuning('chain_launches') - before
@@ -137,7 +137,7 @@ def test_one_launch_against_the_oracle(ia, oracle, interp):
     for deg, zoom in ((28.0, 1.0), (-61.0, 0.8), (5.0, 1.3)):
         M = rot_persp(h, w, deg, zoom=zoom)
         try:
-            ctx.set_tuning(tile_chain=1)
+            ctx.set_tuning(tile_chain=2)
             got = ops.warp_perspective_sepconv2d(d, M, (h, w), g, g, interp, 'constant', 0.5).get()
         finally:
             ctx.set_tuning(tile_chain=0)

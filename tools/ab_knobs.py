@@ -80,6 +80,12 @@ def main():
         r7x = ctx.to_device(((R7[0, 0] * xx + R7[0, 1] * yy + R7[0, 2]) / W).astype(np.float32))
         r7y = ctx.to_device(((R7[1, 0] * xx + R7[1, 1] * yy + R7[1, 2]) / W).astype(np.float32))
         del yy, xx, W
+    gk, gk1 = {}, {}
+    for kk in (3, 5, 7, 9):
+        t = np.exp(-0.5 * (np.arange(kk) - kk // 2) ** 2)
+        t /= t.sum()
+        gk[kk] = np.outer(t, t)
+        gk1[kk] = t
     calls = {
         'c3': lambda: ops.warp_perspective_sepconv2d(src, Hm, (h, w), g9, g9, 'linear', out=dst),
         'warp5': lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k5, 'linear', out=dst),
@@ -88,6 +94,18 @@ def main():
         'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
         'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
         'conv5': lambda: ops.conv2d(src, k5, out=dst),
+        # Gaussian outer products of 3 / 7 / 9 taps (knob rank1_sep: dense loop against the K + K loop)
+        'gconv3': lambda: ops.conv2d(src, gk[3], out=dst),
+        'gconv7': lambda: ops.conv2d(src, gk[7], out=dst),
+        'gconv9': lambda: ops.conv2d(src, gk[9], out=dst),
+        'fusedg3': lambda: ops.remap_conv2d(src, dmx, dmy, gk[3], out=dst),
+        'fusedg7': lambda: ops.remap_conv2d(src, dmx, dmy, gk[7], out=dst),
+        'fusedg9': lambda: ops.remap_conv2d(src, dmx, dmy, gk[9], out=dst),
+        'gsep3': lambda: ops.sepconv2d(src, gk1[3], gk1[3], out=dst),
+        'gsep5': lambda: ops.sepconv2d(src, gk1[5], gk1[5], out=dst),
+        'gsep7': lambda: ops.sepconv2d(src, gk1[7], gk1[7], out=dst),
+        'gsep9': lambda: ops.sepconv2d(src, gk1[9], gk1[9], out=dst),
+        'undist5': lambda: ops.undistort_conv2d(src, K, dist, K, k5, out=dst),
         'conv11': lambda: ops.conv2d(src, k11, out=dst),
         'lz4': lambda: ops.warp_perspective(src, Hm, (h, w), 'lanczos4', out=dst),
         'cubic': lambda: ops.warp_perspective(src, Hm, (h, w), 'cubic', out=dst),

@@ -51,7 +51,7 @@ def main():
         out = []
         try:
             for tc in (0, 1):
-                ctx.set_tuning(tile_chain=tc, **knobs)
+                ctx.set_tuning(tile_chain=2 * tc, **knobs)
                 before = ctx.get_tuning('chain_launches')
                 out.append(ops.warp_perspective_sepconv2d(d, M, (dh, dw), ky, kx, interp, border, cval, conv).get())
                 taken += ctx.get_tuning('chain_launches') - before

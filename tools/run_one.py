@@ -50,6 +50,11 @@ def main():
             interp = interp[:-4]
             src = ctx.to_device((src.get() * 65535).astype(np.uint16))
             dst = ctx.empty((batch, h, w), np.uint16)
+    from imgprocessor_amd.utils import getPerspectiveTransform
+    quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
+    rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
+    Hq = np.linalg.inv(getPerspectiveTransform(quad, rect))
+    g9 = ops.gaussian_kernel1d(1.0)
     k7 = np.random.default_rng(123).random((7, 7))
     k7 /= k7.sum()
     u16 = ctx.to_device(np.round(src.get() * 4095).astype(np.uint16)) if case == 'c4' else None
@@ -70,6 +75,10 @@ def main():
             ops.conv2d(src, k5, out=dst)
         elif case == 'copy':
             dst.copy_from(src)
+        elif case in ('lz4q', 'cubicq', 'linq'):   # bench.py's C3 homography (quad -> full frame), standalone warp
+            ops.warp_perspective(src, Hq, (h, w), interpolation={'lz4q': 'lanczos4', 'cubicq': 'cubic', 'linq': 'linear'}[case], out=dst)
+        elif case in ('c3lin', 'c3cubic'):
+            ops.warp_perspective_sepconv2d(src, Hq, (h, w), g9, g9, 'linear' if case == 'c3lin' else 'cubic', out=dst)
         elif case == 'lanczos_h':
             ops.warp_perspective(src, H, (h, w), interpolation='lanczos4', out=dst)
         elif analytic:
