@@ -173,7 +173,13 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     g /= g.sum()
     k5 = np.outer(g, g)
 
-    def entry(name, frames, h, w, ms, comp_bytes, launches, note=None, bound='hbm', work=None):
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'r06_issue.json')) as f:
+            issue_tab = json.load(f)
+    except (OSError, ValueError):
+        issue_tab = {}
+
+    def entry(name, frames, h, w, ms, comp_bytes, launches, note=None, bound='hbm', work=None, issue=None):
         """comp_bytes: the WORKLOAD's compulsory HBM bytes (inputs once, outputs once) whatever the
         number of launches - an intermediate image through the workspace is not compulsory.
         bound: the roofline that binds the dominant kernel; for 'valu' / 'lds' `work` is the
@@ -194,6 +200,17 @@ def other_configs(ctx, ia, ops, budget_launches=60):
             # (256 CUs x 64 lanes per clock at the guide's 2.4 GHz)
             e['vector_lane_instructions'] = int(work)
             e['frac_valu_issue'] = round(work / (ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+        if issue and issue in issue_tab:
+            # what bounds a kernel that is not HBM-bound, MEASURED: the rocprofv3 counter passes of this round on
+            # this configuration (tools/r06_pmc.sh -> tools/issue_table.py -> profiles/r06_issue.json): the
+            # fraction of the launch the SIMDs spend issuing vector instructions, the fraction the LDS arrays
+            # are busy, bank conflicts as a share of that
+            t = issue_tab[issue]
+            e['issue_counters'] = {k: t[k] for k in ('kernel', 'valu_per_unit', 'unit', 'frac_valu_issue',
+                                                     'frac_lds_busy', 'frac_lds_conflict') if k in t}
+            e['issue_counters']['source'] = 'recorded: profiles/r06_issue.json (rocprofv3 --pmc SQ_* passes, round 6)'
+            fv, fl = t.get('frac_valu_issue', 0), t.get('frac_lds_busy', 0)
+            e['bound'] = ('lds + valu_issue' if min(fv, fl) > 0.55 else ('lds' if fl > fv else 'valu_issue'))
         if note:
             e['note'] = note
         out.append(e)
@@ -227,7 +244,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
         entry('LensDistortion.correct 4K f32, cv2.remap from the map pair (%s), %d frames/launch' % (interp, B),
               B, h, w, ms, (8 * B + 8) * h * w, 1,
               'tile kernel with the map pair as coordinate source (csrc/tile_warp.hpp)',
-              **({'bound': 'lds', 'work': 40 * 8 * B * h * w} if interp == 'lanczos4' else {}))
+              **({'bound': 'lds', 'work': 40 * 8 * B * h * w, 'issue': 'lz4q'} if interp == 'lanczos4' else {}))
     del src, dst, dmx, dmy
 
     # C3: 4K float32, perspective remap (homography in the kernel: no maps) + separable 9+9
@@ -245,8 +262,20 @@ def other_configs(ctx, ia, ops, budget_launches=60):
         two = interp != 'linear'
         entry('C3 4K f32, PerspectiveCorrection warp (%s) + separable 9+9, %d frames/launch'
               % (interp, B), B, h, w, ms, 8 * B * h * w, 2 if two else 1,
-              'two launches through the workspace: tile warp, then the filter (16 B/px of traffic for '
-              'an 8 B/px workload)' if two else None)
+              'two launches through the workspace: tile warp (vector-issue-bound, see issue_counters), then the '
+              'filter (16 B/px of traffic for an 8 B/px workload)' if two else None,
+              issue='c3cubic' if two else 'c3lin')
+
+    # C3 bilinear at the headline's batch: 64 frames per launch (the coordinate table of the launch - the
+    # homography evaluated once, csrc/stored_coords.hpp - is shared by 16 frame groups instead of 4)
+    B64 = 64
+    s64 = ctx.to_device(synth_frames(B64, h, w, 300))
+    d64 = ctx.empty((B64, h, w), np.float32)
+    ms = timed_settled(ctx, lambda: ops.warp_perspective_sepconv2d(s64, Hm, (h, w), g9, g9, 'linear', out=d64),
+                       budget_launches // 2, 3)
+    entry('C3 4K f32, PerspectiveCorrection warp (linear) + separable 9+9, %d frames/launch' % B64, B64, h, w, ms,
+          8 * B64 * h * w, 1, issue='c3lin')
+    del s64, d64
 
     # PerspectiveCorrection.correct as the reference calls it (cv2.warpPerspective with
     # INTER_LANCZOS4, camera/PerspectiveCorrection.py:401-405): float32 frames and the camera's
@@ -256,7 +285,7 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     entry('PerspectiveCorrection default 4K f32, Lanczos4 warp, %d frames/launch' % B, B, h, w, ms,
           8 * B * h * w, 1, 'tile kernel (csrc/tile_warp.hpp): the source box of a 64 x 32 output tile '
           'in LDS, rows in interleaved pairs; 40 8-byte LDS reads per sample (5 row pairs x 8 columns)',
-          bound='lds', work=40 * 8 * B * h * w)
+          bound='lds', work=40 * 8 * B * h * w, issue='lz4q')
 
     # the same three chains with the picture rotated by 15 degrees: the row-walking kernels pay per
     # cache line a wave's gather touches (profiles/r04_micro.txt: up to 3x at 45 degrees); the tile
@@ -276,8 +305,9 @@ def other_configs(ctx, ia, ops, budget_launches=60):
           'an 8 B/px workload); the one fused kernel takes 0.72 ms at this angle')
     ms = timed_settled(ctx, lambda: ops.warp_perspective(src, Hr, (h, w), 'lanczos4', out=dst), budget_launches, 5)
     entry('PerspectiveCorrection default rotated by 15 degrees: 4K f32, Lanczos4 warp, %d frames/launch' % B,
-          B, h, w, ms, 8 * B * h * w, 1, 'tile kernel; ring + gather kernels: 1.7 ms at this angle',
-          bound='lds', work=40 * 8 * B * h * w)
+          B, h, w, ms, 8 * B * h * w, 1, 'tile kernel; ring + gather kernels: 1.7 ms at this angle '
+          '(issue_counters: the unrotated launch of the same kernel)',
+          bound='lds', work=40 * 8 * B * h * w, issue='lz4q')
     u16 = ctx.to_device(np.round(synth_frames(B, h, w, 320) * 65535).astype(np.uint16))
     d16 = ctx.empty((B, h, w), np.uint16)
     ms = timed_settled(ctx, lambda: ops.warp_perspective(u16, Hm, (h, w), 'lanczos4', out=d16),
@@ -343,7 +373,10 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     dst = placed((B, h, w), np.float32, lambda d: ops.remap_conv2d(u16, dmx, dmy, k7, out=d))
     ms = timed_settled(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst), budget_launches // 2, 3)
     entry('C4 4K uint16 -> float32, undistort (maps) + dense 7x7, %d frames/launch (kernel only)'
-          % B, B, h, w, ms, (6 * B + 8) * h * w, 1)
+          % B, B, h, w, ms, (6 * B + 8) * h * w, 1,
+          'streams 3.2 GB while its SIMDs issue vector instructions ~80 % of the launch (98 packed fmas for the 49 '
+          'taps x 4 pixels + ~120 for sampling, unpacking and coefficient restores per row step): priced against '
+          'HBM, bound by vector issue', issue='c4')
     del u16, dst
     # the same chain host -> host through page-locked buffers (PCIe-inclusive; never `value`)
     try:
@@ -374,6 +407,70 @@ def other_configs(ctx, ia, ops, budget_launches=60):
     return out
 
 
+def collectives(world, rank):
+    """(barrier, max_over_ranks, gather_over_ranks) - the ONLY cross-rank traffic of this benchmark: timing
+    plumbing over gloo (frames are independent: no data-path collective); at world = 1 plain functions"""
+    if world <= 1:
+        return (lambda: None), (lambda v: v), (lambda v: [v])
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def gather_over_ranks(v):
+        mine = torch.tensor([v], dtype=torch.float64)
+        every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(every, mine)
+        return [float(t[0]) for t in every]
+    return dist.barrier, max_over_ranks, gather_over_ranks
+
+
+def e2e_plan(world, frames_per_rank, h, w):
+    """the end-to-end leg at N > 1 (ingest, not HBM, limits the sharded batch): every rank
+    streams its OWN block of uint16 frames host -> device -> host (float32 results) - BASELINE's C4 chain -
+    through page-locked buffers; bytes over PCIe per rank and in total"""
+    per_rank = (2 + 4) * frames_per_rank * h * w
+    return {'frames_per_rank': frames_per_rank, 'frames_total': world * frames_per_rank,
+            'pcie_bytes_per_rank': per_rank, 'pcie_bytes': world * per_rank,
+            'workload': 'C4 chain host -> host: %d x %dx%d uint16 frames per rank in, undistort (maps) + dense 7x7, '
+                        'float32 frames out; FramePipeline (3 overlapped workers per GPU, page-locked buffers, '
+                        'threads pinned to the GPU\'s NUMA node)' % (frames_per_rank, w, h)}
+
+
+def end_to_end_c4(ia, ops, device, rank, h, w, n_frames, barrier):
+    """milliseconds this rank takes to stream n_frames uint16 frames host -> device -> host through the C4
+    chain; barrier before and after (the caller takes the MAX over ranks)"""
+    from imgprocessor_amd.sharding import FramePipeline, numa_cpus_of_device
+    K, dcoef = camera(h, w)
+    k7 = np.random.default_rng(123).random((7, 7))
+    k7 /= k7.sum()
+    cpus = numa_cpus_of_device(device)
+    pipe = FramePipeline(device, 3, cpus=cpus)
+    maps = {id(c): ops.build_undistort_map(K, dcoef, K, h, w, ctx=c, device=True) for c in pipe.contexts}
+    fin = pipe.pinned_empty((n_frames, h, w), np.uint16)
+    fout = pipe.pinned_empty((n_frames, h, w), np.float32)
+    one = np.round(synth_frames(1, h, w, 400 + rank)[0] * 4095).astype(np.uint16)
+    for i in range(n_frames):
+        fin[i] = np.roll(one, 29 * i, axis=1)
+
+    def fn(c, d, o):
+        mx, my = maps[id(c)]
+        ops.remap_conv2d(d, mx, my, k7, out=o)
+    pipe.run(fin[:3], fout[:3], fn)   # buffers, maps and code objects in place
+    barrier()
+    t0 = time.perf_counter()
+    pipe.run(fin, fout, fn)
+    ms = (time.perf_counter() - t0) * 1e3
+    barrier()
+    ok = bool(np.isfinite(fout[n_frames - 1]).all() and float(fout[n_frames - 1].max()) > 0)
+    del fin, fout
+    return ms, ok, (sorted(cpus)[:1] + sorted(cpus)[-1:]) if cpus else None
+
+
 def self_launch_cmd(n_gpus, argv, port):
     """the command a bare `python bench.py --gpus N` (N > 1, no launcher around it) runs as a child:
     the driver's own launch line, one rank per GPU, rendezvous on 127.0.0.1"""
@@ -401,6 +498,9 @@ def main():
                          'default: IMGPROC_HIP_PLACE, 1 = every allocation as it comes; 2 = the better of two)')
     ap.add_argument('--no-settle', action='store_true',
                     help='skip the untimed clock-settling launches of the setup phase')
+    ap.add_argument('--e2e-frames', type=int, default=64,
+                    help='N > 1: uint16 frames every rank streams host -> device -> host in the end-to-end leg '
+                         '(0 skips it)')
     ap.add_argument('--no-configs', action='store_true',
                     help='skip the other_configs leg (BASELINE configurations C2..C5)')
     args = ap.parse_args()
@@ -424,24 +524,9 @@ def main():
         print('bench.py: --gpus %d but WORLD_SIZE=%d: the line below is a %d-rank measurement'
               % (args.gpus, world, world), file=sys.stderr)
     dist_on = world > 1
+    barrier, max_over_ranks, gather_over_ranks = collectives(world, rank)
     if dist_on:
-        import torch
         import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
-
-        def barrier():
-            dist.barrier()
-
-        def max_over_ranks(v):
-            t = torch.tensor([v], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return float(t[0])
-    else:
-        def barrier():
-            pass
-
-        def max_over_ranks(v):
-            return v
 
     import imgprocessor_amd as ia
     from imgprocessor_amd import ops
@@ -508,6 +593,25 @@ def main():
         literal_px, compulsory, launches = 16, 16 * B * h * w, 2
         kname = 'remap_kernel<float,float,linear,UndistortCoord> + wave_stencil_kernel<LoadRowSrc,5>'
 
+    # which loop the library takes for this call: the bench's 5x5 is outer(g, g) - an exact outer product goes
+    # to the separable 5 + 5 loop (knob rank1_sep, on by default; csrc/fused.hip::rank1_chain)
+    routed0 = ctx.get_tuning('rank1_routed')
+    # the very first launches of this process, one event pair each: the clock ramp of a GPU that idled while
+    # the host built the frames, as a driver-side record sees it (config.first_launch_ms)
+    n_first = 30
+    fev = [ctx.event() for _ in range(n_first + 1)]
+    fev[0].record()
+    for i in range(n_first):
+        step()
+        fev[i + 1].record()
+    ctx.synchronize()
+    first_ms = [round(fev[i].elapsed_ms(fev[i + 1]), 4) for i in range(n_first)]
+    del fev
+    sep_route = ctx.get_tuning('rank1_routed') > routed0
+    if sep_route:
+        kname_dense = kname
+        kname = kname.replace('wave_stencil_kernel', 'wave_sep_kernel').replace(',5>', ',5+5>')
+
     # What a run WITHOUT any preparation sees (clocks still ramping up from idle): the first
     # min(steps, 20) steps after the driver's warm-up count, reported as no_settle_*.
     ns_steps = min(args.steps, 20)
@@ -533,8 +637,19 @@ def main():
     ctx.synchronize()
     el = time.perf_counter() - t0
     barrier()
+    per_rank_ms = gather_over_ranks(el / args.steps * 1e3)
     el = max_over_ranks(el)
     ev_ms = e0.elapsed_ms(e1)  # HIP events on the stream the kernels ran on
+
+    # the dense 5x5 loop on the same buffers, same process (knob rank1_sep = 0): what the call cost before
+    # round 6 routed outer products to the separable loop - reported beside the line, never as `value`
+    dense_ms = None
+    if sep_route and rank == 0:
+        old_knob = ctx.set_tuning(rank1_sep=0)
+        try:
+            dense_ms = timed(ctx, step, max(20, min(args.steps, 60)), 5)
+        finally:
+            ctx.set_tuning(**old_knob)
 
     # SURVEY section 8(d) asks for the MEDIAN of >= 20 iterations: a second, untimed-for-`value`
     # pass with one event pair per step (the contract's `value` / `ms_per_step` stay the
@@ -549,6 +664,25 @@ def main():
     per_step = sorted(evs[i].elapsed_ms(evs[i + 1]) for i in range(n_med))
     med_ms = per_step[n_med // 2]
     del evs
+
+    # N > 1: the end-to-end half (every rank: its own uint16 frames host -> device -> host).  The kernel-only
+    # line above scales trivially; this is the leg SURVEY section 8(e) names as the real limiter.
+    e2e = None
+    if dist_on and args.e2e_frames > 0 and (h, w) == (H4K, W4K):
+        try:
+            ms_e2e, ok_e2e, cpu_span = end_to_end_c4(ia, ops, ctx.device_id, rank, h, w, args.e2e_frames, barrier)
+            failed = 0.0 if ok_e2e else 1.0
+        except Exception as ex:  # noqa: BLE001 - every rank must still reach the collectives below
+            ms_e2e, failed, cpu_span = 0.0, 1.0, repr(ex)
+        e2e_ms = gather_over_ranks(ms_e2e)
+        e2e_failed = max_over_ranks(failed)
+        plan = e2e_plan(world, args.e2e_frames, h, w)
+        worst = max(e2e_ms)
+        e2e = dict(plan, per_rank_ms=[round(v, 2) for v in e2e_ms],
+                   Gpix_s_aggregate=round(plan['frames_total'] * h * w / worst / 1e6, 2) if worst > 0 else None,
+                   GB_s_pcie_aggregate=round(plan['pcie_bytes'] / worst / 1e6, 2) if worst > 0 else None,
+                   numa_cpus_rank0=cpu_span, ok=not e2e_failed,
+                   note='barrier, every rank streams its block, barrier; MAX over ranks; PCIe-inclusive, never `value`')
 
     if rank == 0:
         value = world * px * args.steps / el / 1e6
@@ -610,6 +744,11 @@ def main():
                                    'border) + 5x5 Gaussian (reflect), %d frames/step/GPU, '
                                    'variant=%s' % (w, h, B, args.variant),
                        'frames_per_step_per_gpu': B, 'variant': args.variant,
+                       'path': ('separable 5 + 5 loop: the 5x5 kernel is an exact outer product (library default, '
+                                'knob rank1_sep)' if sep_route else 'dense 5x5 loop'),
+                       'probe_src_ms': probe_ms['source'], 'probe_dst_ms': probe_ms['result'],
+                       'first_launch_ms': first_ms,
+                       'per_rank_ms_per_step': [round(v, 4) for v in per_rank_ms],
                        'clock_settle_launches': settle, 'buffer_placement': placement,
                        'no_settle_ms_per_step': round(ns_ms, 4),
                        'no_settle_value': round(world * px / ns_ms / 1e3, 1),
@@ -627,15 +766,16 @@ def main():
                          'compulsory_bytes_per_launch': compulsory // launches
                          if launches == 1 else None,
                          'compulsory_bytes_per_step': compulsory,
-                         'limiter': 'the stream rate of the marching-strip shape of the sampling kernels (a gather '
-                                    'COPY in that shape - same strips, same order, same stores, no arithmetic - runs '
-                                    '0.93 ms on a slow-class box with the 240-px strip step of the library, 0.99 with '
-                                    'the 248-px step of rounds 1 - 4, 0.82 on 256-px aligned strips: '
-                                    'tools/sector_micro.hip) with the vector work (0.47 ms of issue time) next to it; '
-                                    'the aligned geometry streams faster still but its halo samples cost more than '
-                                    'that (profiles/r05_micro.txt); HBM is the roofline the compulsory bytes are '
-                                    'priced against, not what saturates',
+                         'limiter': 'the gather + strip-store stream of the marching-strip shape (a gather COPY in that '
+                                    'shape - same strips, same order, same stores, no arithmetic - runs 0.80 - 0.97 ms '
+                                    'by the box, tools/sector_micro.hip); the filter is worth 2 - 3 % of the launch '
+                                    '(dense 25 taps -> separable 5 + 5: profiles/r06_micro.txt); HBM is the roofline the '
+                                    'compulsory bytes are priced against, not what saturates',
                          'kernel': kname, 'launches_per_step': launches,
+                         'dense_loop': ({'kernel': kname_dense, 'ms_per_step': round(dense_ms, 4),
+                                         'frac': round(compulsory / (dense_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         'note': 'the same call with rank1_sep = 0, same buffers, same process'}
+                                        if dense_ms else None),
                          'avg_step_ms_hip_events': round(ev_ms / args.steps, 4),
                          'literal_survey_8d': {
                              'bytes_per_px': literal_px,
@@ -651,6 +791,8 @@ def main():
                                      'the result batch in this run, read + write bytes; context '
                                      'for `peak`, not a substitute for it'}},
         }
+        if e2e is not None:
+            line['end_to_end'] = e2e
         if world == 1 and not args.no_configs and (h, w) == (H4K, W4K):
             del d_src, d_dst, d_tmp
             extra = []

@@ -180,13 +180,32 @@ __device__ __forceinline__ double ipa_abs(double x) { return __builtin_fabs(x); 
 __device__ __forceinline__ float ipa_rint(float x) { return rintf(x); }
 __device__ __forceinline__ double ipa_rint(double x) { return rint(x); }
 
-// OpenCV interpolateCubic generalised over A
+// OpenCV interpolateCubic generalised over A:
+//   w0 = ((A t1 - 5 A) t1 + 8 A) t1 - 4 A,  w1 = ((A + 2) t - (A + 3)) t t + 1,  w2 = the same in u = 1 - t,
+//   w3 = 1 - w0 - w1 - w2,  t1 = t + 1.
+// Written with EXPLICIT fused multiply-adds, in the grouping the compiler's own contraction gave the scalar float
+// form through round 5 (so those bits stay): round 6 evaluates the weights of TWO pixels in the halves of packed
+// instructions on the tile kernel (CT = v2f) and a second contraction decision must not be able to differ from
+// the first.  ipa_fma has float, double and v2f overloads; every other operation is a lone add / sub / mul.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f ipa_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename CT> __device__ __forceinline__ CT ipa_splat(float v) { return (CT)v; }
+template <> __device__ __forceinline__ v2f ipa_splat<v2f>(float v) { return v2f{v, v}; }
 template <typename CT> __device__ __forceinline__ void cubic_weights(CT t, CT A, CT (&w)[4]) {
-  CT t1 = t + (CT)1, u = (CT)1 - t;
-  w[0] = ((A * t1 - (CT)5 * A) * t1 + (CT)8 * A) * t1 - (CT)4 * A;
-  w[1] = ((A + (CT)2) * t - (A + (CT)3)) * t * t + (CT)1;
-  w[2] = ((A + (CT)2) * u - (A + (CT)3)) * u * u + (CT)1;
-  w[3] = (CT)1 - w[0] - w[1] - w[2];
+  const CT one = ipa_splat<CT>(1.f);
+  const CT t1 = t + one, u = one - t;
+  const CT a2 = A + ipa_splat<CT>(2.f), a3n = -(A + ipa_splat<CT>(3.f));
+  CT p = ipa_fma(A, t1, -(ipa_splat<CT>(5.f) * A));
+  p = t1 * p;
+  p = ipa_fma(A, ipa_splat<CT>(8.f), p);
+  w[0] = ipa_fma(t1, p, -(ipa_splat<CT>(4.f) * A));
+  CT x = ipa_fma(a2, t, a3n);
+  x = t * x;
+  w[1] = ipa_fma(t, x, one);
+  CT y = ipa_fma(a2, u, a3n);
+  y = u * y;
+  w[2] = ipa_fma(u, y, one);
+  w[3] = ((one - w[0]) - w[1]) - w[2];
 }
 
 // coordinate (float: map / undistort; double: homography) -> first tap + weights

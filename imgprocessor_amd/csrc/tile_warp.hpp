@@ -33,6 +33,9 @@ namespace ipa {
 // 32 x 32 and 32 x 16 for homographies that shrink parts of the picture (PerspectiveCorrection's
 // uncorrect / distort, strong trapezoids: a 64 x 32 tile of the far side can span 180 x 96 source
 // pixels).  TW = 64: lane = column, wave + 4 j = row; TW = 32: lanes 0-31 / 32-63 = two rows.
+#ifndef IPA_TILE_CUBIC_PACKED
+#define IPA_TILE_CUBIC_PACKED 1   // 0: the scalar bicubic loop of rounds 4 - 5 (same bits; tuning A/B builds)
+#endif
 constexpr int kWarpShapes = 3;
 constexpr int kWarpTileWs[kWarpShapes] = {64, 32, 32}, kWarpTileHs[kWarpShapes] = {32, 32, 16};
 constexpr int kWarpTileLdsBytes = 40960;  // the box of one tile (4 workgroups per CU at the most)
@@ -662,6 +665,37 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
         if (ad[j] >= 0 && x < a.dw && y < a.dh)
           store_px(o, y);
         __builtin_amdgcn_sched_barrier(0);   // one sample's taps in flight
+      }
+    } else if constexpr (INTERP == kCubic && !kU16 && IPA_TILE_CUBIC_PACKED != 0 && kWarpTilePx % 2 == 0) {
+      // bicubic on float32 frames, two pixels of the thread at a time in the halves of packed instructions (round
+      // 6): the Keys weights of both (cubic_weights<v2f>), then per tap row one packed multiply and three packed
+      // fmas on (tap of pixel a, tap of pixel b) - 20 vector instructions for the 2 x 16 taps instead of 40, 14
+      // for the weights instead of 28.  Every half is the scalar operation of sample() on the same operands in
+      // the same order: the bits of the gather kernel (tests/test_gpu_tile_warp.py, tools/fuzz_tile_warp.py).
+#pragma unroll
+      for (int j0 = 0; j0 < kWarpTilePx; j0 += 2) {
+        const int ya = y0 + yl + kRowsPass * j0, yb = ya + kRowsPass;
+        v2f wx[4], wy[4];
+        cubic_weights<v2f>(v2f{tx[j0], tx[j0 + 1]}, v2f{s.cubic_a, s.cubic_a}, wx);
+        cubic_weights<v2f>(v2f{ty[j0], ty[j0 + 1]}, v2f{s.cubic_a, s.cubic_a}, wy);
+        const float* tpa = tile_lds + (ad[j0] < 0 ? 0 : ad[j0]);
+        const float* tpb = tile_lds + (ad[j0 + 1] < 0 ? 0 : ad[j0 + 1]);
+        v2f o = v2f{0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          // (volatile: one ds_read_b32 per tap, each straight into its half of a register pair - merged into
+          // ds_read2_b32 the taps of ONE pixel share a pair and 16 moves per pixel pair put them apart again)
+          typedef const volatile __attribute__((address_space(3))) float* lds_vf;
+          lds_vf tra = (lds_vf)(tpa + r * a.pitch);
+          lds_vf trb = (lds_vf)(tpb + r * a.pitch);
+          v2f rs = wx[0] * v2f{tra[0], trb[0]};
+#pragma unroll
+          for (int c = 1; c < 4; c++) rs = ipa_fma(wx[c], v2f{tra[c], trb[c]}, rs);
+          o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+        }
+        if (ad[j0] >= 0 && x < a.dw && ya < a.dh) store_px(o.x, ya);
+        if (ad[j0 + 1] >= 0 && x < a.dw && yb < a.dh) store_px(o.y, yb);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
 #pragma unroll

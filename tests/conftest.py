@@ -27,6 +27,21 @@ def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 
 
+def load_cv_golden(name):
+    """cv_modes.npz / cv_resize.npz - the numpy restatements of OpenCV's published algorithms - with the
+    cv2-GENERATED vectors laid over them when tests/golden/gen_cv2_golden.py has been run on a machine
+    that has an OpenCV (files <name>_cv2.npz, same keys).  Returns (dict, label): the label says which
+    of the two the comparison below it is pinned to, and the tests print it."""
+    g = load_golden(name)
+    cvp = os.path.join(GOLDEN, name.replace('.npz', '_cv2.npz'))
+    if os.path.exists(cvp):
+        c = dict(np.load(cvp))
+        ver = str(c.pop('cv2_version', 'unknown'))
+        g.update(c)
+        return g, 'cv2-pinned (OpenCV %s, %d arrays from %s)' % (ver, len(c), os.path.basename(cvp))
+    return g, 'cv2-unpinned (numpy restatement; run tests/golden/gen_cv2_golden.py where cv2 exists)'
+
+
 def synth(shape, seed, dtype=np.float32):
     """SURVEY §8(d) synthetic image content"""
     rng = np.random.default_rng(seed)

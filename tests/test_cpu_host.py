@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from .conftest import ROOT, load_golden, assert_close
+from .conftest import ROOT, load_golden, assert_close, load_cv_golden
 
 HEADER = os.path.join(ROOT, 'include', 'imgproc_hip.h')
 
@@ -318,6 +318,52 @@ def test_two_rank_partition_gloo(tmp_path):
     assert res['cover'] == [1] * 37
 
 
+BENCH_WORKER = r'''
+import os, sys, json, importlib.util
+spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(%(root)r, 'bench.py'))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+barrier, mx, gather = bench.collectives(world, rank)
+barrier()
+ms = 10.0 + 5.0 * rank          # what a rank's end-to-end leg would report
+every = gather(ms)
+worst = mx(ms)
+plan = bench.e2e_plan(world, 64, 2160, 3840)
+if rank == 0:
+    print(json.dumps({'every': every, 'worst': worst, 'plan': plan}))
+import torch.distributed as dist
+dist.destroy_process_group()
+'''
+
+
+def test_bench_end_to_end_plumbing_two_ranks_gloo(tmp_path):
+    """the N > 1 half of bench.py that is not a kernel: per-rank times gathered over gloo, MAX over ranks,
+    and the end-to-end plan (every rank streams its own 64 uint16 4K frames host -> device -> host: 6 bytes
+    per pixel over PCIe) - world_size 2 on CPU; the streaming itself needs the GPU box"""
+    import json
+    script = tmp_path / 'bworker.py'
+    script.write_text(BENCH_WORKER % {'root': ROOT})
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29633', WORLD_SIZE='2')
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE) for r in range(2)]
+    outs = [p.communicate(timeout=240) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e.decode()[-2000:]
+    res = json.loads(outs[0][0].decode().strip().splitlines()[-1])
+    assert res['every'] == [10.0, 15.0] and res['worst'] == 15.0
+    plan = res['plan']
+    assert plan['frames_total'] == 128 and plan['pcie_bytes_per_rank'] == 6 * 64 * 2160 * 3840
+    assert plan['pcie_bytes'] == 2 * plan['pcie_bytes_per_rank']
+    # world 1: plain functions, no process group
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod1', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    b, m, g = bench.collectives(1, 0)
+    assert b() is None and m(3.5) == 3.5 and g(2.0) == [2.0]
+
+
 def test_bench_gpus_n_means_n(tmp_path):
     """`python bench.py --gpus N` without a launcher around it starts the N ranks itself (review
     item 6 of round 4: it used to measure one GPU and print n_gpus 1): the child command is the
@@ -358,7 +404,8 @@ def test_optimal_new_camera_matrix_independent_restatement():
     import numpy as np
     from tests.conftest import load_golden
     from imgprocessor_amd.utils import getOptimalNewCameraMatrix
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     for name in ('barrel', 'pincushion', 'c2'):
         v = g['optK_in_' + name]
         K, d, (w, h) = v[:9].reshape(3, 3), v[9:14], (int(v[14]), int(v[15]))
@@ -373,6 +420,26 @@ def test_optimal_new_camera_matrix_independent_restatement():
                 # alpha = 0 maps the inner rectangle EXACTLY onto [0, W-1]: ceil / floor of a value
                 # that is an integer up to the convergence error of the inverse lens model
                 assert all(abs(int(a) - b) <= 1 for a, b in zip(roi, want_roi)), (name, roi)
+
+
+def test_cv2_golden_generator_is_one_command_away():
+    """tests/golden/gen_cv2_golden.py: with an OpenCV it writes the cv2-generated vectors the parity tests
+    then prefer; without one (this container, the GPU box) it says so and exits 0 without writing, and
+    load_cv_golden labels every cv2-specific comparison "cv2-unpinned" """
+    script = os.path.join(ROOT, 'tests', 'golden', 'gen_cv2_golden.py')
+    have = subprocess.run([sys.executable, '-c', 'import cv2'], capture_output=True).returncode == 0
+    g, pin = load_cv_golden('cv_modes.npz')
+    if have:
+        # (never run the generator from a test: it would change the fixtures the test run is reading)
+        assert pin.startswith('cv2-pinned') or pin.startswith('cv2-unpinned')
+        return
+    before = sorted(os.listdir(os.path.dirname(script)))
+    r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert 'cv2 not available' in r.stdout
+    assert sorted(os.listdir(os.path.dirname(script))) == before
+    if not os.path.exists(os.path.join(ROOT, 'tests', 'golden', 'cv_modes_cv2.npz')):
+        assert pin.startswith('cv2-unpinned')
 
 
 def test_hand_scheduled_kernels_static_check(tmp_path):

@@ -5,7 +5,7 @@ identities the algorithm must satisfy."""
 import numpy as np
 import pytest
 
-from .conftest import load_golden, assert_close
+from .conftest import load_golden, assert_close, load_cv_golden
 from .test_oracle_golden import fast_filter_cases
 
 pytestmark = pytest.mark.gpu
@@ -169,7 +169,8 @@ def test_fast_filter_and_fast_mean_end_to_end(ia, oracle):
 def test_resize_vs_second_restatement(ia):
     """the GPU against the numpy restatement's fixture (cv_resize.npz), independent of oracle.c"""
     from .test_oracle_golden import cv_resize_cases
-    g = load_golden('cv_resize.npz')
+    g, pin = load_cv_golden('cv_resize.npz')
+    print(pin)
     n = 0
     for key, src, dsize, kind, _ in cv_resize_cases(g):
         got = ia.ops.resize(src, dsize, kind)

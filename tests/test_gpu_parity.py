@@ -11,7 +11,7 @@ import contextlib
 import numpy as np
 import pytest
 
-from .conftest import load_golden, assert_close, synth
+from .conftest import load_golden, assert_close, synth, load_cv_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -823,7 +823,8 @@ def test_cv_u16_arithmetic(ia, oracle):
     the last-bit differences of the 1-D tables).  This is what LensDistortion.correct /
     PerspectiveCorrection.correct do on the camera's uint16 frames (camera/LensDistortion.py:
     323-326, camera/PerspectiveCorrection.py:401-405)."""
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     img16 = g['img16']
     big = np.round(synth((300, 700), 77, np.float64) * 65535).astype(np.uint16)
     yy, xx = np.mgrid[0:300, 0:700].astype(np.float32)
@@ -867,7 +868,8 @@ def test_cv_modes_vs_independent_restatements(ia, oracle):
     test_oracle_golden.py).  These are the DEFAULTS of the reference's classes:
     PerspectiveCorrection.correct = Lanczos4, uncorrect / distort = bicubic a=-0.75 at 1/32 px,
     cv2.remap on uint8 = 15-bit fixed point."""
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     img, img8 = g['img'], g['img8']
     for name in ('radial', 'strong'):
         mx, my = g['mapx_' + name], g['mapy_' + name]
@@ -896,6 +898,28 @@ def test_cv_modes_vs_independent_restatements(ia, oracle):
                 want = g['%s_%s_%s' % (key, kind, name)]
                 d = np.abs(ia.ops.remap(img8, mx, my, iname, border_value=cv).astype(np.int32) - want)
                 assert d.max() <= 1 and (d != 0).mean() <= frac, (kind, name, key)
+
+
+def test_cv2_warp_perspective_vectors_when_present(ia):
+    """the GPU path against cv2.warpPerspective's own output (PerspectiveCorrection.correct: Lanczos4,
+    uncorrect: INTER_CUBIC | WARP_INVERSE_MAP) - only where tests/golden/gen_cv2_golden.py has run
+    under an OpenCV; without it the test states "cv2-unpinned" and returns"""
+    from .test_oracle_golden import cv2_warp_cases
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
+    if 'warp_H' not in g:
+        assert pin.startswith('cv2-unpinned')
+        return
+    H = g['warp_H']
+    names = {'linear': 'linear_cv_q5', 'cubic': 'cubic_cv_q5', 'lanczos4': 'lanczos4'}
+    for key, img, kind, inverse in cv2_warp_cases(g):
+        M = H if inverse else np.linalg.inv(H)
+        got = ia.ops.warp_perspective(img, M, img.shape, names[kind])
+        if img.dtype == np.float32:
+            close32(got, g[key], key, scale=1.0)
+        else:
+            d = np.abs(got.astype(np.int64) - g[key].astype(np.int64))
+            assert d.max() <= 1 and (d != 0).mean() <= 0.01, (key, d.max(), (d != 0).mean())
 
 
 def test_u8_lanczos4_footprints_ending_on_the_last_pixel(ia, oracle):

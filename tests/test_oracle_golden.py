@@ -6,7 +6,7 @@ identity shim), scipy.ndimage and skimage — see tests/golden/gen_golden.py.
 import numpy as np
 import pytest
 
-from .conftest import load_golden, assert_close
+from .conftest import load_golden, assert_close, load_cv_golden
 
 F32 = 2.5e-7  # one float32 ulp-ish: oracle accumulates in double, output is float32
 
@@ -338,7 +338,8 @@ def test_cv_modes_independent_restatements(oracle):
     restatements (tests/golden/gen_golden.py::gen_cv_modes).  Measured deviations are printed:
     they are the margin these modes have against a different implementation of the same
     definition - cv2 itself remains unavailable."""
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     img, img8 = g['img'], g['img8']
     worst = {}
     for name in ('radial', 'strong'):
@@ -375,7 +376,8 @@ def test_cv_u8_fixed_point_tables(oracle):
     """OpenCV's 8U bicubic / Lanczos4 (short weights with the sum fix-up, integer accumulation):
     the oracle against the independent numpy restatement - tables and remapped images"""
     import ctypes as C
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     lib = oracle.lib()
     for which, kind, ks in ((0, 'cubic', 4), (1, 'lanczos4', 8)):
         t = np.zeros((32, ks), np.float32)
@@ -414,7 +416,8 @@ def test_cv_u16_arithmetic_independent_restatement(oracle):
     the second, independently written float32-numpy one (gen_golden.py::remap_u16_cv_np).
     Bilinear and bicubic bit for bit; Lanczos4 up to the last-bit differences of the two 1-D
     weight tables (off by one on a few pixels).  cv2 itself is absent: unpinned."""
-    g = load_golden('cv_modes.npz')
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
     img16 = g['img16']
     for name in ('radial', 'strong'):
         mx, my = g['mapx_' + name], g['mapy_' + name]
@@ -433,6 +436,36 @@ def test_cv_u16_arithmetic_independent_restatement(oracle):
     a = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR)
     b = oracle.remap(img16, g['mapx_radial'], g['mapy_radial'], oracle.LINEAR | oracle.Q5)
     assert not np.array_equal(a, b)
+
+
+def cv2_warp_cases(g):
+    """(key, image, interpolation name, inverse-map flag) of the cv2.warpPerspective vectors that only the
+    cv2-generated file carries (gen_cv2_golden.py): PerspectiveCorrection.correct / uncorrect as called"""
+    for tag, img in (('f32', g['img']), ('u8', g['img8']), ('u16', g['img16'])):
+        for kind in ('linear', 'cubic', 'lanczos4'):
+            yield 'warp_%s_%s' % (kind, tag), img, kind, False
+        yield 'warpinv_cubic_' + tag, img, 'cubic', True
+
+
+def test_cv2_warp_perspective_vectors_when_present(oracle):
+    """cv2.warpPerspective itself (camera/PerspectiveCorrection.py:401-405 Lanczos4, :377-378
+    INTER_CUBIC | WARP_INVERSE_MAP) - only where tests/golden/gen_cv2_golden.py has run under an OpenCV;
+    here (no cv2) the test states that and returns"""
+    g, pin = load_cv_golden('cv_modes.npz')
+    print(pin)
+    if 'warp_H' not in g:
+        assert pin.startswith('cv2-unpinned')
+        return
+    H = g['warp_H']
+    ids = {'linear': oracle.LINEAR | oracle.Q5, 'cubic': oracle.CUBIC_CV | oracle.Q5, 'lanczos4': oracle.LANCZOS4}
+    for key, img, kind, inverse in cv2_warp_cases(g):
+        M = H if inverse else np.linalg.inv(H)      # the library takes the destination -> source matrix
+        got = oracle.warp_perspective(img, M, img.shape, ids[kind])
+        if img.dtype == np.float32:
+            assert_close(got, g[key], 0, 2e-6, key)
+        else:
+            d = np.abs(got.astype(np.int64) - g[key].astype(np.int64))
+            assert d.max() <= 1 and (d != 0).mean() <= 0.01, (key, d.max(), (d != 0).mean())
 
 
 def interp_more_cases(g):
@@ -575,7 +608,8 @@ def test_cv_resize_independent_restatement(oracle):
     (tests/golden/gen_golden.py::resize_np).  Bilinear, bicubic and both INTER_AREA forms agree bit
     for bit; Lanczos4 to the last bits of the float32 coefficients (numpy's vectorised sin / cos
     against libm's, as for the remap table in cv_modes.npz)."""
-    g = load_golden('cv_resize.npz')
+    g, pin = load_cv_golden('cv_resize.npz')
+    print(pin)
     n = 0
     for key, src, dsize, kind, oid in cv_resize_cases(g):
         got = oracle.resize(src, dsize, oid)
