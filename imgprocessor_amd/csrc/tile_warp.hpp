@@ -33,6 +33,14 @@ namespace ipa {
 // 32 x 32 and 32 x 16 for homographies that shrink parts of the picture (PerspectiveCorrection's
 // uncorrect / distort, strong trapezoids: a 64 x 32 tile of the far side can span 180 x 96 source
 // pixels).  TW = 64: lane = column, wave + 4 j = row; TW = 32: lanes 0-31 / 32-63 = two rows.
+#ifndef IPA_TILE_SLOW_INSIDE
+#define IPA_TILE_SLOW_INSIDE 1    // 0 (round 6, measured with IPA_TILE_RECOMPUTE = 1: slower, off): the rare tap-by-tap footprints of
+                                  // float32 frames in a frame loop of their own behind the main one
+#endif
+#ifndef IPA_TILE_RECOMPUTE
+#define IPA_TILE_RECOMPUTE 0      // 1 (round 6, measured slower, off): the frame loop's scalar invariants recomputed per frame on
+                                  // the scalar unit instead of hoisted and restored with v_readlane_b32 - see the frame loop
+#endif
 #ifndef IPA_TILE_CUBIC_PACKED
 #define IPA_TILE_CUBIC_PACKED 1   // 0: the scalar bicubic loop of rounds 4 - 5 (same bits; tuning A/B builds)
 #endif
@@ -183,7 +191,8 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
     tile = r / gc;
   }
   const int tyi = (int)(tile / (unsigned)a.tiles_x), txi = (int)tile - tyi * a.tiles_x;
-  const int x0 = txi * kWarpTileW, y0 = tyi * kWarpTileH;
+  const int x0 = txi * kWarpTileW;
+  int y0 = tyi * kWarpTileH;   // (not const: made opaque per frame below)
   const int x1 = x0 + kWarpTileW - 1 < a.dw ? x0 + kWarpTileW - 1 : a.dw - 1;
   const int y1 = y0 + kWarpTileH - 1 < a.dh ? y0 + kWarpTileH - 1 : a.dh - 1;
   int bx0 = 0, by0 = 0, bw = 0, bh = 0;
@@ -509,6 +518,16 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
   if (kPrefetch && direct && f0 < f1) box_issue(RimT{}, s.rsrc);
 #pragma unroll 1
   for (unsigned f = f0; f < f1; f++) {
+#if IPA_TILE_RECOMPUTE
+    // Round 6: everything the frame loop derives from the box's first row, its height and the tile's first row -
+    // the 10 + 4 row offsets of the box loads, the per-row store predicates of the fill, the 8 row offsets of the
+    // result stores - is loop-invariant, so the compiler forms it once, runs out of scalar registers (102) and
+    // restores ~70 of those values per frame with v_readlane_b32: VECTOR instructions in a kernel whose SIMDs issue
+    // 70 - 88 % of the launch.  Opaque copies make it recompute them on the scalar unit instead - MEASURED SLOWER
+    // (16 x 4K: bicubic 0.303 -> 0.324 ms, under 15 degrees 0.409 -> 0.468, bilinear 0.304 -> 0.381; Lanczos4 level):
+    // the recomputed multiplies and selects sit in front of the loads that need them, the restores did not.  Off.
+    asm volatile("" : "+s"(by0), "+s"(bh), "+s"(y0));
+#endif
     s.rsrc = make_rsrc(a.src + (long)f * a.src_frame_bytes, a.src_bytes);
     __syncthreads();   // the previous frame's taps are read (first pass: the Lanczos table is written)
     // 1. the box
@@ -741,7 +760,11 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
       __builtin_amdgcn_sched_barrier(0);
     }
     }
-    // 3. rare: footprints the box does not hold, through the gather kernel's sample()
+    // 3. rare: footprints the box does not hold, through the gather kernel's sample().  uint16 frames here (their
+    //    border footprints take what the frame's box holds from LDS); float32 frames in a frame loop of their own
+    //    below, so that the coordinate source and the sampler's state are not live through THIS loop (round 6: 134 of
+    //    the bicubic kernel's 747 vector instructions per frame were v_readlane_b32 restores of spilled scalars)
+    if constexpr (kU16 || IPA_TILE_SLOW_INSIDE != 0) {
     if (slow) {
 #pragma unroll 1
       for (int j = 0; j < kWarpTilePx; j++) {
@@ -755,6 +778,26 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
                                                 (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
         else
           store_px(tile_slow_sample<INTERP, C>(s, sx, sy, a.cval), y);
+      }
+    }
+    }
+  }
+  if constexpr (!kU16 && IPA_TILE_SLOW_INSIDE == 0) {
+    if (slow) {
+#pragma unroll 1
+      for (unsigned f = f0; f < f1; f++) {
+        s.rsrc = make_rsrc(a.src + (long)f * a.src_frame_bytes, a.src_bytes);
+        const __amdgpu_buffer_rsrc_t drs = make_rsrc(dst0 + (long)f * a.dst_frame_elems, a.dst_bytes);
+#pragma unroll 1
+        for (int j = 0; j < kWarpTilePx; j++) {
+          if (!((slow >> j) & 1u)) continue;
+          const int y = y0 + yl + kRowsPass * j;
+          if (x >= a.dw || y >= a.dh) continue;
+          C sx, sy;
+          coord.get(x, y, sx, sy);
+          const float o = tile_slow_sample<INTERP, C>(s, sx, sy, a.cval);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
+        }
       }
     }
   }
