@@ -34,12 +34,17 @@ struct ipa_tuning {
                           // and cross-check of that scheme (same bits, slower)
   int group_chunk = -1;   // batches on the shared-record loop: frame groups walked this many at a time (-1: a
                           // quarter of them, 0: all groups of a strip together); see wave_grid
+#ifndef IPA_WITH_TILE_CHAIN
+#define IPA_WITH_TILE_CHAIN 0   // 1: experiment builds that carry tools/tile_chain (make TILE_CHAIN=1); not the product
+#endif
+#if IPA_WITH_TILE_CHAIN
   int tile_chain = 0;     // 1: perspective warp + separable filter in ONE launch on the tile skeleton (tile_chain.hpp)
                           // for the chains that take two launches (bicubic; bilinear under a rotation); 2: wherever
                           // that kernel covers the chain.  Off: built, bit-identical to the two launches through the
                           // workspace, and 25 - 50 % slower (profiles/r05_micro.txt)
   int chain_steps = 0;    // ... steps of 32 rows a workgroup walks down its column (0: 4)
   int chain_frames = 0;   // ... frames per workgroup (0: up to 8, by launch size)
+#endif
   int pipe7 = 1;          // 7x7 after a bilinear map remap of a batch: resident coefficients on the shared-map loop
   int frame_major = 1;    // kernels whose frames share nothing (plain filters): frame after frame, every
                           // XCD streaming through frames of its own
@@ -100,7 +105,9 @@ struct ipa_ctx {
   unsigned long tile_warp_clock = 0;
   unsigned long rank1_routed = 0;     // dense calls sent to the separable loops so far (read through ipa_ctx_get_tuning)
   int group_chunk_used = 0;           // groups per chunk of the last launch on the shared-record loop (0: all together)
+#if IPA_WITH_TILE_CHAIN
   unsigned long chain_launches = 0;   // launches of tile_chain.hpp's kernel (read through ipa_ctx_get_tuning: the tests' evidence of the path taken)
+#endif
   // map remaps on the tile kernel: per (map pair, geometry) - least recently used of kTileSlowHints
   // replaced - a device word the kernel counts its tap-by-tap pixels in, the page-locked word it is
   // read back to by an asynchronous copy, and the event behind that copy: the word is the hint of

@@ -12,11 +12,13 @@ int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k7(ipa_ctx*, const FusedCall&);
 int ipa_fused_big_launch(ipa_ctx*, const FusedCall&, int K);  // fused_big.hip; 1 = not covered
 int ipa_check_interp_border(ipa_ctx* ctx, int interp, int border);  // remap.hip
+#if IPA_WITH_TILE_CHAIN
 // tile_chain.hip: 0 = launched, 1 = not a chain for that kernel
 int ipa_tile_chain_launch(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const double* M,
                           const double* ky, const double* kx, int K, void* d_dst, int dh, int dw,
                           long dst_pitch, int n_frames, long src_frame_stride, long dst_frame_stride,
                           int interp, int border_mode, double border_value, int cby, int cbx);
+#endif
 
 static int inv3f(const double* m, double* o) {
   double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
@@ -276,6 +278,7 @@ int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_
   };
   const bool rotated = dh > 0 && dw > 0 &&
                        rotated_warp_in_two_launches(ctx, M, src_dtype, dst_dtype, interp, dh, dw, n_frames);
+#if IPA_WITH_TILE_CHAIN   // experiment builds only (tools/tile_chain): the one-launch chain, slower than the two launches
   // knob tile_chain = 1: the chains that take two launches - bicubic warps, bilinear warps that rotate
   // the picture - in ONE launch on the tile skeleton (tile_chain.hpp).  Built for the review of round
   // 4, bit-identical, and slower than the two launches (16 x 4K + 9 + 9: bicubic 0.80 against 0.55 ms,
@@ -317,6 +320,7 @@ int ipa_warp_perspective_sepconv2d_dev(ipa_ctx* ctx, const void* d_src, int src_
       }
     }
   }
+#endif
   return fused_sep_common(ctx, f, two, d_src, src_dtype, sh, sw, src_pitch, ky, nky, kx, nkx, d_dst,
                           dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
                           dst_frame_stride, interp, border_mode, border_value, conv_border_y,

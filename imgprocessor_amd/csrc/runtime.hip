@@ -71,9 +71,11 @@ const TuneName kTuneNames[] = {
     {"frame_major", "IPA_FRAME_MAJOR", &ipa_tuning::frame_major},
     {"pipe7", "IPA_PIPE7", &ipa_tuning::pipe7},
     {"group_chunk", "IPA_GROUP_CHUNK", &ipa_tuning::group_chunk},
+#if IPA_WITH_TILE_CHAIN
     {"tile_chain", "IPA_TILE_CHAIN", &ipa_tuning::tile_chain},
     {"chain_steps", "IPA_CHAIN_STEPS", &ipa_tuning::chain_steps},
     {"chain_frames", "IPA_CHAIN_FRAMES", &ipa_tuning::chain_frames},
+#endif
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
     {"rank1_sep", "IPA_RANK1_SEP", &ipa_tuning::rank1_sep},
@@ -112,10 +114,12 @@ int ipa_ctx_set_tuning(ipa_ctx* ctx, const char* name, int value) {
 
 int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
   if (!ctx || !name || !value) return IPA_ERR_BAD_ARG;
+#if IPA_WITH_TILE_CHAIN
   if (strcmp(name, "chain_launches") == 0) {   // read-only counter, not a knob
     *value = (int)(ctx->chain_launches & 0x7fffffff);
     return IPA_OK;
   }
+#endif
   if (strcmp(name, "rank1_routed") == 0) {
     *value = (int)(ctx->rank1_routed & 0x7fffffff);
     return IPA_OK;

@@ -87,16 +87,11 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   "stored_coords" (smallest batch whose homography / lens coordinates are evaluated once
  *   for all frames, 0 = never), "pipe", "tile_warp" (perspective warps of float32 frames with an
  *   output tile's source box in LDS: 0 never, 1 where it pays, 2 whenever the homography fits).
- *   "tile_chain" (1: perspective warp + separable filter in one launch on the tile skeleton instead of
- *   two launches through the workspace, for the chains that take two - bicubic, rotated bilinear; 2: for
- *   every chain that kernel covers - same bits, slower, off by default; with "chain_steps" /
- *   "chain_frames" = steps of 32 rows / frames per workgroup, 0 = the library's choice).
  *   "rank1_sep" (dense K x K kernels that are an outer product ky (x) kx on the separable K + K loops: bit 0
  *   the remap -> filter chains (float32 frames, bilinear taps, 3 / 5 / 7 / 9 taps), bit 1 the plain 9 x 9
  *   filter; default 3; the reference obtains its Gaussians separably: scipy.ndimage.gaussian_filter,
  *   filters/fastFilter.py:42).
- *   ipa_ctx_get_tuning also answers the read-only names "chain_launches" (launches of the tile-chain kernel
- *   so far), "rank1_routed" (dense calls sent to the separable loops so far) and "group_chunk_used" (frame
+ *   ipa_ctx_get_tuning also answers the read-only names "rank1_routed" (dense calls sent to the separable loops so far) and "group_chunk_used" (frame
  *   groups per chunk of the last launch on the shared-record loop; "group_chunk" values that do not divide
  *   the group count go to the nearest divisor).
  * Values are range-checked (IPA_ERR_BAD_ARG).  ipa_ctx_create reads the IPA_* environment

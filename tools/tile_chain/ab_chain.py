@@ -5,7 +5,7 @@ bicubic.  Knob sweeps: python tools/ab_chain.py [chain_steps=2,4,8] [chain_frame
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import imgprocessor_amd as ia
 from imgprocessor_amd import ops

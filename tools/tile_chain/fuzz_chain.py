@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, R)
 import imgprocessor_amd as ia  # noqa: E402
 from imgprocessor_amd import ops  # noqa: E402

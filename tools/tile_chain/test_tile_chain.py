@@ -7,12 +7,21 @@ rotations, perspective, zooms, tap counts, both interpolations, every border mod
 the filter, ragged sizes, short pictures, batches that do not divide by the frames of a workgroup and
 coordinates outside the source; and against the oracle.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from .conftest import assert_close
-from .gpu_helpers import frames, same_bits
-from .test_gpu_tile_warp import rot_persp
+# an EXPERIMENT's test, not part of tests/: the chain kernel is not in the product library since round 6.  Run it on a
+# GPU box against the experiment build (make -C imgprocessor_amd/csrc VARIANT=chain TILE_CHAIN=1):
+#   IMGPROC_HIP_LIB=$PWD/imgprocessor_amd/libimgproc_hip_chain.so python -m pytest tools/tile_chain/test_tile_chain.py -m gpu -q
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+from tests.conftest import assert_close, oracle  # noqa: E402,F401  (the oracle fixture)
+from tests.gpu_helpers import frames, same_bits  # noqa: E402
+from tests.test_gpu_tile_warp import rot_persp  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
