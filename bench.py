@@ -23,6 +23,7 @@ C2..C5 kernel-only, C4 also PCIe-inclusive; N=1 only) and `cpu_baseline` (the
 oracle C restatement timed on this box's host cores, N=1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -443,32 +444,44 @@ def e2e_plan(world, frames_per_rank, h, w):
 
 def end_to_end_c4(ia, ops, device, rank, h, w, n_frames, barrier):
     """milliseconds this rank takes to stream n_frames uint16 frames host -> device -> host through the C4
-    chain; barrier before and after (the caller takes the MAX over ranks)"""
+    chain; barrier before and after (the caller takes the MAX over ranks).  Every rank reaches BOTH barriers
+    whatever happens to it - a rank whose setup or run raised reports (0, False, reason) instead of leaving
+    the others waiting."""
     from imgprocessor_amd.sharding import FramePipeline, numa_cpus_of_device
-    K, dcoef = camera(h, w)
-    k7 = np.random.default_rng(123).random((7, 7))
-    k7 /= k7.sum()
-    cpus = numa_cpus_of_device(device)
-    pipe = FramePipeline(device, 3, cpus=cpus)
-    maps = {id(c): ops.build_undistort_map(K, dcoef, K, h, w, ctx=c, device=True) for c in pipe.contexts}
-    fin = pipe.pinned_empty((n_frames, h, w), np.uint16)
-    fout = pipe.pinned_empty((n_frames, h, w), np.float32)
-    one = np.round(synth_frames(1, h, w, 400 + rank)[0] * 4095).astype(np.uint16)
-    for i in range(n_frames):
-        fin[i] = np.roll(one, 29 * i, axis=1)
+    pipe = fin = fout = fn = cpus = None
+    err = None
+    try:
+        K, dcoef = camera(h, w)
+        k7 = np.random.default_rng(123).random((7, 7))
+        k7 /= k7.sum()
+        cpus = numa_cpus_of_device(device)
+        pipe = FramePipeline(device, 3, cpus=cpus)
+        maps = {id(c): ops.build_undistort_map(K, dcoef, K, h, w, ctx=c, device=True) for c in pipe.contexts}
+        fin = pipe.pinned_empty((n_frames, h, w), np.uint16)
+        fout = pipe.pinned_empty((n_frames, h, w), np.float32)
+        one = np.round(synth_frames(1, h, w, 400 + rank)[0] * 4095).astype(np.uint16)
+        for i in range(n_frames):
+            fin[i] = np.roll(one, 29 * i, axis=1)
 
-    def fn(c, d, o):
-        mx, my = maps[id(c)]
-        ops.remap_conv2d(d, mx, my, k7, out=o)
-    pipe.run(fin[:3], fout[:3], fn)   # buffers, maps and code objects in place
+        def fn(c, d, o):
+            mx, my = maps[id(c)]
+            ops.remap_conv2d(d, mx, my, k7, out=o)
+        pipe.run(fin[:3], fout[:3], fn)   # buffers, maps and code objects in place
+    except Exception as ex:  # noqa: BLE001 - reported in the line; the barriers below must still be reached
+        err = repr(ex)
     barrier()
-    t0 = time.perf_counter()
-    pipe.run(fin, fout, fn)
-    ms = (time.perf_counter() - t0) * 1e3
+    ms = 0.0
+    if err is None:
+        try:
+            t0 = time.perf_counter()
+            pipe.run(fin, fout, fn)
+            ms = (time.perf_counter() - t0) * 1e3
+        except Exception as ex:  # noqa: BLE001
+            err = repr(ex)
     barrier()
-    ok = bool(np.isfinite(fout[n_frames - 1]).all() and float(fout[n_frames - 1].max()) > 0)
+    ok = err is None and bool(np.isfinite(fout[n_frames - 1]).all() and float(fout[n_frames - 1].max()) > 0)
     del fin, fout
-    return ms, ok, (sorted(cpus)[:1] + sorted(cpus)[-1:]) if cpus else None
+    return ms, ok, ((sorted(cpus)[:1] + sorted(cpus)[-1:]) if cpus else None) if err is None else err
 
 
 def self_launch_cmd(n_gpus, argv, port):
@@ -669,11 +682,8 @@ def main():
     # line above scales trivially; this is the leg SURVEY section 8(e) names as the real limiter.
     e2e = None
     if dist_on and args.e2e_frames > 0 and (h, w) == (H4K, W4K):
-        try:
-            ms_e2e, ok_e2e, cpu_span = end_to_end_c4(ia, ops, ctx.device_id, rank, h, w, args.e2e_frames, barrier)
-            failed = 0.0 if ok_e2e else 1.0
-        except Exception as ex:  # noqa: BLE001 - every rank must still reach the collectives below
-            ms_e2e, failed, cpu_span = 0.0, 1.0, repr(ex)
+        ms_e2e, ok_e2e, cpu_span = end_to_end_c4(ia, ops, ctx.device_id, rank, h, w, args.e2e_frames, barrier)
+        failed = 0.0 if ok_e2e else 1.0
         e2e_ms = gather_over_ranks(ms_e2e)
         e2e_failed = max_over_ranks(failed)
         plan = e2e_plan(world, args.e2e_frames, h, w)
@@ -825,6 +835,30 @@ def main():
                                       '(wave_pipe.hpp::border_blend); through sample() this ran 45 % '
                                       'over the line above'})
                 del s2, o2, ax, ay
+                # ... and at 256 frames per launch (8.5 GB in, 8.5 GB out of the 288 GB): the per-frame cost of this
+                # launch shape falls with the frames per launch until ~192 (tools/batch_sweep.py: 15.4 us per frame
+                # at 64, 14.8 at 128, 14.1 at 192 - 256 on a slow-class box); `value` stays on BASELINE's per-GPU
+                # batch of 64
+                try:
+                    B3 = 256
+                    s3 = ctx.empty((B3, h, w), np.float32)
+                    part = ctx.to_device(synth_frames(64, h, w, seed0=11))
+                    for i0 in range(0, B3, 64):
+                        ctx._check(ctx._lib.ipa_memcpy_d2d(ctx.handle, ctypes.c_void_p(s3.ptr.value + i0 * h * w * 4),
+                                                          part.ptr, part.nbytes), 'memcpy_d2d')
+                    del part
+                    o3 = ctx.empty((B3, h, w), np.float32)
+                    ms4 = timed_settled(ctx, lambda: ops.remap_conv2d(s3, dmx, dmy, k5, out=o3), 20, 3)
+                    c3 = (8 * B3 + 8) * h * w
+                    extra.append({'workload': 'headline at %d frames/launch' % B3, 'frames': B3,
+                                  'ms': round(ms4, 4), 'Mpix_s': round(B3 * h * w / ms4 / 1e3, 1),
+                                  'compulsory_bytes': c3,
+                                  'frac_compulsory': round(c3 / (ms4 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  'launches': 1})
+                    del s3, o3
+                    ctx.trim()
+                except MemoryError:
+                    pass
             line['other_configs'] = extra + other_configs(ctx, ia, ops)
         if world == 1 and not args.no_cpu:
             line['cpu_baseline'] = cpu_baseline(h, w, K, dcoef, k5)

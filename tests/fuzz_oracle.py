@@ -54,6 +54,11 @@ def main():
         pp = rng.normal(0, 2e-5, 2)                # (the warp's perspective terms, see below)
         K = int(rng.choice([3, 5, 7, 9]))          # (the fused chain's filter, see below)
         kern = rng.random((K, K))
+        # every third case: an exact outer product - the library then takes its separable K + K loops (knob
+        # rank1_sep, round 6) and must still be within the tolerance of the oracle's dense double sum
+        outer = rng.random(2 * K)
+        if case % 3 == 0:
+            kern = np.outer(outer[:K] - 0.3, outer[K:] + 0.1)
         kern /= kern.sum()
         cmode = str(rng.choice(['reflect', 'constant', 'wrap', 'mirror', 'nearest']))
         if os.environ.get('FUZZ_ONLY') and int(os.environ['FUZZ_ONLY']) != case:
