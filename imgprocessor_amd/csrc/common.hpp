@@ -57,6 +57,9 @@ struct ipa_tuning {
   int ring_remap = 1;     // standalone remap of batches on the ring kernel: 1 where it pays, 2 always
   int tile_warp = 1;      // perspective warps of float32 frames with the tile's source box in LDS (tile_warp.hpp):
                           // 0 never, 1 where it pays, 2 whenever the homography is covered
+  int tail_rows = -1;     // chunked batches on the shared-record loop: every XCD's share of the launch ends on strips of this
+                          // many rows (-1: a quarter of the strip height, at least 24; 0: uniform strips) - the workgroups
+                          // that run while the launch drains (WaveParams::seg_count)
   int rank1_sep = 3;      // dense K x K kernels that are an exact outer product ky (x) kx (how the reference obtains its
                           // Gaussians: scipy.ndimage.gaussian_filter, filters/fastFilter.py:42) run on the separable K + K
                           // loops wherever those cover the call: bit 0 the remap -> filter chains, bit 1 the plain filter
@@ -104,6 +107,7 @@ struct ipa_ctx {
   } tile_warp_plans[kTileWarpPlans];
   unsigned long tile_warp_clock = 0;
   unsigned long rank1_routed = 0;     // dense calls sent to the separable loops so far (read through ipa_ctx_get_tuning)
+  int tail_rows_used = 0;             // height of the short strips of the last such launch (0: uniform strips)
   int group_chunk_used = 0;           // groups per chunk of the last launch on the shared-record loop (0: all together)
 #if IPA_WITH_TILE_CHAIN
   unsigned long chain_launches = 0;   // launches of tile_chain.hpp's kernel (read through ipa_ctx_get_tuning: the tests' evidence of the path taken)

@@ -31,7 +31,7 @@ static void fused_big_launch_one(ipa_ctx* ctx, const FusedCall& f) {
   a.p.strips_x = (a.p.dw + G::OW - 1) / G::OW;
   a.p.strip_h = wave_strip_height(ctx, a.p.dh, a.p.dw, f.n_frames, K, true, 0, a.p.strips_x);
   a.p.strips = (unsigned)a.p.strips_x * (unsigned)((a.p.dh + a.p.strip_h - 1) / a.p.strip_h);
-  dim3 grid = wave_grid(ctx, a.p, f.n_frames, IPA_WPB, true, coord_is_table<typename Src::coord_type>::value),
+  dim3 grid = wave_grid(ctx, a.p, f.n_frames, IPA_WPB, true, coord_is_table<typename Src::coord_type>::value, false, K),
        block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_big_kernel<Src, K>), grid, block, 0, ctx->stream, a);
 }

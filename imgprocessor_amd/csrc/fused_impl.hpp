@@ -119,7 +119,7 @@ static void fused_launch_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c) {
   // frames (L2 fetch traffic -62 % on 16 x 4K), and even without shared rows the order measured
   // ~5 % faster than frame-after-frame
   dim3 grid = wave_grid(ctx, p, f.n_frames, IPA_WPB, true,
-                        coord_is_table<Coord>::value || shared_capable<Src, K>::value);
+                        coord_is_table<Coord>::value || shared_capable<Src, K>::value, false, K);
   dim3 block(64 * IPA_WPB);
   hipLaunchKernelGGL((wave_stencil_kernel<Src, K>), grid, block, 0, ctx->stream, p, s, w);
 }

@@ -79,6 +79,7 @@ const TuneName kTuneNames[] = {
     {"pipe", "IPA_PIPE_LOOPS", &ipa_tuning::pipe},
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
     {"rank1_sep", "IPA_RANK1_SEP", &ipa_tuning::rank1_sep},
+    {"tail_rows", "IPA_TAIL_ROWS", &ipa_tuning::tail_rows},
 };
 }  // namespace
 
@@ -93,6 +94,7 @@ static bool tune_in_range(const char* name, int v) {
   if (strcmp(name, "chain_steps") == 0) return v >= 0 && v <= 64;
   if (strcmp(name, "chain_frames") == 0) return v >= 0 && v <= 8;
   if (strcmp(name, "rank1_sep") == 0) return v >= 0 && v <= 3;
+  if (strcmp(name, "tail_rows") == 0) return v >= -1 && v <= 4096;
   if (strcmp(name, "tile_chain") == 0) return v >= 0 && v <= 2;
   return v == 0 || v == 1;
 }
@@ -122,6 +124,10 @@ int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
 #endif
   if (strcmp(name, "rank1_routed") == 0) {
     *value = (int)(ctx->rank1_routed & 0x7fffffff);
+    return IPA_OK;
+  }
+  if (strcmp(name, "tail_rows_used") == 0) {
+    *value = ctx->tail_rows_used;
     return IPA_OK;
   }
   if (strcmp(name, "group_chunk_used") == 0) {

@@ -329,8 +329,8 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   Cols c;
   c.xs = xs;
   c.xo = xs + lane * 4;
-  const int y0 = syi * p.strip_h;
-  const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
+  int y0, nrows;
+  if (!wave_strip_rows(p, syi, y0, nrows)) return;
   const bool writer = lane >= HL && lane < 64 - HL && c.xo < p.dw;
   float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
@@ -390,7 +390,7 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
   // plain rows (LoadRowSrc): frames share nothing - frame after frame, every XCD streaming through frames of its
   // own (knob frame_major, as the dense plain filters since round 4)
   dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value,
-                        std::is_same<Src, LoadRowSrc>::value), block(256);
+                        std::is_same<Src, LoadRowSrc>::value, -K), block(256);
   hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 

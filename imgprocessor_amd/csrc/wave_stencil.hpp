@@ -160,6 +160,17 @@ struct WaveParams {
   int group_chunk = 0; // frames_wg launches: n > 0 = the frame groups are walked n at a time - all strips of n
                        // groups (4 n frames), then the next n groups - instead of all groups of a strip
                        // together (set by wave_grid; knob group_chunk)
+  // SHORT strips at the end of every XCD's share of a chunked frames_wg launch (round 6).  A 64 x 4K launch pays ~95 us
+  // - a tenth of its duration - over the marginal cost of 64 more frames, and that cost scales with the height of its
+  // strips (2 T(64) - T(128) on the same memory: 95 / 61 / 47 / 41 us at 144 / 108 / 72 / 48 rows, tools/drain_probe.py):
+  // the last round of workgroups drains the machine.  Short strips everywhere pay that back in halo rows, and a
+  // block order that moves whole chunks to the end breaks the lock-step of the XCD pairs through the map rows
+  // (+4 %: each pair then fetches its own map rows from HBM instead of finding the other pairs' in the Infinity
+  // Cache).  So the geometry itself is non-uniform, identically for every chunk: a frame is `seg_count` segments of
+  // seg_rows rows - one per XCD of a chunk's XCD group -, each seg_tall strips of strip_h rows followed by seg_short
+  // strips of short_h rows; every XCD still owns a contiguous block range = one segment of one chunk, walks it in
+  // lock-step with the others, and ends on short workgroups.  seg_count = 0: uniform strips.
+  int seg_count = 0, seg_rows = 0, seg_tall = 0, seg_short = 0, short_h = 0;
   int frames_wg = 0;   // 1: the waves of a workgroup are consecutive FRAMES of one strip - the strip's
                        // map rows then reach the CU's L1 once per workgroup instead of once per
                        // frame (64 x 4K fused 5x5: 1.361 -> 1.335 ms); set by wave_grid
@@ -169,7 +180,7 @@ struct WaveParams {
 // share_maps: the row source reads a coordinate table the frames of a batch share (MapCoord)
 static inline dim3 wave_grid(ipa_ctx* ctx, WaveParams& p, int n_frames, int waves_per_block,
                              bool frames_inner, bool share_maps = false,
-                             bool may_frame_major = false) {
+                             bool may_frame_major = false, int taps = 0) {
   unsigned blocks = (p.strips + waves_per_block - 1) / waves_per_block;
   frames_inner = frames_inner && ctx->tune.frames_inner != 0;
   p.frames_wg = 0;
@@ -208,6 +219,45 @@ static inline dim3 wave_grid(ipa_ctx* ctx, WaveParams& p, int n_frames, int wave
       p.group_chunk = best;
       ctx->group_chunk_used = best;
     }
+    p.seg_count = 0;
+    ctx->tail_rows_used = 0;
+    if (p.group_chunk > 0 && ctx->tune.tail_rows != 0 && !p.skip && !p.rim_only) {
+      // knob tail_rows: n > 0 = short strips of that many rows, 0 = uniform strips, -1 = the measured rule (4K frames,
+      // in-process A/Bs, profiles/r06_micro.txt): what the shorter drain gives is roughly fixed per launch, what the short
+      // strips cost - K - 1 more halo rows and one more prologue per strip - grows with the kernel and the launch.
+      //   up to 16 frames: a quarter of the strip height for every kernel (16 x 4K: maps / homography + 9 + 9 -5.1 / -3.6 %,
+      //     maps + 7 + 7 -6.0 %, C4 -0.6 %, headline +0.5 %);
+      //   more: 3 / 5 taps a quarter (64 frames: headline 0.947 -> 0.924 ms, -2.3 .. -2.8 % on four boxes; 3 + 3 -2.6 %;
+      //     32 frames -0.7 %), from 64 frames the dense 7 x 7 half the strip height (C4 -1.0 .. -1.4 %; a quarter: level;
+      //     at 32 frames +1.0 %), separable 7 + 7 and every 9-tap kernel uniform (+1.3 .. +1.7 % otherwise);
+      //   128 frames: level either way.
+      // (taps > 0: a dense taps x taps filter, < 0: a separable one, 0: unknown = the short-kernel rule)
+      int hs = ctx->tune.tail_rows;
+      if (hs < 0) {
+        const int k = taps < 0 ? -taps : taps;
+        if (n_frames <= 16 || k <= 5) hs = p.strip_h / 4;
+        else if (taps == 7 && n_frames >= 64) hs = p.strip_h / 2;
+        else hs = 0;
+        if (hs > 0 && hs < 24) hs = 24;
+      }
+      const int chunks = groups / p.group_chunk;
+      // XCDs per chunk (the contiguous block ranges of xcd_swizzle): 8 / chunks; 8 chunks and more: whole chunks per XCD
+      const int segs = chunks >= kXcds ? (chunks % kXcds == 0 ? 1 : 0) : (kXcds % chunks == 0 ? kXcds / chunks : 0);
+      const int rows = segs ? (p.dh + segs - 1) / segs : 0;
+      if (segs && hs > 0 && hs < p.strip_h && rows >= 2 * p.strip_h) {
+        // about a fifth of a segment's rows on short strips; the tall ones cover the rest (the last of them clipped)
+        int nshort = (rows / 5 + hs - 1) / hs;
+        if (nshort < 1) nshort = 1;
+        const int tall_rows = rows - nshort * hs;
+        const int ntall = (tall_rows + p.strip_h - 1) / p.strip_h;
+        const unsigned long strips = (unsigned long)segs * (ntall + nshort) * p.strips_x;
+        if (tall_rows > 0 && strips * n_frames < (1ul << 31)) {
+          p.seg_count = segs; p.seg_rows = rows; p.seg_tall = ntall; p.seg_short = nshort; p.short_h = hs;
+          p.strips = (unsigned)strips;
+          ctx->tail_rows_used = hs;
+        }
+      }
+    }
     return dim3(p.strips * (unsigned)groups, 1);
   }
   if (frames_inner && n_frames > 1 && (unsigned long)blocks * n_frames < (1ul << 31)) {
@@ -216,6 +266,30 @@ static inline dim3 wave_grid(ipa_ctx* ctx, WaveParams& p, int n_frames, int wave
   }
   p.frames_inner = 0;
   return dim3(blocks, (unsigned)n_frames);
+}
+
+// rows [y0, y0 + nrows) of strip row syi; false: an empty strip (the clipped end of a segment)
+__device__ __forceinline__ bool wave_strip_rows(const WaveParams& p, int syi, int& y0, int& nrows) {
+  if (!p.seg_count) {
+    y0 = syi * p.strip_h;
+    nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
+    return nrows > 0;
+  }
+  const int per = p.seg_tall + p.seg_short, seg = syi / per, idx = syi - seg * per;
+  const int base = seg * p.seg_rows;
+  const int rows = p.dh - base < p.seg_rows ? p.dh - base : p.seg_rows;       // of this segment
+  int t0 = rows - p.seg_short * p.short_h;                                     // where its short strips begin
+  t0 = t0 > 0 ? t0 : 0;
+  if (idx < p.seg_tall) {
+    const int o = idx * p.strip_h;
+    y0 = base + o;
+    nrows = t0 - o < p.strip_h ? t0 - o : p.strip_h;
+  } else {
+    const int o = t0 + (idx - p.seg_tall) * p.short_h;
+    y0 = base + o;
+    nrows = rows - o < p.short_h ? rows - o : p.short_h;
+  }
+  return nrows > 0;
 }
 
 // columns of the filter domain a lane covers, resolved once per strip
@@ -774,8 +848,8 @@ __device__ __forceinline__ void wave_stencil_body(const WaveParams& p, Src src,
   Cols c;
   c.xs = xs;
   c.xo = xs + lane * 4;
-  const int y0 = syi * p.strip_h;
-  const int nrows = p.dh - y0 < p.strip_h ? p.dh - y0 : p.strip_h;
+  int y0, nrows;
+  if (!wave_strip_rows(p, syi, y0, nrows)) return;
   const bool writer = lane >= G::HL && lane < 64 - G::HL && c.xo < p.dw;
   float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
 

@@ -161,3 +161,38 @@ def test_group_chunk_read_back(ia):
         finally:
             ctx.set_tuning(**old)
         same_bits(got, flat, '%d frames: chunked order vs all groups together' % n)
+
+
+@pytest.mark.parametrize('n', [8, 16, 20, 32, 64])
+@pytest.mark.parametrize('shape', [(301, 517), (700, 530), (1080, 300)])
+def test_short_strips_at_the_end_of_every_xcd_share(ia, n, shape):
+    """knob tail_rows (round 6): chunked batches end every XCD's share of the launch on short strips - a
+    non-uniform strip geometry (segments of tall strips followed by short ones, WaveParams::seg_count) that
+    must tile the frame exactly as the uniform one does: identical bits for every short height, frame count
+    (chunks of 1 .. 4 groups, group counts that do not divide) and ragged size, dense and separable loops"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w)
+    mx, my, _, _ = radial_maps(h, w)
+    d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    dense = np.random.default_rng(2).random((5, 5))
+    g = gauss(5)
+    used = set()
+    for sh in (0, 40, 96):
+        for kern, what in ((dense, 'dense 5x5'), (np.outer(g, g), 'separable 5 + 5')):
+            ref = None
+            for tail in (0, -1, 8, 24, 50, 1000):
+                old = ctx.set_tuning(strip_h=sh, tail_rows=tail)
+                try:
+                    got = ops.remap_conv2d(d_src, dmx, dmy, kern).get()
+                    used.add(ctx.get_tuning('tail_rows_used'))
+                finally:
+                    ctx.set_tuning(**old)
+                if ref is None:
+                    ref = got
+                else:
+                    same_bits(got, ref, '%s, %d frames, strip_h %d, tail_rows %d' % (what, n, sh, tail))
+    # (8 frames = 2 groups: no chunks; 20 frames = 5 chunks of one group, which do not map onto the 8 XCDs' block
+    # ranges: uniform strips; the others must have taken the geometry at least once)
+    assert (used == {0}) == (n in (8, 20)), used
