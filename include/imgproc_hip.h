@@ -91,7 +91,11 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   the remap -> filter chains (float32 frames, bilinear taps, 3 / 5 / 7 / 9 taps), bit 1 the plain 9 x 9
  *   filter; default 3; the reference obtains its Gaussians separably: scipy.ndimage.gaussian_filter,
  *   filters/fastFilter.py:42).
- *   ipa_ctx_get_tuning also answers the read-only names "rank1_routed" (dense calls sent to the separable loops so far) and "group_chunk_used" (frame
+ *   "tail_rows" (chunked batches on the shared-record loop end every XCD's share of the launch on short strips -
+ *   the workgroups that run while the launch drains: -1 = the measured rule by taps and launch size, 0 = uniform
+ *   strips, n = short strips of n rows; same bits).
+ *   ipa_ctx_get_tuning also answers the read-only names "tail_rows_used" (height of the short strips of the last such
+ *   launch, 0 = uniform), "rank1_routed" (dense calls sent to the separable loops so far) and "group_chunk_used" (frame
  *   groups per chunk of the last launch on the shared-record loop; "group_chunk" values that do not divide
  *   the group count go to the nearest divisor).
  * Values are range-checked (IPA_ERR_BAD_ARG).  ipa_ctx_create reads the IPA_* environment
