@@ -37,6 +37,9 @@ namespace ipa {
 #define IPA_TILE_SLOW_INSIDE 1    // 0 (round 6, measured with IPA_TILE_RECOMPUTE = 1: slower, off): the rare tap-by-tap footprints of
                                   // float32 frames in a frame loop of their own behind the main one
 #endif
+#ifndef IPA_LZ_TABLE_STRIDE12
+#define IPA_LZ_TABLE_STRIDE12 1   // 0: the Lanczos4 weight table with rows of 8 floats (rounds 4 - 5)
+#endif
 #ifndef IPA_TILE_RECOMPUTE
 #define IPA_TILE_RECOMPUTE 0      // 1 (round 6, measured slower, off): the frame loop's scalar invariants recomputed per frame on
                                   // the scalar unit instead of hoisted and restored with v_readlane_b32 - see the frame loop
@@ -90,7 +93,7 @@ __host__ __device__ inline void tile_axis_box(double lo, double hi, int n, int& 
 // sample() of sampler.hpp tap by tap (rolled loops, a handful of registers): the same weights,
 // products and sums in the same order - for the few footprints a tile's box does not hold
 template <int INTERP, typename C>
-__device__ __forceinline__ float tile_slow_sample(const SrcView& s, C sx, C sy, float cval) {
+__device__ __forceinline__ float tile_slow_sample(const SrcView& s, C sx, C sy, float cval, int lz_stride = 8) {
   constexpr int NT = ntaps<INTERP>::value;
   if (!(sx > (C)-kCoordLimit && sx < (C)kCoordLimit && sy > (C)-kCoordLimit && sy < (C)kCoordLimit)) {
     if (s.border == IPA_BORDER_CONSTANT || sx != sx || sy != sy) return cval;
@@ -104,8 +107,8 @@ __device__ __forceinline__ float tile_slow_sample(const SrcView& s, C sx, C sy, 
     const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
     ix0 = (qx >> 5) - 3;
     iy0 = (qy >> 5) - 3;
-    wxr += (qx & 31) * 8;
-    wyr += (qy & 31) * 8;
+    wxr += (qx & 31) * lz_stride;
+    wyr += (qy & 31) * lz_stride;
   } else {
     float wx[NT], wy[NT];
     axis_split<INTERP, float, C>(s, sx, ix0, wx);
@@ -174,11 +177,17 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
   };
   extern __shared__ __attribute__((aligned(16))) float tile_lds[];
   __shared__ double corner[8];   // (homography: the tile's corners; tables: the waves' footprint spans)
-  __shared__ __attribute__((aligned(16))) float lz[kU16 ? 384 : (kLz ? 256 : 4)];
+  // float32 Lanczos4: the 32 x 8 weight table with its rows 12 floats apart (round 6).  A sample reads four 16-byte
+  // pieces of it - two rows picked by the lanes' own fractions -; at 8 floats per row the rows r, r + 8, r + 16, r + 24
+  // start on the same bank and the 16 lanes of a ds_read_b128 group pile up 2 - 4 deep on them (a fifth of the
+  // kernel's LDS cycles were bank conflicts, and its LDS arrays are busy 77 % of the launch); at 12 only r and r + 16 meet.
+  // (uint16 frames, Lanczos4: the same table, the same reads; uint16 bicubic keeps its 4-float rows behind 256 floats)
+  constexpr int kLzStride = (kLz && IPA_LZ_TABLE_STRIDE12) ? 12 : 8;
+  __shared__ __attribute__((aligned(16))) float lz[kLz ? 32 * kLzStride : (kU16 ? 384 : 4)];
   const unsigned tid = threadIdx.x, lane = tid & 63u;
   const unsigned wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if constexpr (kLz || kU16) lz[tid] = a.lanczos[tid];
-  if constexpr (kU16)
+  if constexpr (kLz || kU16) lz[(tid >> 3) * kLzStride + (tid & 7u)] = a.lanczos[tid];
+  if constexpr (kU16 && !kLz)
     if (tid < 128u) lz[256 + tid] = a.lanczos[256 + tid];
 
   const unsigned groups = ((unsigned)a.n_frames + a.frames_wg - 1) / (unsigned)a.frames_wg;
@@ -246,7 +255,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
       const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
       ix0 = (qx >> 5) - 3;
       iy0 = (qy >> 5) - 3;
-      tx[j] = __int_as_float(((qx & 31) << 3) | ((qy & 31) << 19));   // float offsets of both table rows
+      tx[j] = __int_as_float(((qx & 31) * kLzStride) | (((qy & 31) * kLzStride) << 16));   // float offsets of both table rows
       ty[j] = 0.f;
     } else if constexpr (kU16) {   // bicubic: rows of the float32 table at 256, 1/32-px coordinates
       const int qx = (int)ipa_rint(sx * (C)32), qy = (int)ipa_rint(sy * (C)32);
@@ -466,8 +475,8 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
     const int ix0 = (qx >> 5) - (ks / 2 - 1), iy0 = (qy >> 5) - (ks / 2 - 1);
     if (a.border == IPA_BORDER_CONSTANT && (ix0 >= a.sw || ix0 + ks <= 0 || iy0 >= a.sh || iy0 + ks <= 0))
       return cv16;
-    const float* wx = lz + (INTERP == kCubic ? 256 : 0) + (qx & 31) * ks;
-    const float* wy = lz + (INTERP == kCubic ? 256 : 0) + (qy & 31) * ks;
+    const float* wx = lz + (INTERP == kCubic ? 256 : 0) + (qx & 31) * (INTERP == kCubic ? ks : kLzStride);
+    const float* wy = lz + (INTERP == kCubic ? 256 : 0) + (qy & 31) * (INTERP == kCubic ? ks : kLzStride);
     const float cv = (float)cv16;
     const bool whole = ix0 >= 0 && iy0 >= 0 && ix0 + ks <= a.sw && iy0 + ks <= a.sh;
     auto tap = [&](int yy, int xx) -> float {
@@ -777,7 +786,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
           __builtin_amdgcn_raw_buffer_store_b16((short)slow_u16(sx, sy), drs,
                                                 (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
         else
-          store_px(tile_slow_sample<INTERP, C>(s, sx, sy, a.cval), y);
+          store_px(tile_slow_sample<INTERP, C>(s, sx, sy, a.cval, kLzStride), y);
       }
     }
     }
@@ -795,7 +804,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
           if (x >= a.dw || y >= a.dh) continue;
           C sx, sy;
           coord.get(x, y, sx, sy);
-          const float o = tile_slow_sample<INTERP, C>(s, sx, sy, a.cval);
+          const float o = tile_slow_sample<INTERP, C>(s, sx, sy, a.cval, kLzStride);
           __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(o), drs, (int)((long)y * a.dpitch + x) << kEsh, 0, 0);
         }
       }
