@@ -37,6 +37,9 @@ namespace ipa {
 #define IPA_TILE_SLOW_INSIDE 1    // 0 (round 6, measured with IPA_TILE_RECOMPUTE = 1: slower, off): the rare tap-by-tap footprints of
                                   // float32 frames in a frame loop of their own behind the main one
 #endif
+#ifndef IPA_TILE_PITCH_ODD
+#define IPA_TILE_PITCH_ODD 0      // 1: the LDS box pitch among the odd candidates only (rounds 4 - 5)
+#endif
 #ifndef IPA_LZ_TABLE_STRIDE12
 #define IPA_LZ_TABLE_STRIDE12 1   // 0: the Lanczos4 weight table with rows of 8 floats (rounds 4 - 5)
 #endif
@@ -908,9 +911,13 @@ static inline int tile_warp_pitch(const double* m, int dh, int dw, int min_pitch
     sx = (m[0] * u + m[1] * v + m[2]) * iw;
     sy = (m[3] * u + m[4] * v + m[5]) * iw;
   };
+  // (rounds 4 - 5 tried the odd pitches only.  A line that advances about one column per lane puts a 32-lane group on 32
+  // consecutive columns, and then a pitch that is a MULTIPLE of 32 is conflict-free whatever rows the line crosses - the
+  // bank is the column; round 6 counts every pitch: C5's bicubic warp under 7 degrees read its taps at 46 % conflict cycles)
   int best = min_pitch | 1;
   long best_cost = -1;
-  for (int P = min_pitch | 1; P < (min_pitch | 1) + 32; P += 2) {
+  for (int P = IPA_TILE_PITCH_ODD ? (min_pitch | 1) : min_pitch; P < (min_pitch | 1) + (IPA_TILE_PITCH_ODD ? 32 : 33);
+       P += IPA_TILE_PITCH_ODD ? 2 : 1) {
     if (tile_warp_lds_bytes<NT>(P, rows) > kWarpTileLdsBytes) break;
     long cost = 0;
     for (int py = 0; py < 3; py++)

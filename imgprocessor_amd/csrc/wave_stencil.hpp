@@ -635,6 +635,20 @@ __device__ __forceinline__ void window_pairs(const float* row, unsigned lane, un
       if constexpr ((i & 1) == 0) pair[m] = e[i / 2];
       else pair[m] = pk_mov_hi_lo(e[i / 2], e[i / 2 + 1]);
     });
+  } else if constexpr (IPA_WINDOW_B128 != 0 && H == 5 && kRowPad == 4) {
+    // 11 taps: the window 4 L - 5 .. 4 L + 8 lies in the 20 floats 4 L - 8 .. 4 L + 11: five aligned 16-byte reads (the first
+    // starts 4 floats in front of the row for lane 0, the last ends 4 floats behind it for lane 63: the lead-in / lead-out
+    // floats the kernels with H > kRowPad reserve around their rows, wave_stencil_body::kLead).  The plain 11 x 11 spent 72 %
+    // of its LDS cycles on the conflicts of the thirteen 8-byte reads (LDS arrays busy 62 % of the launch).
+    const v4f* wv = reinterpret_cast<const v4f*>(row + 4u * lane) - 1;
+    const v4f q0 = wv[0], q1 = wv[1], q2 = wv[2], q3 = wv[3], q4 = wv[4];
+    const v2f e[10] = {v2f{q0.x, q0.y}, v2f{q0.z, q0.w}, v2f{q1.x, q1.y}, v2f{q1.z, q1.w}, v2f{q2.x, q2.y},
+                       v2f{q2.z, q2.w}, v2f{q3.x, q3.y}, v2f{q3.z, q3.w}, v2f{q4.x, q4.y}, v2f{q4.z, q4.w}};
+    static_for<0, K + 2>([&](auto M) {
+      constexpr int m = decltype(M)::value, i = 8 - H + m;   // pair[m] = floats i, i + 1 of the twenty
+      if constexpr ((i & 1) == 0) pair[m] = e[i / 2];
+      else pair[m] = pk_mov_hi_lo(e[i / 2], e[i / 2 + 1]);
+    });
   } else {
     // Pairs at even and at odd m are read through two offsets the compiler cannot relate:
     // read once, the odd pairs would straddle register pairs and fall back to scalar fmas.

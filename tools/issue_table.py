@@ -22,6 +22,8 @@ CUS, SIMDS = 256, 1024
 UNITS = {   # units of work per launch: (frames, what)
     'c4': (64, 'row'), 'fused': (64, 'row'), 'lz4q': (16, 'px64'), 'cubicq': (16, 'px64'),
     'c3lin': (16, 'row'), 'c3cubic': (16, 'px64'),
+    'lz16q': (16, 'px64'), 'lz8q': (16, 'px64'), 'remaplin': (16, 'px64'), 'remaplz4': (16, 'px64'),
+    'c5': (16, 'row'), 'conv11': (16, 'row'),
 }
 H, W = 2160, 3840
 
@@ -38,6 +40,8 @@ def main():
     root, tag = sys.argv[1], sys.argv[2]
     out = {}
     for case, (frames, what) in UNITS.items():
+        if not os.path.isdir(os.path.join(root, 'pmc_%s_%s' % (tag, case))):
+            continue
         per = counters(os.path.join(root, 'pmc_%s_%s' % (tag, case)))
         per = {k: v for k, v in per.items() if 'build_' not in k and 'rocclr' not in k and 'store_coords' not in k}
         if not per:

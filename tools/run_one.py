@@ -58,6 +58,15 @@ def main():
     k7 = np.random.default_rng(123).random((7, 7))
     k7 /= k7.sum()
     u16 = ctx.to_device(np.round(src.get() * 4095).astype(np.uint16)) if case == 'c4' else None
+    xsrc = xdst = None
+    if case == 'lz16q':
+        xsrc = ctx.to_device(np.round(src.get() * 65535).astype(np.uint16)); xdst = ctx.empty((batch, h, w), np.uint16)
+    if case == 'lz8q':
+        xsrc = ctx.to_device(np.round(src.get() * 255).astype(np.uint8)); xdst = ctx.empty((batch, h, w), np.uint8)
+    k11 = np.random.default_rng(321).random((11, 11))
+    k11 /= k11.sum()
+    ang = np.deg2rad(7.0)
+    R7 = np.array([[np.cos(ang), -np.sin(ang), 150.0], [np.sin(ang), np.cos(ang), -100.0], [4e-6, -2e-6, 1.0]])
     for _ in range(steps):
         if case == 'cubic_maps':
             ops.remap(src, dmx, dmy, interpolation='cubic', out=dst)
@@ -75,6 +84,16 @@ def main():
             ops.conv2d(src, k5, out=dst)
         elif case == 'copy':
             dst.copy_from(src)
+        elif case in ('lz16q', 'lz8q'):   # PerspectiveCorrection's default on the camera's uint16 / uint8 frames
+            ops.warp_perspective(xsrc, Hq, (h, w), interpolation='lanczos4', out=xdst)
+        elif case == 'remaplin':          # LensDistortion.correct itself: cv2.remap from the map pair (tile kernel)
+            ops.remap(src, dmx, dmy, out=dst)
+        elif case == 'remaplz4':
+            ops.remap(src, dmx, dmy, interpolation='lanczos4', out=dst)
+        elif case == 'c5':                # bicubic warp (rotation + perspective) + dense 11 x 11
+            ops.warp_perspective_conv2d(src, R7, (h, w), k11, 'cubic', out=dst)
+        elif case == 'conv11':
+            ops.conv2d(src, k11, out=dst)
         elif case in ('lz4q', 'cubicq', 'linq'):   # bench.py's C3 homography (quad -> full frame), standalone warp
             ops.warp_perspective(src, Hq, (h, w), interpolation={'lz4q': 'lanczos4', 'cubicq': 'cubic', 'linq': 'linear'}[case], out=dst)
         elif case in ('c3lin', 'c3cubic'):
