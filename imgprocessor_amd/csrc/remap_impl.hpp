@@ -592,7 +592,10 @@ static int tile_warp_launch_map(ipa_ctx* ctx, const RemapParams& p, const MapCoo
   // tile with its halo and some drift - keeps them; 16 x 4K: 0.228 against 0.281 ms)
   // bicubic: beyond a zoom of 1.4 its boxes make it slower than the gather kernel (1.7: 0.66
   // against 0.48 ms) - a reserve that does not hold them hands such maps back through the count
-  t.pitch = NT == 8 ? 127 : 97;
+  // (pitch: the homography's boxes get theirs from a conflict count over its tap lines, tile_warp_pitch; a map is device
+  // data.  Measured on the lens maps, 16 x 4K, 97 / 127 against 96 / 128: bilinear 0.2547 / 0.2565 ms, bicubic 0.3510 /
+  // 0.3494, Lanczos4 0.6157 / 0.6086 - a multiple of 32 pays for the kernel whose LDS arrays are the bound)
+  t.pitch = NT == 8 ? 128 : 97;
   t.rows = NT == 2 ? 48 : (NT == 8 ? 72 : 56);
   // A map whose tiles need more - the host cannot know: the map is device data - sends the pixels
   // outside the box tap by tap, at 10 - 100 times the cost (16 x 4K zoomed out 2.5 x: Lanczos4

@@ -141,6 +141,8 @@ def main():
             'fused9': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k9, out=m.dst),
             'fused11': lambda o=ops, m=mod: o.remap_conv2d(m.src, m.dmx, m.dmy, k11, out=m.dst),
             'remap': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, out=m.dst),
+            'remapcubic': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, 'cubic', out=m.dst),
+            'remaplz4': lambda o=ops, m=mod: o.remap(m.src, m.dmx, m.dmy, 'lanczos4', out=m.dst),
             # perspective warps on the tile kernel under a rotation of 15 / 45 degrees
             'lin15': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(15), (h, w), 'linear', out=m.dst),
             'lin45': lambda o=ops, m=mod: o.warp_perspective(m.src, rot(45), (h, w), 'linear', out=m.dst),
