@@ -37,6 +37,9 @@ namespace ipa {
 #define IPA_TILE_SLOW_INSIDE 1    // 0 (round 6, measured with IPA_TILE_RECOMPUTE = 1: slower, off): the rare tap-by-tap footprints of
                                   // float32 frames in a frame loop of their own behind the main one
 #endif
+#ifndef IPA_TILE_CUBIC_READS_FIRST
+#define IPA_TILE_CUBIC_READS_FIRST 1   // 0: the taps of a pixel pair read and summed row by row
+#endif
 #ifndef IPA_TILE_PITCH_ODD
 #define IPA_TILE_PITCH_ODD 0      // 1: the LDS box pitch among the odd candidates only (rounds 4 - 5)
 #endif
@@ -712,11 +715,31 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
         const float* tpa = tile_lds + (ad[j0] < 0 ? 0 : ad[j0]);
         const float* tpb = tile_lds + (ad[j0 + 1] < 0 ? 0 : ad[j0 + 1]);
         v2f o = v2f{0.f, 0.f};
+        // (volatile: one ds_read_b32 per tap, each straight into its half of a register pair - merged into
+        // ds_read2_b32 the taps of ONE pixel share a pair and 16 moves per pixel pair put them apart again.
+        // All 32 reads of the pixel pair first, then the sums: read and used row by row, only 8 reads were in flight
+        // and their latency stood in front of every tap row - the kernel neither issued (0.70) nor kept its LDS
+        // arrays busy (0.47))
+        typedef const volatile __attribute__((address_space(3))) float* lds_vf;
+#if IPA_TILE_CUBIC_READS_FIRST
+        v2f tp[4][4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          // (volatile: one ds_read_b32 per tap, each straight into its half of a register pair - merged into
-          // ds_read2_b32 the taps of ONE pixel share a pair and 16 moves per pixel pair put them apart again)
-          typedef const volatile __attribute__((address_space(3))) float* lds_vf;
+          lds_vf tra = (lds_vf)(tpa + r * a.pitch);
+          lds_vf trb = (lds_vf)(tpb + r * a.pitch);
+#pragma unroll
+          for (int c = 0; c < 4; c++) tp[r][c] = v2f{tra[c], trb[c]};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          v2f rs = wx[0] * tp[r][0];
+#pragma unroll
+          for (int c = 1; c < 4; c++) rs = ipa_fma(wx[c], tp[r][c], rs);
+          o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
+        }
+#else
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
           lds_vf tra = (lds_vf)(tpa + r * a.pitch);
           lds_vf trb = (lds_vf)(tpb + r * a.pitch);
           v2f rs = wx[0] * v2f{tra[0], trb[0]};
@@ -724,6 +747,7 @@ tile_warp_kernel(TileWarpArgs a, Coord coord) {
           for (int c = 1; c < 4; c++) rs = ipa_fma(wx[c], v2f{tra[c], trb[c]}, rs);
           o = r == 0 ? wy[0] * rs : ipa_fma(wy[r], rs, o);
         }
+#endif
         if (ad[j0] >= 0 && x < a.dw && ya < a.dh) store_px(o.x, ya);
         if (ad[j0 + 1] >= 0 && x < a.dw && yb < a.dh) store_px(o.y, yb);
         __builtin_amdgcn_sched_barrier(0);
