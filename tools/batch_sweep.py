@@ -27,8 +27,6 @@ dmx, dmy = ops.build_undistort_map(K, dist, K, h, w, ctx=ctx, device=True)
 NMAX = 256
 one = np.random.default_rng(0).random((16, h, w), dtype=np.float32)
 src = ctx.empty((NMAX, h, w), np.float32)
-for i in range(NMAX // 16):
-    src.frame(i * 16).ctx  # noqa: B018
 dst = ctx.empty((NMAX, h, w), np.float32)
 host = np.concatenate([one] * (NMAX // 16))
 src.set(host)
