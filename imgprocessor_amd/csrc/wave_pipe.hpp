@@ -369,9 +369,13 @@ template <typename Src, int K, bool STREAM> struct geom_halo {
 // taps lie inside the source (bits 8 + 4 k .. 11 + 4 k of the interior word; rows that have none
 // pay nothing), and the blend replaces the others by the border value: sample()'s arithmetic in
 // sample()'s order, no tap inside = the border value itself.
-// PACKED (uint16 frames: ONE dword at the byte offset of the left tap holds both taps of a row):
-// where that offset is negative - the left tap in column -1 of row 0 - the range check drops the
-// whole dword, the right tap with it: bit 31 sends such a lane through sample().
+// The one footprint whose INSIDE tap the gathers cannot deliver: the left tap in column -1 of row 0 (ix0 = -1,
+// iy0 = 0 or -1).  The byte offset of that tap row is -4; uint16 frames hold both taps of a row in ONE dword at
+// that offset and the range check drops it whole, and float32 frames fetch the right tap - pixel (0, 0) - as
+// `offen offset:4` from the same -4: the hardware range-checks the UNSIGNED sum without wrapping it, so the load
+// returns 0 for a pixel that is there (found by tools/fuzz_paths.py seed 63 in round 6: one or two samples per
+// frame where the map crosses the source's top-left corner).  Bit 31 sends such a lane through sample().
+// (`PACKED` is kept in the signature for the callers; both element types take the same rule.)
 constexpr unsigned kBorderSlow = 1u << 31;
 template <int NS, int QM, bool PACKED, typename C>
 __device__ __forceinline__ unsigned border_tap_bits(const SrcView& s, const C (&sx)[NS],
@@ -390,8 +394,10 @@ __device__ __forceinline__ unsigned border_tap_bits(const SrcView& s, const C (&
       const unsigned b = ((y0 && x0) ? 1u : 0u) | ((y0 && x1) ? 2u : 0u) | ((y1 && x0) ? 4u : 0u) |
                          ((y1 && x1) ? 8u : 0u);
       vb |= (ok ? b : 0u) << (8 + 4 * k);
+#ifdef IPA_DEBUG_CORNER_AS_ROUND5   // (test builds only: the rule as it was - float32 frames not flagged - to see the tests fail)
       if constexpr (PACKED)
-        if (ok && ix0 == -1 && (iy0 == 0 || iy0 == -1) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
+#endif
+      if (ok && ix0 == -1 && (iy0 == 0 || iy0 == -1) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
     }
   }
   return vb;
@@ -574,17 +580,19 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
         // ones outside the source replaced by the border value (border_tap_bits / border_blend)
 #pragma unroll
         for (int k = 0; k < NS; k++) {
-          if (!((interior >> k) & 1u))
+          if (!((interior >> k) & 1u) && !(interior & kBorderSlow))
             xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
                 border_blend(top[2 * k], top[2 * k + 1], bot[2 * k], bot[2 * k + 1], tx[k], ty[k],
                              (interior >> (8 + 4 * k)) & 15u, src.cval);
         }
-      } else {
-        // the other border modes (rare): redo them tap by tap, straight into the LDS row - ONE
-        // copy of the border-aware sampler per step (a loop, not unrolled)
+      }
+      if (__builtin_amdgcn_ballot_w64(s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow) != 0u)) {
+        // the other border modes, and the lanes border_tap_bits left to it (the source's top-left
+        // corner; rare): redo them tap by tap, straight into the LDS row - ONE copy of the
+        // border-aware sampler per step (a loop, not unrolled)
 #pragma unroll 1
         for (int k = 0; k < NS; k++) {
-          if (!((interior >> k) & 1u)) {
+          if (!((interior >> k) & 1u) && (s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow))) {
             const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
             float sx, sy;
             src.coord.get(col, yb + t, sx, sy);

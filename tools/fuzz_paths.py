@@ -2,7 +2,8 @@
 """Randomised differential check of the alternative kernels against the plain ones (GPU):
 ring remap, ring big, frame-pair kernel, lens map cache - every result must have the bits of
 the per-frame / gather kernels.  usage: python tools/fuzz_paths.py [n_cases] [seed] [big]
-(big: frames up to 2200 x 3900 instead of 420 x 1300)"""
+(big: frames up to 2200 x 3900 instead of 420 x 1300; FUZZ_ONLY=<case> runs one case of the sequence,
+FUZZ_DUMP=<file.npz> stores the inputs and both results of the last mismatch)"""
 import os
 import sys
 
@@ -119,6 +120,10 @@ def main():
                             rows = np.bincount(idx[:, 1], minlength=bad.shape[-2])
                             print('   rows with mismatches (row: count): %s' % ', '.join(
                                 '%d: %d' % (r, c) for r, c in enumerate(rows) if c)[:600])
+                            if os.environ.get('FUZZ_DUMP'):   # the inputs and both results, for a look on the CPU
+                                np.savez_compressed(os.environ['FUZZ_DUMP'], src=src, M=M, k=k, mx=mx, my=my, Kc=Kc,
+                                                    dist=dist, got=got, ref=ref, cval=cval, what=name, alt=repr(alt),
+                                                    interp=finterp, border=border, cmode=cmode)
                             print('MISMATCH case %d %s %r rep %d: %dx%d -> %dx%d n=%d interp=%s '
                                   'border=%s K=%d cmode=%s' % (case, name, alt, rep, h, w, dh, dw,
                                                                n, interp, border, K, cmode))
