@@ -375,7 +375,6 @@ template <typename Src, int K, bool STREAM> struct geom_halo {
 // `offen offset:4` from the same -4: the hardware range-checks the UNSIGNED sum without wrapping it, so the load
 // returns 0 for a pixel that is there (found by tools/fuzz_paths.py seed 63 in round 6: one or two samples per
 // frame where the map crosses the source's top-left corner).  Bit 31 sends such a lane through sample().
-// (`PACKED` is kept in the signature for the callers; both element types take the same rule.)
 constexpr unsigned kBorderSlow = 1u << 31;
 template <int NS, int QM, bool PACKED, typename C>
 __device__ __forceinline__ unsigned border_tap_bits(const SrcView& s, const C (&sx)[NS],
@@ -394,10 +393,16 @@ __device__ __forceinline__ unsigned border_tap_bits(const SrcView& s, const C (&
       const unsigned b = ((y0 && x0) ? 1u : 0u) | ((y0 && x1) ? 2u : 0u) | ((y1 && x0) ? 4u : 0u) |
                          ((y1 && x1) ? 8u : 0u);
       vb |= (ok ? b : 0u) << (8 + 4 * k);
-#ifdef IPA_DEBUG_CORNER_AS_ROUND5   // (test builds only: the rule as it was - float32 frames not flagged - to see the tests fail)
+#ifdef IPA_DEBUG_CORNER_AS_ROUND5   // (test builds only: the rules as they were, to see the tests fail)
       if constexpr (PACKED)
-#endif
+        if (ok && ix0 == -1 && (iy0 == 0 || iy0 == -1) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
+#else
       if (ok && ix0 == -1 && (iy0 == 0 || iy0 == -1) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
+      // PACKED, the opposite corner: the left tap in the LAST column of the LAST row - the dword that holds it
+      // ends two bytes past the frame and is dropped whole (tools/fuzz_corners.py, round 6)
+      if constexpr (PACKED)
+        if (ok && ix0 == s.w - 1 && (iy0 == s.h - 1 || iy0 == s.h - 2) && s.w > 0 && s.h > 0) vb |= kBorderSlow;
+#endif
     }
   }
   return vb;

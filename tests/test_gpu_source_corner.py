@@ -154,6 +154,42 @@ def test_every_lane_of_the_rim_strip(ia, oracle, loop, K):
         ctx.set_tuning(**old)
 
 
+@pytest.mark.parametrize('loop', list(LOOPS))
+def test_last_pixel_of_uint16_frames(ia, oracle, loop):
+    """the OPPOSITE corner, uint16 frames (one dword holds both taps of a tap row): the footprint whose left tap is
+    the last pixel of the last row - that dword ends two bytes past the frame and the range check can drop it whole,
+    the pixel with it (tools/fuzz_corners.py, round 6: 405 of 4095 off in 2 samples per frame, every frame of the
+    batch - at 12 x 170 px and 116 x 65 px frames, not at 23 x 170: it depends on where the frame ends, so the
+    frame size is swept through every residue of 16 bytes and both failing geometries are here as drawn)."""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    k = kern(3)
+    cases = [(12, 170, 71, 340, 12, np.array([[9.99999272e-01, 1.20700418e-03, -4.71179433], [-1.20700418e-03, 9.99999272e-01, -38.236679],
+                                                [0.0, 0.0, 1.0]])),
+             (116, 65, 160, 108, 8, np.array([[1.04, 0.0, -7.25123345], [0.0, 1.04, -15.95355581], [0.0, 0.0, 1.0]]))]
+    for h in (12, 23):
+        for w in range(160, 177):
+            cases.append((h, w, h + 20, w + 40, 4, np.array([[1.0, 0.0, -7.3], [0.0, 1.0, -5.4], [0.0, 0.0, 1.0]])))
+    old = ctx.set_tuning(**LOOPS[loop])
+    try:
+        for h, w, dh, dw, n, M in cases:
+            y, x = np.mgrid[0:dh, 0:dw].astype(np.float64)
+            mx = (M[0, 0] * x + M[0, 1] * y + M[0, 2]).astype(np.float32)
+            my = (M[1, 0] * x + M[1, 1] * y + M[1, 2]).astype(np.float32)
+            dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+            src = frames(n, h, w, np.uint16)
+            src[:, -1, -1] = 4095
+            d = ctx.to_device(src)
+            plain = ops.remap(d, dmx, dmy, 'linear', 'constant', 17).get()
+            got = ops.remap_conv2d(d, dmx, dmy, k, 'linear', 'constant', 17.0).get()
+            for f in (0, n - 1):
+                assert np.array_equal(plain[f], oracle.remap(src[f], mx, my, oracle.LINEAR, oracle.CONSTANT, 17.0)), (h, w, n, f)
+                mid = oracle.remap(src[f], mx, my, oracle.LINEAR, oracle.CONSTANT, 17.0, out_dtype=np.float32)
+                assert_close(got[f], oracle.conv2d(mid, k), 1e-5, 0.04, '%s, %d frames of %d x %d px, frame %d' % (loop, n, h, w, f))
+    finally:
+        ctx.set_tuning(**old)
+
+
 def test_lens_model_through_the_corner(ia, oracle):
     """LensDistortion with the reference's own camera matrix (alpha = 1 keeps every source pixel: the source's
     corners lie INSIDE the undistorted picture) - the rim the constant border fills passes all four corners"""

@@ -103,7 +103,8 @@ def main():
             old = ctx.set_tuning(**plain)
             try:
                 ref = fn().get()
-                for alt in alts:
+                # (last: the library's OWN defaults for every knob `plain` touched - the combination callers get)
+                for alt in alts + [dict(old)]:
                     ctx.set_tuning(**plain)
                     ctx.set_tuning(**alt)
                     for rep in range(2):  # the second call takes the cached plan / hint
