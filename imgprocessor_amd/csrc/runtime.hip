@@ -80,6 +80,7 @@ const TuneName kTuneNames[] = {
     {"u8_lz_lds", "IPA_U8_LZ_LDS", &ipa_tuning::u8_lz_lds},
     {"rank1_sep", "IPA_RANK1_SEP", &ipa_tuning::rank1_sep},
     {"tail_rows", "IPA_TAIL_ROWS", &ipa_tuning::tail_rows},
+    {"sep_u16", "IPA_SEP_U16", &ipa_tuning::sep_u16},
 };
 }  // namespace
 

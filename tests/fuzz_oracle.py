@@ -108,7 +108,7 @@ def main():
                                               K, cmode, d))
                         break
         # ... and the separable form (remap -> ky then kx), 3 / 5 / 7 / 9 / 13 taps per axis
-        if dt == np.float32 and iname != 'nearest':
+        if dt in (np.float32, np.uint16) and iname != 'nearest':
             ny_, nx_ = int(sep[0]), int(sep[1])
             if ny_ < dh and nx_ < dw:
                 ky_, kx_ = sepw[:ny_] / sepw[:ny_].sum(), sepw[:nx_][::-1] / sepw[:nx_].sum()

@@ -79,12 +79,51 @@ def test_not_rank1_stays_dense(ia, oracle):
         assert routed(ctx) == before, name
         want = oracle.conv2d(oracle.remap(src[0], mx, my), k)
         assert_close(got[0], want, 1e-5, 1e-5 * max(np.abs(want).max(), 1e-30), name)
-    # uint16 frames and bicubic taps: the separable chain would take two launches - dense
-    u16 = ctx.to_device(np.round(src * 4095).astype(np.uint16))
+    # bicubic taps: the separable chain would take two launches - dense
     before = routed(ctx)
-    ops.remap_conv2d(u16, dmx, dmy, np.outer(g, g)).get()
     ops.remap_conv2d(d_src, dmx, dmy, np.outer(g, g), 'cubic').get()
     assert routed(ctx) == before
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 8])
+@pytest.mark.parametrize('K', [3, 5, 7, 9])
+def test_uint16_frames_take_the_one_kernel_separable_chain(ia, oracle, n, K):
+    """round 6: map-based bilinear remap -> separable K + K filter on uint16 frames (camera frames as
+    transformations.toFloatArray ingests them) runs in ONE kernel as float32 frames always did (knob sep_u16), and an
+    outer-product K x K kernel then takes that route too; both against the oracle, the two-launch form beside it"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 150, 610
+    src = frames(n, h, w, np.uint16)
+    mx, my, Kc, dist = radial_maps(h, w, shift=3.3)
+    mx = mx - np.float32(20.0)              # a rim of border pixels on the left: the filter sees the constant border
+    ky, kx = gauss(K), gauss(K, 0.8)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    got = ops.remap_sepconv2d(d, dmx, dmy, ky, kx, 'linear', 'constant', 100.0).get()
+    before = routed(ctx)
+    dense_call = ops.remap_conv2d(d, dmx, dmy, np.outer(ky, kx), 'linear', 'constant', 100.0).get()
+    assert routed(ctx) == before + 1, 'uint16 frames + maps + outer product: the separable chain'
+    old = ctx.set_tuning(sep_u16=0)
+    try:
+        two = ops.remap_sepconv2d(d, dmx, dmy, ky, kx, 'linear', 'constant', 100.0).get()
+        before = routed(ctx)
+        dense = ops.remap_conv2d(d, dmx, dmy, np.outer(ky, kx), 'linear', 'constant', 100.0).get()
+        # (9 x 9 on uint16 frames is remap -> workspace -> plain filter, and the plain 9 x 9 filter has its own route)
+        assert routed(ctx) == before + (1 if K == 9 else 0), 'knob off: the dense loop'
+    finally:
+        ctx.set_tuning(**old)
+    for f in range(n):
+        mid = oracle.remap(src[f], mx, my, oracle.LINEAR, oracle.CONSTANT, 100.0, out_dtype=np.float32)
+        want = oracle.sepconv2d(mid, ky, kx)
+        for name, a in (('one kernel', got), ('routed dense call', dense_call), ('two launches', two), ('dense loop', dense)):
+            assert_close(a[f], want, 1e-5, 1e-5 * 4095, '%s, %d+%d taps, frame %d of %d' % (name, K, K, f, n))
+    # the lens model by value: its cached map takes the same route
+    before = routed(ctx)
+    got_u = ops.undistort_conv2d(d, Kc, dist, Kc, np.outer(ky, kx)).get()
+    assert routed(ctx) >= before + 1
+    umx, umy = oracle.build_undistort_map(Kc, dist, Kc, h, w)
+    want = oracle.conv2d(oracle.remap(src[n - 1], umx, umy, out_dtype=np.float32), np.outer(ky, kx))
+    assert_close(got_u[n - 1], want, 1e-5, 1e-5 * 4095, 'undistort + outer product, uint16 frames')
 
 
 def test_rank1_other_coordinate_sources(ia, oracle):

@@ -58,7 +58,7 @@ def main():
     k7 = rng.random((7, 7))
     k7 /= k7.sum()
     u16 = None
-    if 'c4' in what:
+    if {'c4', 'c4g7', 'c4g5', 'c4sep9', 'c4sep5'} & set(what):
         u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
                             if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
     Hm = None
@@ -91,6 +91,11 @@ def main():
         'warp5': lambda: ops.warp_perspective_conv2d(src, Hm, (h, w), k5, 'linear', out=dst),
         'sep9map': lambda: ops.remap_sepconv2d(src, dmx, dmy, g9, g9, out=dst),
         'c4': lambda: ops.remap_conv2d(u16, dmx, dmy, k7, out=dst),
+        # uint16 frames + Gaussian outer products / separable taps (knob sep_u16: one kernel against two launches / dense)
+        'c4g7': lambda: ops.remap_conv2d(u16, dmx, dmy, gk[7], out=dst),
+        'c4g5': lambda: ops.remap_conv2d(u16, dmx, dmy, gk[5], out=dst),
+        'c4sep9': lambda: ops.remap_sepconv2d(u16, dmx, dmy, g9, g9, out=dst),
+        'c4sep5': lambda: ops.remap_sepconv2d(u16, dmx, dmy, gk1[5], gk1[5], out=dst),
         'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
         'fused5': lambda: ops.remap_conv2d(src, dmx, dmy, k5, out=dst),
         'conv5': lambda: ops.conv2d(src, k5, out=dst),

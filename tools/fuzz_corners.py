@@ -19,6 +19,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, R)
 import imgprocessor_amd as ia  # noqa: E402
 from imgprocessor_amd import ops  # noqa: E402
+from imgprocessor_amd.utils.geometry import getOptimalNewCameraMatrix  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 INTERPS = {'nearest': oracle.NEAREST, 'linear': oracle.LINEAR, 'cubic': oracle.CUBIC_KEYS,
@@ -75,8 +76,17 @@ def main():
         g = rng.random(K) + 0.1
         g /= g.sum()
         cmode = str(rng.choice(['reflect', 'constant', 'wrap', 'mirror', 'nearest']))
+        k1 = float(rng.uniform(-0.25, 0.1))
         if os.environ.get('FUZZ_ONLY') and int(os.environ['FUZZ_ONLY']) != case:
             continue
+        lens = None
+        if h >= 24 and w >= 24:
+            fxy = float(max(h, w))
+            Kc = np.array([[fxy, 0, (w - 1) / 2.0], [0, fxy, (h - 1) / 2.0], [0, 0, 1.0]])
+            dist = np.array([k1, 0.02, 1e-3, -5e-4, 0.0])
+            newK, _ = getOptimalNewCameraMatrix(Kc, dist, (w, h), 1)
+            lmx, lmy = oracle.build_undistort_map(Kc, dist, newK, h, w)
+            lens = (Kc, dist, newK, lmx, lmy)
         what = '%s %dx%d -> %dx%d n=%d %s %s cval %g, corner at (%.2f, %.2f), K=%d %s' % (
             np.dtype(dt).name, h, w, dh, dw, n, iname, bname, cval, ox, oy, K, cmode)
         d_src, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
@@ -99,6 +109,20 @@ def main():
                          ('warp + K+K', lambda: ops.warp_perspective_sepconv2d(d_src, M, (dh, dw), g, g[::-1].copy(), iname,
                                                                                bname, cval, cmode),
                           lambda f: oracle.sepconv2d(mid_w(f), g, g[::-1].copy(), cmode), True)]
+        # the lens model with the reference's own camera matrix (getOptimalNewCameraMatrix, alpha = 1: every source
+        # pixel kept - all four corners inside the undistorted picture), coordinates evaluated in the kernels
+        if lens is not None:
+            Kc, dist, newK, lmx, lmy = lens
+            runs.append(('undistort', lambda: ops.undistort(d_src, Kc, dist, newK, iname, bname, cval),
+                         lambda f: oracle.remap(src[f], lmx, lmy, INTERPS[iname], BORDERS[bname], cval), isf))
+            if dt in (np.float32, np.uint16) and iname != 'nearest' and K < min(h, w):
+                mid_l = lambda f: oracle.remap(src[f], lmx, lmy, INTERPS[iname], BORDERS[bname], cval, out_dtype=np.float32)  # noqa: E731
+                runs.append(('undistort + KxK', lambda: ops.undistort_conv2d(d_src, Kc, dist, newK, kern, iname, bname, cval, cmode),
+                             lambda f: oracle.conv2d(mid_l(f), kern, cmode), True))
+                if K <= 9:
+                    runs.append(('undistort + K+K', lambda: ops.undistort_sepconv2d(d_src, Kc, dist, newK, g, g[::-1].copy(), iname,
+                                                                                     bname, cval, cmode),
+                                 lambda f: oracle.sepconv2d(mid_l(f), g, g[::-1].copy(), cmode), True))
         for name, fn, ref, is_float in runs:
             try:
                 got = fn().get()
