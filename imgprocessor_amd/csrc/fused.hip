@@ -52,9 +52,26 @@ static bool rank1_chain(ipa_ctx* ctx, const double* kernel, int kh, int kw, int 
 // for the rest (bicubic, analytic coordinates, uint16 frames) the sampling source plus 9 / 11
 // running rows exceed the VGPR budget that pays: the chain runs as two launches through the
 // context workspace: remap kernel -> 9x9 / 11x11 filter.
-static int big_kernel_tmp(ipa_ctx* ctx, int kh, int kw, int dst_dtype, int dh, int dw, int n_frames,
-                          void** tmp) {
-  if (kh != kw || !(kh == 9 || kh == 11)) return 1;  // not the two-launch case
+// Round 6: so does every combination the standalone entry points accept and no fused kernel is
+// built for - Lanczos4 / nearest taps, uint8 frames, uint16 frames with a homography or bicubic
+// taps, rectangular or larger kernels (they returned IPA_ERR_UNSUPPORTED before): a caller of the
+// chain gets what remap + filter give, in whatever number of launches.
+static bool dense_chain_built(int src_dtype, int coord_kind, int interp, int kh, int kw) {
+  const int base = interp & 0xff;
+  if (kh != kw || !(kh == 3 || kh == 5 || kh == 7)) return false;
+  if (src_dtype == IPA_F32)
+    return base == IPA_INTER_LINEAR || base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS;
+  if (src_dtype == IPA_U16) return base == IPA_INTER_LINEAR && coord_kind != 2;
+  return false;
+}
+static int big_kernel_tmp(ipa_ctx* ctx, int src_dtype, int coord_kind, int interp, int kh, int kw, int dst_dtype,
+                          int dh, int dw, int n_frames, void** tmp) {
+  const bool big = kh == kw && (kh == 9 || kh == 11);
+  if (!big) {
+    if (dense_chain_built(src_dtype, coord_kind, interp, kh, kw)) return 1;   // one kernel
+    // (anything the two launches would reject themselves goes on to the fused path's own checks)
+    if (dst_dtype != IPA_F32 || dh <= 0 || dw <= 0 || n_frames < 1 || kh < 1 || kw < 1) return 1;
+  }
   IPA_REQUIRE(ctx, dst_dtype == IPA_F32, "fused remap+filter writes float32");
   int rc = ipa_ws_reserve(ctx, (size_t)n_frames * dh * dw * 4);
   if (rc) return rc;
@@ -387,7 +404,7 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
     }
   }
   void* tmp = nullptr;
-  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  int big = big_kernel_tmp(ctx, src_dtype, 0, interp, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;
   if (big == 0) {
     int rc = ipa_remap_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, tmp,
@@ -438,7 +455,7 @@ int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                                 conv_border_y);
   }
   void* tmp = nullptr;
-  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  int big = big_kernel_tmp(ctx, src_dtype, 1, interp, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;
   if (big == 0) {
     int rc = ipa_undistort_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, tmp,
@@ -480,7 +497,7 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
     }
   }
   void* tmp = nullptr;
-  int big = big_kernel_tmp(ctx, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
+  int big = big_kernel_tmp(ctx, src_dtype, 2, interp, kh, kw, dst_dtype, dh, dw, n_frames, &tmp);
   if (big < 0) return big;
   if (big != 0 && kernel && dh > 0 && dw > 0 &&
       rotated_warp_in_two_launches(ctx, M, src_dtype, dst_dtype, interp, dh, dw, n_frames)) {

@@ -94,8 +94,7 @@ def test_chains(ia, oracle, n, K, dtype):
     scale = float(src.max())
     for what, k in (('dense', dense), ('outer product', np.outer(g, g))):
         got_m = ops.remap_conv2d(d, dmx, dmy, k, 'linear', 'constant', cval).get()
-        # (uint16 frames + homography + dense filter is not a built chain: IPA_ERR_UNSUPPORTED by the C ABI's contract)
-        got_w = ops.warp_perspective_conv2d(d, M, (h, w), k, 'linear', 'constant', cval).get() if dtype == np.float32 else None
+        got_w = ops.warp_perspective_conv2d(d, M, (h, w), k, 'linear', 'constant', cval).get()
         for f in range(n):
             wm = oracle.conv2d(oracle.remap(src[f], mx, my, oracle.LINEAR, oracle.CONSTANT, cval, out_dtype=np.float32), k)
             assert_close(got_m[f], wm, 1e-5, 1e-5 * scale, 'map + %s %dx%d, frame %d of %d' % (what, K, K, f, n))
