@@ -63,7 +63,7 @@ struct ipa_tuning {
   int rank1_sep = 3;      // dense K x K kernels that are an exact outer product ky (x) kx (how the reference obtains its
                           // Gaussians: scipy.ndimage.gaussian_filter, filters/fastFilter.py:42) run on the separable K + K
                           // loops wherever those cover the call: bit 0 the remap -> filter chains, bit 1 the plain filter
-  int sep_u16 = 1;        // map-based bilinear remap -> separable 3 / 5 / 7 / 9-tap filter on uint16 frames in ONE kernel
+  int sep_u16 = 1;        // bilinear remap (maps, homographies) -> separable 3 / 5 / 7 / 9-tap filter on uint16 frames in ONE kernel
                           // (float32 frames always were; 0: two launches through the workspace, as in rounds 1 - 5)
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates

@@ -42,7 +42,7 @@ static bool rank1_chain(ipa_ctx* ctx, const double* kernel, int kh, int kw, int 
                         int interp, double* ky, double* kx, bool maps = false) {
   if (!(ctx->tune.rank1_sep & 1) || !kernel || kh != kw) return false;
   if (!(kh == 3 || kh == 5 || kh == 7 || kh == 9)) return false;
-  // (uint16 frames: where the separable chain is one kernel for them - with maps, knob sep_u16)
+  // (uint16 frames: where the separable chain is one kernel for them - maps, homographies; knob sep_u16)
   const bool src_ok = src_dtype == IPA_F32 || (src_dtype == IPA_U16 && maps && ctx->tune.sep_u16 != 0);
   if (!src_ok || dst_dtype != IPA_F32 || (interp & 0xff) != IPA_INTER_LINEAR) return false;
   return ipa_rank1_factor(kernel, kh, kw, ky, kx);
@@ -165,9 +165,9 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   const int base = interp & 0xff;
   // bicubic: built and correct, but 16 taps per sample on the K-1 extra halo rows of every
   // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
-  // (uint16 frames: with maps - f.coord_kind is set by the caller before it comes here)
+  // (uint16 frames: with maps or a homography - f.coord_kind is set by the caller before it comes here)
   const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9) &&
-                          (src_dtype == IPA_F32 || (src_dtype == IPA_U16 && f.coord_kind == 0 && ctx->tune.sep_u16 != 0)) &&
+                          (src_dtype == IPA_F32 || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
                           base == IPA_INTER_LINEAR && !prefer_two;
   if (!one_kernel) {
     IPA_REQUIRE(ctx, dh > 0 && dw > 0 && n_frames >= 1, "empty image");
@@ -488,7 +488,7 @@ int ipa_warp_perspective_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dty
   IPA_REQUIRE(ctx, M, "null matrix");
   {
     double ky[9], kx[9];
-    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx)) {
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx, true)) {
       ctx->rank1_routed++;
       return ipa_warp_perspective_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, ky, kh, kx, kw, d_dst,
                                                 dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,

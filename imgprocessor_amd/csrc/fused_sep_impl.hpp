@@ -4,7 +4,7 @@
 //
 // wave_sep_kernel with a sampling row source: the remapped image never exists in HBM
 // (8 B/px analytic, 16 B/px map-based instead of 16 / 24 for two launches).  Built for
-// float32 -> float32 (and uint16 -> float32 with maps), K = 3, 5, 7, 9 taps on both axes; fused.hip routes bilinear here and
+// float32 -> float32 (and uint16 -> float32 with maps or a homography), K = 3, 5, 7, 9 taps on both axes; fused.hip routes bilinear here and
 // every other combination (bicubic included: measured slower fused) through two launches.
 #pragma once
 
@@ -53,9 +53,10 @@ static void fused_sep_one(ipa_ctx* ctx, const FusedCall& f, const Coord& c, cons
 
 template <typename Coord, int K>
 static void fused_sep_interp(ipa_ctx* ctx, const FusedCall& f, const Coord& c, const FusedSep& q) {
-  // uint16 frames (camera frames as toFloatArray ingests them): map-based only - fused.hip sends the other
-  // coordinate sources through two launches (round 6: the chain was two launches for every uint16 batch)
-  if constexpr (std::is_same<Coord, MapCoord>::value) {
+  // uint16 frames (camera frames as toFloatArray ingests them): maps and homographies - fused.hip sends the
+  // lens model by value through its cached map or two launches (round 6: the chain was two launches for every
+  // uint16 batch)
+  if constexpr (std::is_same<Coord, MapCoord>::value || std::is_same<Coord, HomographyCoord>::value) {
     if (f.src_dt == IPA_U16) {
       fused_sep_one<uint16_t, kLinear, Coord, K>(ctx, f, c, q);
       return;

@@ -91,7 +91,7 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   the remap -> filter chains (float32 frames, bilinear taps, 3 / 5 / 7 / 9 taps), bit 1 the plain 9 x 9
  *   filter; default 3; the reference obtains its Gaussians separably: scipy.ndimage.gaussian_filter,
  *   filters/fastFilter.py:42).
- *   "sep_u16" (uint16 frames, map-based bilinear remap -> separable 3 / 5 / 7 / 9-tap filter in one kernel: default 1;
+ *   "sep_u16" (uint16 frames, bilinear remap by maps or a homography -> separable 3 / 5 / 7 / 9-tap filter in one kernel: default 1;
  *   0 = two launches through the workspace).
  *   "tail_rows" (chunked batches on the shared-record loop end every XCD's share of the launch on short strips -
  *   the workgroups that run while the launch drains: -1 = the measured rule by taps and launch size, 0 = uniform

@@ -117,6 +117,22 @@ def test_uint16_frames_take_the_one_kernel_separable_chain(ia, oracle, n, K):
         want = oracle.sepconv2d(mid, ky, kx)
         for name, a in (('one kernel', got), ('routed dense call', dense_call), ('two launches', two), ('dense loop', dense)):
             assert_close(a[f], want, 1e-5, 1e-5 * 4095, '%s, %d+%d taps, frame %d of %d' % (name, K, K, f, n))
+    # a homography as the coordinate source: the same kernel family (C3's chain on camera frames)
+    Mh = np.array([[1.01, 0.004, -3.0], [-0.003, 0.99, 2.0], [1e-5, -2e-5, 1.0]])
+    got_h = ops.warp_perspective_sepconv2d(d, Mh, (h, w), ky, kx, 'linear', 'constant', 100.0).get()
+    before = routed(ctx)
+    got_hd = ops.warp_perspective_conv2d(d, Mh, (h, w), np.outer(ky, kx), 'linear', 'constant', 100.0).get()
+    assert routed(ctx) == before + 1
+    old = ctx.set_tuning(sep_u16=0)
+    try:
+        two_h = ops.warp_perspective_sepconv2d(d, Mh, (h, w), ky, kx, 'linear', 'constant', 100.0).get()
+    finally:
+        ctx.set_tuning(**old)
+    for f in (0, n - 1):
+        mid = oracle.warp_perspective(src[f], Mh, (h, w), oracle.LINEAR, oracle.CONSTANT, 100.0, out_dtype=np.float32)
+        want = oracle.sepconv2d(mid, ky, kx)
+        for name, a in (('one kernel', got_h), ('routed dense call', got_hd), ('two launches', two_h)):
+            assert_close(a[f], want, 1e-5, 1e-5 * 4095, 'homography, %s, %d+%d taps, frame %d of %d' % (name, K, K, f, n))
     # the lens model by value: its cached map takes the same route
     before = routed(ctx)
     got_u = ops.undistort_conv2d(d, Kc, dist, Kc, np.outer(ky, kx)).get()

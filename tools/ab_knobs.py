@@ -58,11 +58,11 @@ def main():
     k7 = rng.random((7, 7))
     k7 /= k7.sum()
     u16 = None
-    if {'c4', 'c4g7', 'c4g5', 'c4sep9', 'c4sep5'} & set(what):
+    if {'c4', 'c4g7', 'c4g5', 'c4sep9', 'c4sep5', 'c3u16'} & set(what):
         u16 = ctx.to_device(np.round(np.concatenate([one] * (batch // 16)) * 4095).astype(np.uint16)
                             if batch >= 16 else np.round(one[:batch] * 4095).astype(np.uint16))
     Hm = None
-    if {'c3', 'warp5', 'lz4', 'cubic', 'warplin'} & set(what):
+    if {'c3', 'c3u16', 'warp5', 'lz4', 'cubic', 'warplin'} & set(what):
         from imgprocessor_amd.utils import getPerspectiveTransform
         quad = np.array([(192, 108), (3648, 54), (3744, 2106), (96, 2052)], float)
         rect = np.array([(0, 0), (w - 1, 0), (w - 1, h - 1), (0, h - 1)], float)
@@ -94,6 +94,7 @@ def main():
         # uint16 frames + Gaussian outer products / separable taps (knob sep_u16: one kernel against two launches / dense)
         'c4g7': lambda: ops.remap_conv2d(u16, dmx, dmy, gk[7], out=dst),
         'c4g5': lambda: ops.remap_conv2d(u16, dmx, dmy, gk[5], out=dst),
+        'c3u16': lambda: ops.warp_perspective_sepconv2d(u16, Hm, (h, w), g9, g9, 'linear', out=dst),
         'c4sep9': lambda: ops.remap_sepconv2d(u16, dmx, dmy, g9, g9, out=dst),
         'c4sep5': lambda: ops.remap_sepconv2d(u16, dmx, dmy, gk1[5], gk1[5], out=dst),
         'fused7': lambda: ops.remap_conv2d(src, dmx, dmy, k7, out=dst),
