@@ -378,6 +378,13 @@ def other_configs(ctx, ia, ops, budget_launches=60):
           'streams 3.2 GB while its SIMDs issue vector instructions ~80 % of the launch (98 packed fmas for the 49 '
           'taps x 4 pixels + ~120 for sampling, unpacking and coefficient restores per row step): priced against '
           'HBM, bound by vector issue', issue='c4')
+    # ... with a 7x7 GAUSSIAN in place of the random kernel (how the reference obtains its smoothing kernels:
+    # scipy.ndimage.gaussian_filter): an outer product - the library takes its separable 7 + 7 loop, since round 6 for
+    # uint16 frames too (knob sep_u16)
+    g7 = np.exp(-0.5 * np.arange(-3, 4) ** 2)
+    g7 /= g7.sum()
+    ms = timed_settled(ctx, lambda: ops.remap_conv2d(u16, dmx, dmy, np.outer(g7, g7), out=dst), budget_launches // 2, 3)
+    entry('... with a 7x7 Gaussian (outer product: the separable 7 + 7 loop)', B, h, w, ms, (6 * B + 8) * h * w, 1)
     del u16, dst
     # the same chain host -> host through page-locked buffers (PCIe-inclusive; never `value`)
     try:
