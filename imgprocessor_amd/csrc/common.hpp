@@ -63,6 +63,8 @@ struct ipa_tuning {
   int rank1_sep = 3;      // dense K x K kernels that are an exact outer product ky (x) kx (how the reference obtains its
                           // Gaussians: scipy.ndimage.gaussian_filter, filters/fastFilter.py:42) run on the separable K + K
                           // loops wherever those cover the call: bit 0 the remap -> filter chains, bit 1 the plain filter
+  int strip_remap = 1;    // bilinear remaps of uint16 frames into float32 on the marching strips of the chains, no filter
+                          // (remap.hip::strip_remap_takes; 0: the gather kernels of rounds 1 - 5)
   int sep_u16 = 1;        // bilinear remap (maps, homographies) -> separable 3 / 5 / 7 / 9-tap filter on uint16 frames in ONE kernel
                           // (float32 frames always were; 0: two launches through the workspace, as in rounds 1 - 5)
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
@@ -108,6 +110,7 @@ struct ipa_ctx {
     unsigned long used = 0;
   } tile_warp_plans[kTileWarpPlans];
   unsigned long tile_warp_clock = 0;
+  unsigned long strip_remaps = 0;     // standalone uint16 -> float32 remaps the strip kernel took (remap.hip; read like rank1_routed)
   unsigned long rank1_routed = 0;     // dense calls sent to the separable loops so far (read through ipa_ctx_get_tuning)
   int tail_rows_used = 0;             // height of the short strips of the last such launch (0: uniform strips)
   int group_chunk_used = 0;           // groups per chunk of the last launch on the shared-record loop (0: all together)

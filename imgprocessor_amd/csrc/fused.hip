@@ -6,6 +6,7 @@ using namespace ipa;
 
 void ipa_fused_sep_launch_a(ipa_ctx*, const FusedCall&, const FusedSep&);  // 3, 5 taps
 void ipa_fused_sep_launch_b(ipa_ctx*, const FusedCall&, const FusedSep&);  // 7, 9 taps
+void ipa_fused_sep_launch_c(ipa_ctx*, const FusedCall&, const FusedSep&);  // 1 tap: the remap alone
 
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
@@ -166,7 +167,8 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   // bicubic: built and correct, but 16 taps per sample on the K-1 extra halo rows of every
   // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
   // (uint16 frames: with maps or a homography - f.coord_kind is set by the caller before it comes here)
-  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9) &&
+  // (one tap - the remap alone - is built for uint16 frames: remap.hip::strip_remap_takes)
+  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9 || (nky == 1 && src_dtype == IPA_U16)) &&
                           (src_dtype == IPA_F32 || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
                           base == IPA_INTER_LINEAR && !prefer_two;
   if (!one_kernel) {
@@ -184,7 +186,8 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   if (rc) return rc;
   FusedSep q{ky, kx, nky, 0.0f};
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (nky <= 5) ipa_fused_sep_launch_a(ctx, f, q);
+  if (nky == 1) ipa_fused_sep_launch_c(ctx, f, q);
+  else if (nky <= 5) ipa_fused_sep_launch_a(ctx, f, q);
   else ipa_fused_sep_launch_b(ctx, f, q);
   IPA_HIP(ctx, hipGetLastError());
   return IPA_OK;

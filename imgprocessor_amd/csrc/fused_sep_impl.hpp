@@ -62,7 +62,9 @@ static void fused_sep_interp(ipa_ctx* ctx, const FusedCall& f, const Coord& c, c
       return;
     }
   }
-  fused_sep_one<float, kLinear, Coord, K>(ctx, f, c, q);
+  // K = 1 (the remap alone, fused_sep_c.hip) is built for uint16 frames only: float32 frames have the tile kernel
+  // (level on maps, 15 - 19 % faster under a homography), and fused.hip does not send them here
+  if constexpr (K != 1) fused_sep_one<float, kLinear, Coord, K>(ctx, f, c, q);
 }
 
 template <int K> static void fused_sep_k(ipa_ctx* ctx, const FusedCall& f, const FusedSep& q) {

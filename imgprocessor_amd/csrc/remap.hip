@@ -324,6 +324,44 @@ int ipa_build_undistort_map(ipa_ctx* ctx, const double* K, const double* dist5,
   return IPA_OK;
 }
 
+// Round 6 (knob strip_remap): bilinear remaps of uint16 frames INTO float32 - camera frames as
+// transformations.toFloatArray ingests them (transformations.py:78-87), the element types of BASELINE C4 - run on
+// the marching strips of the fused chains with NO filter (wave_sep_kernel, K = 1: 256-px strips, no halo, both
+// passes the identity; fused_sep_c.hip): the gather kernels these calls took stream 64 x 4K in 1.28 ms, the strips in
+// 0.90 (maps; -30 %), lens model 1.42 -> 0.89, homography 1.16 -> 1.07; identical bits (tools/strip_remap_probe.py).
+// Batches of a multiple of 4 frames (the shared-footprint loop) for maps and homographies that do not turn the
+// picture; the lens model by value at any count (its map is evaluated once and cached).  float32 frames stay where
+// they are: the tile kernel is level with the strips on maps and 15 - 19 % faster on homographies.
+static bool strip_remap_takes(const ipa_ctx* ctx, const void* d_src, const void* d_dst, int src_dtype, int dst_dtype,
+                              int sh, int sw, long src_pitch, int dh, int dw, long dst_pitch, int n_frames,
+                              int interp) {
+  const ipa_tuning& t = ctx->tune;
+  if (!t.strip_remap || !t.sep_u16 || !t.frames_wg || !t.frames_inner || !t.pipe) return false;
+  if (src_dtype != IPA_U16 || dst_dtype != IPA_F32 || !d_src || !d_dst) return false;
+  if ((interp & 0xff) != IPA_INTER_LINEAR || (interp & ~(0xff | IPA_INTER_Q5)) != 0) return false;
+  // (what the chain kernels' 32-bit offsets hold; anything else stays with the gather kernels and their checks)
+  if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || src_pitch < sw || dst_pitch < dw || src_pitch >= (1l << 23)) return false;
+  if (((size_t)(sh - 1) * src_pitch + sw) * 2 >= (1ull << 31) || n_frames < 1 || n_frames > 65535) return false;
+  return true;
+}
+// how far the source row moves along one output row (px per px), at 9 points of the picture
+static double warp_row_drift(const double* m, int dh, int dw) {
+  double drift = 0;
+  for (int py = 0; py < 3; py++)
+    for (int px = 0; px < 3; px++) {
+      const double u = (dw - 2) * 0.5 * px, v = (dh - 2) * 0.5 * py;
+      double y[2];
+      for (int i = 0; i < 2; i++) {
+        const double W = m[6] * (u + i) + m[7] * v + m[8];
+        y[i] = (m[3] * (u + i) + m[4] * v + m[5]) * (W != 0.0 ? 1.0 / W : 0.0);
+      }
+      if (!(fabs(y[1] - y[0]) < 1e6)) return 1e6;
+      drift = fabs(y[1] - y[0]) > drift ? fabs(y[1] - y[0]) : drift;
+    }
+  return drift;
+}
+static const double kOneTap = 1.0;
+
 int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw, long src_pitch,
                   const float* d_mapx, const float* d_mapy, long map_pitch, void* d_dst,
                   int dst_dtype, int dh, int dw, long dst_pitch, int n_frames,
@@ -331,6 +369,14 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
                   double border_value) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
+                                             dst_pitch, n_frames, interp)) {
+    ctx->strip_remaps++;
+    return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, &kOneTap, 1,
+                                   &kOneTap, 1, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                   dst_frame_stride, interp, border_mode, border_value, IPA_BORDER_REFLECT,
+                                   IPA_BORDER_REFLECT);
+  }
   MapCoord c{d_mapx, d_mapy, map_pitch};
   int map_vec = aligned_rows(d_mapx, map_pitch, 0, 1, 4, IPA_VEC_ALIGN) &&
             aligned_rows(d_mapy, map_pitch, 0, 1, 4, IPA_VEC_ALIGN);
@@ -348,6 +394,14 @@ int ipa_undistort_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, in
   UndistortCoord c;
   int rc = make_undistort_coord(ctx, K, dist5, newK, &c);
   if (rc) return rc;
+  if (ctx->tune.lens_cache && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
+                                                dst_pitch, n_frames, interp)) {   // (see ipa_remap_dev)
+    ctx->strip_remaps++;
+    return ipa_undistort_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, &kOneTap, 1, &kOneTap,
+                                       1, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                       dst_frame_stride, interp, border_mode, border_value, IPA_BORDER_REFLECT,
+                                       IPA_BORDER_REFLECT);
+  }
   RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
               n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
   return ipa_remap_launch_undistort(ctx, a, c);
@@ -360,6 +414,15 @@ int ipa_warp_perspective_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                              double border_value) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, M, "null matrix");
+  if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
+                                             dst_pitch, n_frames, interp) &&
+      warp_row_drift(M, dh, dw) < 0.2) {   // (see ipa_remap_dev; pictures that turn stay with the gather kernels)
+    ctx->strip_remaps++;
+    return ipa_warp_perspective_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, &kOneTap, 1, &kOneTap, 1,
+                                              d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
+                                              dst_frame_stride, interp, border_mode, border_value,
+                                              IPA_BORDER_REFLECT, IPA_BORDER_REFLECT);
+  }
   HomographyCoord c;
   for (int i = 0; i < 9; i++) c.m[i] = M[i];
   RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,

@@ -81,6 +81,7 @@ const TuneName kTuneNames[] = {
     {"rank1_sep", "IPA_RANK1_SEP", &ipa_tuning::rank1_sep},
     {"tail_rows", "IPA_TAIL_ROWS", &ipa_tuning::tail_rows},
     {"sep_u16", "IPA_SEP_U16", &ipa_tuning::sep_u16},
+    {"strip_remap", "IPA_STRIP_REMAP", &ipa_tuning::strip_remap},
 };
 }  // namespace
 
@@ -125,6 +126,10 @@ int ipa_ctx_get_tuning(ipa_ctx* ctx, const char* name, int* value) {
 #endif
   if (strcmp(name, "rank1_routed") == 0) {
     *value = (int)(ctx->rank1_routed & 0x7fffffff);
+    return IPA_OK;
+  }
+  if (strcmp(name, "strip_remaps") == 0) {
+    *value = (int)(ctx->strip_remaps & 0x7fffffff);
     return IPA_OK;
   }
   if (strcmp(name, "tail_rows_used") == 0) {

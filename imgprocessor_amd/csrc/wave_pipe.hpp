@@ -600,7 +600,9 @@ __device__ __forceinline__ void wave_run_strip_pipe(const WaveParams& p,
           if (!((interior >> k) & 1u) && (s.border != IPA_BORDER_CONSTANT || (interior & kBorderSlow))) {
             const int col = k < 4 ? c.xs + (int)lane + 64 * k : c.xs - G::H + (int)hcol;
             float sx, sy;
-            src.coord.get(col, yb + t, sx, sy);
+            // (t < T: the loop runs a step or two past the strip - their records are row T - 1's, and the map row
+            //  past a strip that ends with the frame does not exist: found as a page fault in round 6)
+            src.coord.get(col, yb + (t < T ? t : T - 1), sx, sy);
             xp[k < 4 ? kRowPad + 64u * k + lane : kRowPad - G::H + hcol] =
                 sample<float, kLinear, float>(s, sx, sy, src.cval);
           }
@@ -1045,7 +1047,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
           C sx, sy;
           const int col = c.xs - G::H + (int)halo_pos<G::H>(hq);
           if constexpr (EDGE) src.coord.get(uhq < 0 ? 0 : uhq, rowt < 0 ? 0 : rowt, sx, sy);
-          else src.coord.get(col, yb + t, sx, sy);
+          else src.coord.get(col, yb + (t < T ? t : T - 1), sx, sy);   // (see below)
           o = sample<ST, kLinear, C>(s, sx, sy, src.cval);
         }
       }
@@ -1089,7 +1091,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
             if (!(rowt < 0 || uqk < 0)) xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           } else {
-            src.coord.get(col, yb + t, sx, sy);
+            // (t < T: the last block is filled up to a whole number of steps with the records of row T - 1; the
+            //  coordinate row itself must be clamped too - a table source has no row past a strip that ends with
+            //  the frame: a page fault on a map that ended with its allocation, round 6)
+            src.coord.get(col, yb + (t < T ? t : T - 1), sx, sy);
             xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           }
         }

@@ -31,6 +31,12 @@ template <int K> struct sep_geom {
   static constexpr int HL = (K / 2 + 3) / 4 > IPA_SEP_MIN_HL ? (K / 2 + 3) / 4 : IPA_SEP_MIN_HL;
   static constexpr int OW = 256 - 8 * HL;
 };
+// K = 1: no filter at all - the remap alone on the marching strips (round 6: "strip remap").  No halo lanes, no
+// halo rows: 256-px strips whose rows are whole 1024-byte line runs; both passes are the identity (no multiply).
+template <> struct sep_geom<1> {
+  static constexpr int HL = 0;
+  static constexpr int OW = 256;
+};
 
 template <int K> struct SepTaps {
   float ky[K], kx[K];
@@ -58,6 +64,11 @@ template <int K, int I> __device__ __forceinline__ v2f sep_tap_pair(const float 
 // y pass: the arriving row (c0, c1 = pixel pairs) feeds the K running intermediate rows; acc[K - 1] completes
 template <int K>
 __device__ __forceinline__ void sep_y_pass(const SepTaps<K>& w, v2f (&acc)[K][2], v2f c0, v2f c1) {
+  if constexpr (K == 1) {   // the remap alone
+    acc[0][0] = c0;
+    acc[0][1] = c1;
+    return;
+  }
   static_for<0, K>([&](auto Ii) {
     constexpr int i = K - 1 - decltype(Ii)::value;
     const v2f t = sep_tap_pair<K, i>(w.ky);
@@ -74,7 +85,8 @@ __device__ __forceinline__ void sep_y_pass(const SepTaps<K>& w, v2f (&acc)[K][2]
 template <int K>
 __device__ __forceinline__ v4f sep_x_pass(const SepTaps<K>& w, const float (&mid)[4]) {
   constexpr int H = K / 2;
-  static_assert(H >= 1 && H <= 4, "3 .. 9 taps");
+  if constexpr (K == 1) return v4f{mid[0], mid[1], mid[2], mid[3]};   // the remap alone
+  static_assert(K == 1 || (H >= 1 && H <= 4), "3 .. 9 taps");
   // win[m] = intermediate pixel 4 L - H + m, m = 0 .. 3 + 2 H, held as the pairs (2 n, 2 n + 1) when H is even and
   // (2 n - 1, 2 n) when it is odd, so that the lane's own four pixels are its own two register pairs either way
   float win[4 + 2 * H];

@@ -1,0 +1,120 @@
+"""GPU: standalone bilinear remaps of uint16 frames INTO float32 (camera frames as transformations.toFloatArray ingests them,
+transformations.py:78-87; LensDistortion.correct / PerspectiveCorrection.correct on them, camera/LensDistortion.py:316-330,
+camera/PerspectiveCorrection.py:374-406) run on the marching strips of the fused chains with no filter (round 6, knob
+strip_remap; csrc/remap.hip::strip_remap_takes, wave_sep_kernel with K = 1): the bits of the gather kernels they replace
+(knob off), the oracle's values, the route taken where it is claimed (read-only counter "strip_remaps") and nowhere else."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from .conftest import assert_close
+from .gpu_helpers import frames, radial_maps, same_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ia():
+    import imgprocessor_amd
+    imgprocessor_amd.default_context(0)
+    return imgprocessor_amd
+
+
+def taken(ctx):
+    return ctx.get_tuning('strip_remaps')
+
+
+M_UP = np.array([[1.01, 0.004, -3.0], [-0.003, 0.99, 2.0], [1e-5, -2e-5, 1.0]])
+
+
+def rot(deg, h, w):
+    a = np.deg2rad(deg)
+    cx, cy = (w - 1) / 2.0, (h - 1) / 2.0
+    return np.array([[np.cos(a), -np.sin(a), cx - np.cos(a) * cx + np.sin(a) * cy],
+                     [np.sin(a), np.cos(a), cy - np.sin(a) * cx - np.cos(a) * cy], [0, 0, 1.0]])
+
+
+@pytest.mark.parametrize('shape', [(150, 610), (97, 333), (301, 1030)])
+@pytest.mark.parametrize('n', [4, 8, 3])
+@pytest.mark.parametrize('interp', ['linear', 'linear_cv_q5'])
+def test_strip_remap_is_the_gather_remap(ia, oracle, shape, n, interp):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w, np.uint16)
+    mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
+    mx = mx - np.float32(15.0)       # a rim outside the source
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    oi = oracle.LINEAR | (oracle.Q5 if interp.endswith('q5') else 0)
+    for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
+        calls = {
+            'maps': (lambda: ops.remap(d, dmx, dmy, interp, border, 100.0, out_dtype=np.float32), n % 4 == 0),
+            'lens model': (lambda: ops.undistort(d, Kc, dist, Kc, interp, border, 100.0, out_dtype=np.float32), True),
+            'homography': (lambda: ops.warp_perspective(d, M_UP, (h, w), interp, border, 100.0, out_dtype=np.float32), n % 4 == 0),
+        }
+        for name, (fn, expect) in calls.items():
+            before = taken(ctx)
+            got = fn().get()
+            assert taken(ctx) == before + (1 if expect else 0), (name, n, 'route')
+            old = ctx.set_tuning(strip_remap=0)
+            try:
+                before = taken(ctx)
+                ref = fn().get()
+                assert taken(ctx) == before
+            finally:
+                ctx.set_tuning(**old)
+            assert got.dtype == np.float32
+            same_bits(got, ref, '%s, %s, %s, %d frames of %d x %d' % (name, interp, border, n, h, w))
+        if border in ('constant', 'reflect'):
+            f = n - 1
+            bo = {'constant': oracle.CONSTANT, 'reflect': oracle.REFLECT}[border]
+            want = oracle.remap(src[f], mx, my, oi, bo, 100.0, out_dtype=np.float32)
+            got = ops.remap(d, dmx, dmy, interp, border, 100.0, out_dtype=np.float32).get()
+            assert_close(got[f], want, 1e-5, 1e-5 * 4095, 'maps vs oracle, %s' % border)
+
+
+def test_what_stays_with_the_other_kernels(ia):
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 120, 520
+    u16 = ctx.to_device(frames(4, h, w, np.uint16))
+    f32 = ctx.to_device(frames(4, h, w))
+    mx, my, _, _ = radial_maps(h, w)
+    dmx, dmy = ctx.to_device(mx), ctx.to_device(my)
+    before = taken(ctx)
+    ops.remap(f32, dmx, dmy)                                           # float32 frames: the tile kernel
+    ops.remap(u16, dmx, dmy)                                           # uint16 -> uint16
+    ops.remap(u16, dmx, dmy, 'cubic', out_dtype=np.float32)            # bicubic taps
+    ops.remap(u16, dmx, dmy, 'nearest', out_dtype=np.float32)
+    ops.warp_perspective(u16, rot(12.0, h, w), (h, w), 'linear', out_dtype=np.float32)   # a picture that turns
+    assert taken(ctx) == before
+    ops.warp_perspective(u16, rot(0.2, h, w), (h, w), 'linear', out_dtype=np.float32)
+    assert taken(ctx) == before + 1
+
+
+def test_strip_remap_with_pitches(ia):
+    """the C ABI with pitches and frame strides larger than the frames (regions of larger buffers)"""
+    from imgprocessor_amd import ops
+    from imgprocessor_amd.device import dtype_id
+    ctx = ia.default_context(0)
+    n, h, w = 4, 130, 500
+    src = frames(n, h, w, np.uint16)
+    mx, my, _, _ = radial_maps(h, w)
+    want = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), out_dtype=np.float32).get()
+    sp, dp, mp = w + 26, w + 8, w + 12
+    sbig = np.full((n, h + 5, sp), 7, np.uint16)
+    sbig[:, :h, :w] = src
+    mbx, mby = np.full((h, mp), -1e9, np.float32), np.full((h, mp), -1e9, np.float32)
+    mbx[:, :w], mby[:, :w] = mx, my
+    dbig = ctx.to_device(np.full((n, h + 3, dp), -5.0, np.float32))
+    dsb, dmbx, dmby = ctx.to_device(sbig), ctx.to_device(mbx), ctx.to_device(mby)
+    before = taken(ctx)
+    ctx._check(ctx._lib.ipa_remap_dev(
+        ctx.handle, dsb.ptr, dtype_id(np.uint16), h, w, sp, dmbx.ptr, dmby.ptr, mp, dbig.ptr,
+        dtype_id(np.float32), h, w, dp, n, (h + 5) * sp, (h + 3) * dp, ops.interp_id('linear'),
+        ops.border_id('constant'), C.c_double(0.0)), 'remap')
+    assert taken(ctx) == before + 1
+    got = dbig.get()
+    same_bits(np.ascontiguousarray(got[:, :h, :w]), want, 'pitched strip remap')
+    assert (got[:, h:, :] == -5.0).all() and (got[:, :, w:] == -5.0).all(), 'wrote outside'

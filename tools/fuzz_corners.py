@@ -95,6 +95,13 @@ def main():
                  lambda f: oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval), isf),
                 ('warp', lambda: ops.warp_perspective(d_src, M, (dh, dw), iname, bname, cval),
                  lambda f: oracle.warp_perspective(src[f], M, (dh, dw), INTERPS[iname], BORDERS[bname], cval), isf)]
+        if dt != np.float32:
+            # integer frames INTO float32 (transformations.toFloatArray's ingest; uint16 + bilinear: the strip remap, round 6)
+            runs += [('remap -> f32', lambda: ops.remap(d_src, dmx, dmy, iname, bname, cval, out_dtype=np.float32),
+                      lambda f: oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval, out_dtype=np.float32), True),
+                     ('warp -> f32', lambda: ops.warp_perspective(d_src, M, (dh, dw), iname, bname, cval, out_dtype=np.float32),
+                      lambda f: oracle.warp_perspective(src[f], M, (dh, dw), INTERPS[iname], BORDERS[bname], cval,
+                                                        out_dtype=np.float32), True)]
         if dt in (np.float32, np.uint16) and iname != 'nearest' and K < min(dh, dw):
             mid_m = lambda f: oracle.remap(src[f], mx, my, INTERPS[iname], BORDERS[bname], cval, out_dtype=np.float32)  # noqa: E731
             mid_w = lambda f: oracle.warp_perspective(src[f], M, (dh, dw), INTERPS[iname], BORDERS[bname], cval,  # noqa: E731
@@ -115,6 +122,9 @@ def main():
             Kc, dist, newK, lmx, lmy = lens
             runs.append(('undistort', lambda: ops.undistort(d_src, Kc, dist, newK, iname, bname, cval),
                          lambda f: oracle.remap(src[f], lmx, lmy, INTERPS[iname], BORDERS[bname], cval), isf))
+            if dt != np.float32:
+                runs.append(('undistort -> f32', lambda: ops.undistort(d_src, Kc, dist, newK, iname, bname, cval, out_dtype=np.float32),
+                             lambda f: oracle.remap(src[f], lmx, lmy, INTERPS[iname], BORDERS[bname], cval, out_dtype=np.float32), True))
             if dt in (np.float32, np.uint16) and iname != 'nearest' and K < min(h, w):
                 mid_l = lambda f: oracle.remap(src[f], lmx, lmy, INTERPS[iname], BORDERS[bname], cval, out_dtype=np.float32)  # noqa: E731
                 runs.append(('undistort + KxK', lambda: ops.undistort_conv2d(d_src, Kc, dist, newK, kern, iname, bname, cval, cmode),

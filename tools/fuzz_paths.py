@@ -90,7 +90,7 @@ def main():
                                                             cval, cmode))
             if (dh, dw) == (h, w) else None,
         }
-        plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0, stored_coords=0, pipe=1, tile_warp=0)
+        plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0, stored_coords=0, pipe=1, tile_warp=0, strip_remap=0)
         alts = [dict(ring_remap=2), dict(lens_cache=1), dict(frames_wg=1),
                 dict(ring_remap=2, lens_cache=1, frames_wg=1),
                 dict(frames_wg=1, stored_coords=1),     # homography coordinates stored once per batch
