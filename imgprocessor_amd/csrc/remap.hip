@@ -402,6 +402,16 @@ int ipa_undistort_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, in
                                        dst_frame_stride, interp, border_mode, border_value, IPA_BORDER_REFLECT,
                                        IPA_BORDER_REFLECT);
   }
+  // integer frames, batches: the model's float32 coordinates are the same for every frame - through the cached
+  // map (bit for bit what the per-pixel evaluation gives; the chains have used it since round 2) instead of
+  // evaluating the model per pixel and frame: 64 x 4K uint16 -> uint16 1.77 -> 1.31 ms (float32 frames: level, stay)
+  if (ctx->tune.lens_cache && n_frames >= 4 && (src_dtype == IPA_U8 || src_dtype == IPA_U16) && dh > 0 && dw > 0) {
+    float *mx = nullptr, *my = nullptr;
+    rc = ipa_lens_map_cached(ctx, K, dist5, newK, dh, dw, &mx, &my);
+    if (rc) return rc;
+    return ipa_remap_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, mx, my, dw, d_dst, dst_dtype, dh, dw, dst_pitch,
+                         n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value);
+  }
   RemapCall a{d_src, src_dtype, sh, sw, src_pitch, d_dst, dst_dtype, dh, dw, dst_pitch,
               n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value};
   return ipa_remap_launch_undistort(ctx, a, c);

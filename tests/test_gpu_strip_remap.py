@@ -118,3 +118,36 @@ def test_strip_remap_with_pitches(ia):
     got = dbig.get()
     same_bits(np.ascontiguousarray(got[:, :h, :w]), want, 'pitched strip remap')
     assert (got[:, h:, :] == -5.0).all() and (got[:, :, w:] == -5.0).all(), 'wrote outside'
+
+
+@pytest.mark.parametrize('dtype', [np.uint8, np.uint16])
+@pytest.mark.parametrize('interp', ['linear', 'linear_cv_q5', 'cubic_cv_q5', 'lanczos4', 'nearest'])
+def test_integer_batches_undistort_through_the_cached_map(ia, oracle, dtype, interp):
+    """round 6: the lens model BY VALUE on batches of integer frames goes through the context's cached map (the model's
+    float32 coordinates are the same for every frame; bit for bit what the per-pixel evaluation gives) instead of being
+    evaluated per pixel and frame: 64 x 4K uint16 1.77 -> 1.31 ms.  Same bits as the analytic kernels (knob lens_cache = 0)."""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 141, 530, 5
+    src = frames(n, h, w, dtype)
+    _, _, Kc, dist = radial_maps(h, w)
+    newK = Kc.copy()
+    newK[0, 0] *= 0.93
+    newK[1, 1] *= 0.93          # a rim outside the source
+    d = ctx.to_device(src)
+    for odt in (None, np.float32):
+        got = ops.undistort(d, Kc, dist, newK, interp, 'constant', 9.0, out_dtype=odt).get()
+        old = ctx.set_tuning(lens_cache=0, strip_remap=0)
+        try:
+            ref = ops.undistort(d, Kc, dist, newK, interp, 'constant', 9.0, out_dtype=odt).get()
+        finally:
+            ctx.set_tuning(**old)
+        if got.dtype == np.float32:
+            same_bits(got, ref, '%s %s -> float32' % (np.dtype(dtype).name, interp))
+        else:
+            assert got.dtype == dtype and np.array_equal(got, ref), (dtype, interp)
+    oi = {'linear': oracle.LINEAR, 'linear_cv_q5': oracle.LINEAR | oracle.Q5, 'cubic_cv_q5': oracle.CUBIC_CV | oracle.Q5,
+          'lanczos4': oracle.LANCZOS4, 'nearest': oracle.NEAREST}[interp]
+    mx, my = oracle.build_undistort_map(Kc, dist, newK, h, w)
+    got = ops.undistort(d, Kc, dist, newK, interp, 'constant', 9.0).get()
+    assert np.array_equal(got[n - 1], oracle.remap(src[n - 1], mx, my, oi, oracle.CONSTANT, 9.0))
