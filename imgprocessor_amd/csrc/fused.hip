@@ -7,6 +7,7 @@ using namespace ipa;
 void ipa_fused_sep_launch_a(ipa_ctx*, const FusedCall&, const FusedSep&);  // 3, 5 taps
 void ipa_fused_sep_launch_b(ipa_ctx*, const FusedCall&, const FusedSep&);  // 7, 9 taps
 void ipa_fused_sep_launch_c(ipa_ctx*, const FusedCall&, const FusedSep&);  // 1 tap: the remap alone
+void ipa_fused_sep_launch_c16(ipa_ctx*, const FusedCall&);                   // ... uint16 into uint16 (cv2's 16U arithmetic)
 
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
@@ -220,6 +221,38 @@ static bool rotated_warp_in_two_launches(const ipa_ctx* ctx, const double* m, in
       drift = fabs(y1 - y0) > drift ? fabs(y1 - y0) : drift;
     }
   return drift >= (ctx->tune.tile_warp > 1 ? 0.0 : 0.2);
+}
+
+// The strip remap of uint16 frames INTO uint16 (remap.hip::ipa_remap_dev): cv2.remap's 16U bilinear at 1/32-px
+// coordinates - what LensDistortion.correct returns for camera frames - on the shared-record loop.  Returns 1 when the
+// call is not one the loop covers on EVERY strip (the caller then takes the gather kernel), 0 when launched.
+int ipa_strip_remap_u16(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
+                        const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
+                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                        double border_value) {
+  const ipa_tuning& t = ctx->tune;
+  if (!t.strip_remap || !t.sep_u16 || !t.frames_wg || !t.frames_inner || !t.pipe) return 1;
+  if (interp != (IPA_INTER_LINEAR | IPA_INTER_Q5) || n_frames < 4 || n_frames % 4 != 0 || n_frames > 65535) return 1;
+  if (!d_src || !d_dst || !d_mapx || !d_mapy || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (dw & 3) != 0) return 1;
+  if (src_pitch < sw || dst_pitch < dw || map_pitch < dw || src_pitch >= (1l << 23)) return 1;
+  if (((size_t)(sh - 1) * src_pitch + sw) * 2 >= (1ull << 31)) return 1;
+  if ((unsigned long)(((dw + 255) / 256) * ((dh + 15) / 16)) * (unsigned long)n_frames >= (1ul << 31)) return 1;
+  FusedCall f;
+  f.coord_kind = 0;
+  f.map = MapCoord{d_mapx, d_mapy, map_pitch};
+  int rc = fused_fill(ctx, f, d_src, IPA_U16, sh, sw, src_pitch, d_dst, IPA_U16, dh, dw, dst_pitch, n_frames,
+                      src_frame_stride, dst_frame_stride, interp, border_mode, border_value, IPA_BORDER_REFLECT,
+                      IPA_BORDER_REFLECT);
+  if (rc) return rc;
+  if (!f.p.vec_out || !f.map_vec) return 1;   // (rows of the result / of the maps that are no whole 16-byte vectors)
+  // the border value as cv2 casts it: saturate_cast<ushort>
+  const double r16 = rint(border_value);
+  f.cval = r16 > 0 ? (r16 < 65535 ? r16 : 65535) : 0;
+  IPA_HIP(ctx, hipSetDevice(ctx->device));
+  ipa_fused_sep_launch_c16(ctx, f);
+  IPA_HIP(ctx, hipGetLastError());
+  ctx->strip_remaps++;
+  return IPA_OK;
 }
 
 extern "C" {

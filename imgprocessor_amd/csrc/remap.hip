@@ -287,6 +287,11 @@ int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, cons
   return IPA_OK;
 }
 
+int ipa_strip_remap_u16(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
+                        const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
+                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
+                        double border_value);   // fused.hip (internal, C++ linkage)
+
 extern "C" {
 
 int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dist5,
@@ -369,6 +374,13 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
                   double border_value) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
+  if (src_dtype == IPA_U16 && dst_dtype == IPA_U16) {
+    // ... and INTO uint16 with cv2's 16U arithmetic (what LensDistortion.correct returns for camera frames): the same
+    // strips, the blend of sampler.hpp::sample_u16_cv (fused.hip::ipa_strip_remap_u16; 1: not a call it covers)
+    int rc = ipa_strip_remap_u16(ctx, d_src, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, d_dst, dh, dw, dst_pitch,
+                                 n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value);
+    if (rc <= 0) return rc;
+  }
   if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
                                              dst_pitch, n_frames, interp)) {
     ctx->strip_remaps++;

@@ -138,6 +138,30 @@ template <bool NT> __device__ __forceinline__ void pipe_store4(const v4f& x, uns
   else
     asm volatile(IPA_SGPR_HAZARD "global_store_dwordx4 %0, %1, %2\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
 }
+// four uint16 results of a lane (two dwords) - the strip remap of uint16 frames into uint16 (CV16 below)
+__device__ __forceinline__ void pipe_store2(unsigned lo, unsigned hi, unsigned voff, uint16_t* sbase) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  const v2u x = v2u{lo, hi};
+  asm volatile(IPA_SGPR_HAZARD "global_store_dwordx2 %0, %1, %2 " IPA_STORE_FLAVOUR "\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
+}
+// cv2.remap's 16U bilinear sum (sampler.hpp::sample_u16_cv, operation for operation): the 2-D weight of a tap is the
+// float32 PRODUCT wy * wx, the four products are summed left to right, every product and sum rounded (no fma)
+__device__ __forceinline__ float cv16_sum(float v00, float v01, float v10, float v11, float wx0, float wx1,
+                                          float wy0, float wy1) {
+#pragma clang fp contract(off)
+  float sum = v00 * (wy0 * wx0);
+  sum = sum + v01 * (wy0 * wx1);
+  sum = sum + v10 * (wy1 * wx0);
+  sum = sum + v11 * (wy1 * wx1);
+  return sum;
+}
+// saturate_cast<ushort>: round half to even, clamp (NaN -> 0)
+__device__ __forceinline__ unsigned cv16_round(float v) {
+  float r = rintf(v);
+  r = r > 0.f ? r : 0.f;
+  r = r < 65535.f ? r : 65535.f;
+  return (unsigned)r;
+}
 // the two dwords of a bilinear tap row at byte offset `off` of the frame (range-checked)
 __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v4i rs) {
 #ifdef IPA_DEBUG_NO_GATHER   // measurement only (WRONG results): taps from arithmetic
@@ -705,7 +729,10 @@ template <int K> struct DenseFilter {
   }
 };
 
-template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord>
+// CV16 (round 6, the strip remap of uint16 frames INTO uint16 - what LensDistortion.correct returns for camera
+// frames, camera/LensDistortion.py:323-326): K = 1, the blend is cv2's 16U arithmetic (cv16_sum; the slow path is
+// sample_u16_cv itself), `dst` is a uint16 image and a lane's four results leave as two dwords.
+template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord, bool CV16 = false>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       const SampleRowSrc<ST, kLinear, Coord>& src,
                                                       Filter& filt, float* xp, float* ring,
@@ -752,7 +779,9 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned voff = 16u * lane, moff = NAT ? 4u * CB * lane : CB * lane;
   auto ucol = [&](int k) -> int { return NAT ? c.uu[k] : c.uq[k]; };            // EDGE: resolved column of sample k
   auto pxcol = [&](int k) -> int { return NAT ? 4 * (int)lane + k : (int)lane + 64 * k; };   // strip pixel of sample k
+  static_assert(!CV16 || (K == 1 && QM == 1 && !HALO && sizeof(ST) == 2), "CV16: uint16 frames, 1/32-px coordinates, no filter");
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
+  uint16_t* outs16 = reinterpret_cast<uint16_t*>(dst) + ((long)y0 * p.dpitch + c.xs);   // (CV16)
   const int yb = y0 - G::H;                          // first input row of the strip
   // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
   // filter's border mode per lane (c.uq, -1 = constant border), its rows per row on the scalar
@@ -997,12 +1026,16 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       float v00, v01, v10, v11;
       taps_of(top, k, v00, v01);
       taps_of(bot, k, v10, v11);
-      float r0 = wx0 * v00;
-      r0 = ipa_fma(wx1, v01, r0);
-      float o = wy0 * r0;
-      float r1 = wx0 * v10;
-      r1 = ipa_fma(wx1, v11, r1);
-      cur[k] = ipa_fma(wy1, r1, o);
+      if constexpr (CV16) {
+        cur[k] = cv16_sum(v00, v01, v10, v11, wx0, wx1, wy0, wy1);
+      } else {
+        float r0 = wx0 * v00;
+        r0 = ipa_fma(wx1, v01, r0);
+        float o = wy0 * r0;
+        float r1 = wx0 * v10;
+        r1 = ipa_fma(wx1, v11, r1);
+        cur[k] = ipa_fma(wy1, r1, o);
+      }
     }
     int rowt = 0;   // EDGE: resolved row of this strip row
     if constexpr (EDGE) {
@@ -1064,8 +1097,15 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             float v00, v01, v10, v11;
             taps_of(top, k, v00, v01);
             taps_of(bot, k, v10, v11);
-            const float o = border_blend(v00, v01, v10, v11, tx[k], ty[k], (interior >> (8 + 4 * k)) & 15u,
-                                         src.cval);
+            float o;
+            if constexpr (CV16) {   // taps outside the source are the border value, none inside = the border value
+              const unsigned vb = (interior >> (8 + 4 * k)) & 15u;
+              o = cv16_sum((vb & 1u) ? v00 : src.cval, (vb & 2u) ? v01 : src.cval, (vb & 4u) ? v10 : src.cval,
+                           (vb & 8u) ? v11 : src.cval, 1.f - tx[k], tx[k], 1.f - ty[k], ty[k]);
+              o = vb ? o : src.cval;
+            } else {
+              o = border_blend(v00, v01, v10, v11, tx[k], ty[k], (interior >> (8 + 4 * k)) & 15u, src.cval);
+            }
             bool keep = true;   // EDGE: positions the filter's constant border supplies stay
             if constexpr (EDGE) keep = !(rowt < 0 || ucol(k) < 0);
             if (keep) xp[kRowPad + (unsigned)pxcol(k)] = o;
@@ -1089,13 +1129,17 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             // (the column is resolved again: c.uq[k] with a run-time k would live in scratch)
             const int uqk = resolve_idx(col, p.dw, p.cbx);
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
-            if (!(rowt < 0 || uqk < 0)) xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+            if (!(rowt < 0 || uqk < 0)) {
+              if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
+              else xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+            }
           } else {
             // (t < T: the last block is filled up to a whole number of steps with the records of row T - 1; the
             //  coordinate row itself must be clamped too - a table source has no row past a strip that ends with
             //  the frame: a page fault on a map that ended with its allocation, round 6)
             src.coord.get(col, yb + (t < T ? t : T - 1), sx, sy);
-            xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
+            if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
+            else xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           }
         }
       }
@@ -1151,7 +1195,12 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #endif
     IPA_STAMP(4);
     if (o >= 0 && o < nrows) {
-      if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
+      if constexpr (CV16) {
+        const unsigned lo = cv16_round(q.x) | (cv16_round(q.y) << 16), hi = cv16_round(q.z) | (cv16_round(q.w) << 16);
+        if (writer) pipe_store2(lo, hi, 8u * lane, outs16 + (long)o * p.dpitch);
+      } else {
+        if (writer) pipe_store4<true>(q, voff, outs + (long)o * p.dpitch);
+      }
     }
     __builtin_amdgcn_wave_barrier();
     IPA_STAMP(5);

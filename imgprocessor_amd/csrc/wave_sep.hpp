@@ -299,9 +299,13 @@ struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> {
                                 (I == kLinear && IPA_PIPE != 0 && IPA_PIPE_SHARED != 0);
 };
 
-template <typename Src, int K>
+// DT: the destination's element type - float32, or (K = 1, uint16 frames with 1/32-px coordinates on the shared-record
+// loop only: wave_pipe.hpp CV16) uint16; the host launches that form only where every strip takes that loop
+template <typename Src, int K, typename DT = float>
 __global__ void __launch_bounds__(256)
 wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
+  constexpr bool kCv16 = std::is_same<DT, uint16_t>::value;
+  static_assert(std::is_same<DT, float>::value || (kCv16 && K == 1), "float32 results, or the uint16 strip remap");
   constexpr int H = K / 2, D = sep_depth<Src, K>::value, HL = sep_geom<K>::HL, OW = sep_geom<K>::OW;
   constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;
   __shared__ __attribute__((aligned(16))) float xpose[kRegs ? 1 : 4 * kRowStride * D];
@@ -344,7 +348,8 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
   int y0, nrows;
   if (!wave_strip_rows(p, syi, y0, nrows)) return;
   const bool writer = lane >= HL && lane < 64 - HL && c.xo < p.dw;
-  float* dst = reinterpret_cast<float*>(p.dst) + (long)frame * p.dst_frame_elems;
+  // (uint16 results: the same pointer arithmetic in their elements; the loop below reinterprets it)
+  float* dst = reinterpret_cast<float*>(reinterpret_cast<DT*>(p.dst) + (long)frame * p.dst_frame_elems);
   const int rows_touched = ((nrows + K - 1 + D - 1) / D) * D;
   const bool fast = !p.no_pipe && src.vectors_ok() && p.vec_out && xs >= 0 && xs + 256 <= p.dw &&
                     y0 - H >= 0 && y0 - H + rows_touched <= p.dh;
@@ -354,12 +359,18 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     if constexpr (kShared) {
       if (p.frames_wg) {   // every wave of the workgroup: the same strip of another frame
         SepFilter<K> filt(w, xcval);
-        if (src.q5) wave_run_strip_shared<K, 1, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if constexpr (kCv16) {
+          wave_run_strip_shared<K, 1, false, false, SepFilter<K>, typename Src::sample_type, typename Src::coord_type, true>(
+              p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        } else {
+          if (src.q5) wave_run_strip_shared<K, 1, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+          else wave_run_strip_shared<K, 0, false, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        }
         return;
       }
     }
-    if constexpr (!kRegs) {
+    if constexpr (kCv16) return;   // (never: the host launches this form only where every strip takes the loop above)
+    else if constexpr (!kRegs) {
       if (src.q5) wave_sep_strip<true, Src, K, 1>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
       else wave_sep_strip<true, Src, K, 0>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
     } else {
@@ -374,16 +385,21 @@ wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
     if constexpr (kShared) {
       if (p.frames_wg && !p.no_pipe && src.vectors_ok() && p.vec_out && (p.dw & 3) == 0 && IPA_PIPE_EDGE) {
         SepFilter<K> filt(w, xcval);
-        if (src.q5) wave_run_strip_shared<K, 1, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
-        else wave_run_strip_shared<K, 0, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        if constexpr (kCv16) {
+          wave_run_strip_shared<K, 1, true, false, SepFilter<K>, typename Src::sample_type, typename Src::coord_type, true>(
+              p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        } else {
+          if (src.q5) wave_run_strip_shared<K, 1, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+          else wave_run_strip_shared<K, 0, true, false>(p, src, filt, xp, mapring, wave, c, y0, nrows, writer, dst);
+        }
         return;
       }
     }
-    wave_sep_strip<false, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
+    if constexpr (!kCv16) wave_sep_strip<false, Src, K>(p, src, w, xp, c, y0, nrows, writer, dst, xcval);
   }
 }
 
-template <typename Src, int K>
+template <typename Src, int K, typename DT = float>
 static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double* ky,
                        const double* kx, int n_frames, float xcval) {
   SepTaps<K> w;
@@ -403,7 +419,7 @@ static void launch_sep(ipa_ctx* ctx, WaveParams p, const Src& src, const double*
   // own (knob frame_major, as the dense plain filters since round 4)
   dim3 grid = wave_grid(ctx, p, n_frames, 4, true, sep_shares_maps<Src>::value,
                         std::is_same<Src, LoadRowSrc>::value, -K), block(256);
-  hipLaunchKernelGGL((wave_sep_kernel<Src, K>), grid, block, 0, ctx->stream, p, src, w, xcval);
+  hipLaunchKernelGGL((wave_sep_kernel<Src, K, DT>), grid, block, 0, ctx->stream, p, src, w, xcval);
 }
 
 }  // namespace ipa

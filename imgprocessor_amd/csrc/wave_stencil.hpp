@@ -390,6 +390,7 @@ struct LoadRowSrc {
 template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
   using C = typename Coord::coord_t;
   using coord_type = Coord;
+  using sample_type = ST;
   static constexpr bool kMap = std::is_same<Coord, MapCoord>::value;
 #ifndef IPA_SAMPLE_DEPTH
 #define IPA_SAMPLE_DEPTH 2

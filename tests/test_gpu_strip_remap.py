@@ -151,3 +151,63 @@ def test_integer_batches_undistort_through_the_cached_map(ia, oracle, dtype, int
     mx, my = oracle.build_undistort_map(Kc, dist, newK, h, w)
     got = ops.undistort(d, Kc, dist, newK, interp, 'constant', 9.0).get()
     assert np.array_equal(got[n - 1], oracle.remap(src[n - 1], mx, my, oi, oracle.CONSTANT, 9.0))
+
+
+@pytest.mark.parametrize('shape', [(150, 612), (97, 336), (301, 1032), (97, 333)])
+@pytest.mark.parametrize('n', [4, 8, 12, 6])
+def test_uint16_into_uint16_with_cv2_arithmetic(ia, oracle, shape, n):
+    """round 6: cv2.remap on uint16 frames RETURNS uint16 - what LensDistortion.correct gives for camera frames
+    (camera/LensDistortion.py:323-326; the wrapper asks for cv2's 16U arithmetic at 1/32-px coordinates,
+    'linear_cv_q5').  Batches of a multiple of 4 frames with rows of whole vectors run on the marching strips with that
+    arithmetic (wave_pipe.hpp CV16): the gather kernel's integers and the oracle's, bit for bit."""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w, np.uint16)
+    src[:, 0, 0] = src[:, -1, -1] = 65535            # the corners, and saturation
+    mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
+    mx = mx - np.float32(15.0)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    expect = n % 4 == 0 and w % 4 == 0
+    for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
+        for name, fn in (('maps', lambda: ops.remap(d, dmx, dmy, 'linear_cv_q5', border, 17.6)),
+                         ('lens model', lambda: ops.undistort(d, Kc, dist, Kc, 'linear_cv_q5', border, 17.6))):
+            before = taken(ctx)
+            got = fn().get()
+            assert taken(ctx) == before + (1 if expect else 0), (name, shape, n)
+            old = ctx.set_tuning(strip_remap=0)
+            try:
+                ref = fn().get()
+            finally:
+                ctx.set_tuning(**old)
+            assert got.dtype == np.uint16 and np.array_equal(got, ref), (name, border, shape, n)
+        want = oracle.remap(src[n - 1], mx, my, oracle.LINEAR | oracle.Q5, {'constant': oracle.CONSTANT, 'replicate': oracle.REPLICATE,
+                            'reflect': oracle.REFLECT, 'wrap': oracle.WRAP, 'reflect101': oracle.REFLECT101}[border], 17.6)
+        got = ops.remap(d, dmx, dmy, 'linear_cv_q5', border, 17.6).get()
+        assert np.array_equal(got[n - 1], want), (border, shape, n)
+    # exact coordinates ('linear' on integer frames: double arithmetic) is not this route
+    before = taken(ctx)
+    ops.remap(d, dmx, dmy, 'linear', 'constant', 0.0)
+    assert taken(ctx) == before
+
+
+def test_lens_distortion_correct_on_a_uint16_batch(ia, oracle):
+    """the reference's call itself: LensDistortion.correct on (n, h, w) camera frames"""
+    from imgprocessor_amd.camera.LensDistortion import LensDistortion
+    ctx = ia.default_context(0)
+    h, w, n = 120, 640, 8
+    ld = LensDistortion()
+    ld.setCameraParams(float(w), float(w), (w - 1) / 2.0, (h - 1) / 2.0, -0.12, 0.03, 0.0, 1e-3, -5e-4)
+    src = frames(n, h, w, np.uint16)
+    before = taken(ctx)
+    got = ld.correct(ctx.to_device(src), keepSize=True)
+    got = got.get() if hasattr(got, 'get') else got
+    assert got.dtype == np.uint16 and got.shape == (n, h, w)
+    old = ctx.set_tuning(strip_remap=0)
+    try:
+        ref = ld.correct(ctx.to_device(src), keepSize=True)
+        ref = ref.get() if hasattr(ref, 'get') else ref
+    finally:
+        ctx.set_tuning(**old)
+    assert np.array_equal(got, ref)
+    assert taken(ctx) > before
