@@ -8,6 +8,7 @@ void ipa_fused_sep_launch_a(ipa_ctx*, const FusedCall&, const FusedSep&);  // 3,
 void ipa_fused_sep_launch_b(ipa_ctx*, const FusedCall&, const FusedSep&);  // 7, 9 taps
 void ipa_fused_sep_launch_c(ipa_ctx*, const FusedCall&, const FusedSep&);  // 1 tap: the remap alone
 void ipa_fused_sep_launch_c16(ipa_ctx*, const FusedCall&);                   // ... uint16 into uint16 (cv2's 16U arithmetic)
+void ipa_fused_sep_launch_c8(ipa_ctx*, const FusedCall&);                    // ... uint8 into uint8 (cv2's 8U fixed point)
 
 int ipa_fused_launch_k3(ipa_ctx*, const FusedCall&);
 int ipa_fused_launch_k5(ipa_ctx*, const FusedCall&);
@@ -223,33 +224,40 @@ static bool rotated_warp_in_two_launches(const ipa_ctx* ctx, const double* m, in
   return drift >= (ctx->tune.tile_warp > 1 ? 0.0 : 0.2);
 }
 
-// The strip remap of uint16 frames INTO uint16 (remap.hip::ipa_remap_dev): cv2.remap's 16U bilinear at 1/32-px
-// coordinates - what LensDistortion.correct returns for camera frames - on the shared-record loop.  Returns 1 when the
-// call is not one the loop covers on EVERY strip (the caller then takes the gather kernel), 0 when launched.
-int ipa_strip_remap_u16(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
+// The strip remap of integer frames INTO their own type (remap.hip::ipa_remap_dev): cv2.remap's bilinear as it computes
+// it on 16U (float32 product weights at 1/32-px coordinates) and 8U (15-bit fixed point) images - what
+// LensDistortion.correct returns for camera frames - on the shared-record loop.  Returns 1 when the call is not one the
+// loop covers on EVERY strip (the caller then takes the gather kernel), 0 when launched.
+int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
                         const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
                         long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
                         double border_value) {
   const ipa_tuning& t = ctx->tune;
   if (!t.strip_remap || !t.sep_u16 || !t.frames_wg || !t.frames_inner || !t.pipe) return 1;
-  if (interp != (IPA_INTER_LINEAR | IPA_INTER_Q5) || n_frames < 4 || n_frames % 4 != 0 || n_frames > 65535) return 1;
+  // uint16: cv2's arithmetic is what 'linear_cv_q5' names ('linear' = exact coordinates in double: the gather kernel);
+  // uint8: every bilinear remap is cv2's fixed point
+  if (dtype == IPA_U16 ? interp != (IPA_INTER_LINEAR | IPA_INTER_Q5)
+                       : (dtype != IPA_U8 || (interp & 0xff) != IPA_INTER_LINEAR || (interp & ~(0xff | IPA_INTER_Q5)) != 0))
+    return 1;
+  if (n_frames < 4 || n_frames % 4 != 0 || n_frames > 65535) return 1;
   if (!d_src || !d_dst || !d_mapx || !d_mapy || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (dw & 3) != 0) return 1;
   if (src_pitch < sw || dst_pitch < dw || map_pitch < dw || src_pitch >= (1l << 23)) return 1;
-  if (((size_t)(sh - 1) * src_pitch + sw) * 2 >= (1ull << 31)) return 1;
+  if (((size_t)(sh - 1) * src_pitch + sw) * ipa_dtype_size(dtype) >= (1ull << 31)) return 1;
   if ((unsigned long)(((dw + 255) / 256) * ((dh + 15) / 16)) * (unsigned long)n_frames >= (1ul << 31)) return 1;
   FusedCall f;
   f.coord_kind = 0;
   f.map = MapCoord{d_mapx, d_mapy, map_pitch};
-  int rc = fused_fill(ctx, f, d_src, IPA_U16, sh, sw, src_pitch, d_dst, IPA_U16, dh, dw, dst_pitch, n_frames,
+  int rc = fused_fill(ctx, f, d_src, dtype, sh, sw, src_pitch, d_dst, dtype, dh, dw, dst_pitch, n_frames,
                       src_frame_stride, dst_frame_stride, interp, border_mode, border_value, IPA_BORDER_REFLECT,
                       IPA_BORDER_REFLECT);
   if (rc) return rc;
   if (!f.p.vec_out || !f.map_vec) return 1;   // (rows of the result / of the maps that are no whole 16-byte vectors)
-  // the border value as cv2 casts it: saturate_cast<ushort>
-  const double r16 = rint(border_value);
-  f.cval = r16 > 0 ? (r16 < 65535 ? r16 : 65535) : 0;
+  // the border value as cv2 casts it: saturate_cast
+  const double r = rint(border_value), top = dtype == IPA_U16 ? 65535.0 : 255.0;
+  f.cval = r > 0 ? (r < top ? r : top) : 0;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-  ipa_fused_sep_launch_c16(ctx, f);
+  if (dtype == IPA_U16) ipa_fused_sep_launch_c16(ctx, f);
+  else ipa_fused_sep_launch_c8(ctx, f);
   IPA_HIP(ctx, hipGetLastError());
   ctx->strip_remaps++;
   return IPA_OK;

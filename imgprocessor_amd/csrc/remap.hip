@@ -287,7 +287,7 @@ int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, cons
   return IPA_OK;
 }
 
-int ipa_strip_remap_u16(ipa_ctx* ctx, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
+int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
                         const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
                         long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
                         double border_value);   // fused.hip (internal, C++ linkage)
@@ -374,11 +374,13 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
                   double border_value) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
-  if (src_dtype == IPA_U16 && dst_dtype == IPA_U16) {
-    // ... and INTO uint16 with cv2's 16U arithmetic (what LensDistortion.correct returns for camera frames): the same
-    // strips, the blend of sampler.hpp::sample_u16_cv (fused.hip::ipa_strip_remap_u16; 1: not a call it covers)
-    int rc = ipa_strip_remap_u16(ctx, d_src, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, d_dst, dh, dw, dst_pitch,
-                                 n_frames, src_frame_stride, dst_frame_stride, interp, border_mode, border_value);
+  if ((src_dtype == IPA_U16 || src_dtype == IPA_U8) && dst_dtype == src_dtype) {
+    // ... and INTO the frames' own integer type with cv2's arithmetic (what LensDistortion.correct returns for camera
+    // frames): the same strips, the blend of sampler.hpp::sample_u16_cv / sample_u8_fixed
+    // (fused.hip::ipa_strip_remap_int; 1: not a call it covers)
+    int rc = ipa_strip_remap_int(ctx, src_dtype, d_src, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, d_dst, dh, dw,
+                                 dst_pitch, n_frames, src_frame_stride, dst_frame_stride, interp, border_mode,
+                                 border_value);
     if (rc <= 0) return rc;
   }
   if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,

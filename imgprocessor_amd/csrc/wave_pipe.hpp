@@ -155,6 +155,18 @@ __device__ __forceinline__ float cv16_sum(float v00, float v01, float v10, float
   sum = sum + v11 * (wy1 * wx1);
   return sum;
 }
+// cv2.remap's 8U bilinear (sampler.hpp::sample_u8_fixed, integer for integer): 15-bit weights from the 1/32-px
+// fractions, rounded shift; tx / ty are k / 32 exactly
+__device__ __forceinline__ float fix8_sum(int v00, int v01, int v10, int v11, float tx, float ty) {
+  const int fx = (int)(tx * 32.f), fy = (int)(ty * 32.f);
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  const int acc = v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11;
+  const int o = (acc + (1 << 14)) >> 15;
+  return (float)(o < 0 ? 0 : (o > 255 ? 255 : o));
+}
+__device__ __forceinline__ void pipe_store1(unsigned x, unsigned voff, uint8_t* sbase) {
+  asm volatile(IPA_SGPR_HAZARD "global_store_dword %0, %1, %2 " IPA_STORE_FLAVOUR "\n\ts_nop 0" ::"v"(voff), "v"(x), "s"(sbase));
+}
 // saturate_cast<ushort>: round half to even, clamp (NaN -> 0)
 __device__ __forceinline__ unsigned cv16_round(float v) {
   float r = rintf(v);
@@ -182,6 +194,19 @@ __device__ __forceinline__ void pipe_gather2(float& a, float& b, unsigned off, v
 // one dword (uint16 frames: both taps of a bilinear tap row)
 __device__ __forceinline__ void pipe_gather1(float& a, unsigned off, v4i rs) {
   asm volatile(IPA_SGPR_HAZARD "buffer_load_dword %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+}
+// two bytes (uint8 frames: both taps of a bilinear tap row, zero-extended; any byte offset)
+__device__ __forceinline__ void pipe_gather1_b16(float& a, unsigned off, v4i rs) {
+  asm volatile(IPA_SGPR_HAZARD "buffer_load_ushort %0, %1, %2, 0 offen" : "=v"(a) : "v"(off), "s"(rs));
+}
+__device__ __forceinline__ void pipe_gather1_b16_masked(float& a, unsigned off, v4i rs, unsigned long long m) {
+  unsigned long long sv;
+  asm volatile(IPA_SGPR_HAZARD "s_mov_b64 %1, exec\n\t"
+               "s_mov_b64 exec, %4\n\t"
+               "buffer_load_ushort %0, %2, %3, 0 offen\n\t"
+               "s_mov_b64 exec, %1"
+               : "+v"(a), "=&s"(sv)
+               : "v"(off), "s"(rs), "s"(m));
 }
 __device__ __forceinline__ void pipe_gather1_masked(float& a, unsigned off, v4i rs,
                                                     unsigned long long m) {
@@ -732,6 +757,8 @@ template <int K> struct DenseFilter {
 // CV16 (round 6, the strip remap of uint16 frames INTO uint16 - what LensDistortion.correct returns for camera
 // frames, camera/LensDistortion.py:323-326): K = 1, the blend is cv2's 16U arithmetic (cv16_sum; the slow path is
 // sample_u16_cv itself), `dst` is a uint16 image and a lane's four results leave as two dwords.
+// uint8 frames (ST = uint8_t, the same CV16 flag): into uint8 with cv2's 8U fixed-point arithmetic (fix8_sum /
+// sample_u8_fixed); a tap row is one 16-bit load, a lane's four results leave as one dword.
 template <int K, int QM, bool EDGE, bool HALO, typename Filter, typename ST, typename Coord, bool CV16 = false>
 __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
                                                       const SampleRowSrc<ST, kLinear, Coord>& src,
@@ -762,8 +789,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   // registers per tap row of a footprint: float32 frames two dwords, uint16 frames ONE dword that
   // holds both taps (any byte offset, as TapLoad<uint16_t, float> loads it)
   constexpr int NR = sizeof(ST) == 4 ? 2 : 1;
-  constexpr int SH = sizeof(ST) == 4 ? 2 : 1;   // log2 of the element size
-  static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value, "float32 / uint16 frames");
+  constexpr int SH = sizeof(ST) == 4 ? 2 : (sizeof(ST) == 2 ? 1 : 0);   // log2 of the element size
+  constexpr bool FIX8 = sizeof(ST) == 1;        // uint8 frames: integer arithmetic, 16-bit tap loads (CV16 only)
+  static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value ||
+                (std::is_same<ST, uint8_t>::value && CV16), "float32 / uint16 frames, uint8 into uint8");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
   // lane order of the samples: interleaved (sample k of lane L = strip pixel L + 64 k: the 64
   // gathers of an instruction walk along the source row) or natural (pixel 4 L + k; measurement
@@ -779,9 +808,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   const unsigned voff = 16u * lane, moff = NAT ? 4u * CB * lane : CB * lane;
   auto ucol = [&](int k) -> int { return NAT ? c.uu[k] : c.uq[k]; };            // EDGE: resolved column of sample k
   auto pxcol = [&](int k) -> int { return NAT ? 4 * (int)lane + k : (int)lane + 64 * k; };   // strip pixel of sample k
-  static_assert(!CV16 || (K == 1 && QM == 1 && !HALO && sizeof(ST) == 2), "CV16: uint16 frames, 1/32-px coordinates, no filter");
+  static_assert(!CV16 || (K == 1 && QM == 1 && !HALO && sizeof(ST) <= 2), "CV16: integer frames, 1/32-px coordinates, no filter");
   float* outs = dst + ((long)y0 * p.dpitch + c.xs);  // scalar: output row 0
   uint16_t* outs16 = reinterpret_cast<uint16_t*>(dst) + ((long)y0 * p.dpitch + c.xs);   // (CV16)
+  uint8_t* outs8 = reinterpret_cast<uint8_t*>(dst) + ((long)y0 * p.dpitch + c.xs);      // (CV16, uint8 frames)
   const int yb = y0 - G::H;                          // first input row of the strip
   // EDGE: a strip on the rim of the filter domain - its columns are resolved through the
   // filter's border mode per lane (c.uq, -1 = constant border), its rows per row on the scalar
@@ -922,6 +952,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { pipe_gather1(g[2 * k], o, rs); return; }
 #endif
     if constexpr (NR == 2) pipe_gather2(g[2 * k], g[2 * k + 1], o, rs);
+    else if constexpr (FIX8) pipe_gather1_b16(g[k], o, rs);
     else pipe_gather1(g[k], o, rs);
   };
   auto gather_masked = [&](float (&g)[NS * NR], int k, unsigned o, unsigned long long m) {
@@ -929,6 +960,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { pipe_gather1_masked(g[2 * k], o, rs, m); return; }
 #endif
     if constexpr (NR == 2) pipe_gather2_masked(g[2 * k], g[2 * k + 1], o, rs, m);
+    else if constexpr (FIX8) pipe_gather1_b16_masked(g[k], o, rs, m);
     else pipe_gather1_masked(g[k], o, rs, m);
   };
   auto pin_taps = [&](float (&g)[NS * NR]) {
@@ -946,6 +978,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = from_lane_above(v0); return; }
 #endif
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = g[2 * k + 1]; }
+    else if constexpr (FIX8) { v0 = (float)(__float_as_uint(g[k]) & 0xffu); v1 = (float)((__float_as_uint(g[k]) >> 8) & 0xffu); }
     else TapLoad<uint16_t, float>::unpack(__float_as_uint(g[k]), v0, v1);
   };
 
@@ -1026,7 +1059,9 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
       float v00, v01, v10, v11;
       taps_of(top, k, v00, v01);
       taps_of(bot, k, v10, v11);
-      if constexpr (CV16) {
+      if constexpr (FIX8) {
+        cur[k] = fix8_sum((int)v00, (int)v01, (int)v10, (int)v11, tx[k], ty[k]);
+      } else if constexpr (CV16) {
         cur[k] = cv16_sum(v00, v01, v10, v11, wx0, wx1, wy0, wy1);
       } else {
         float r0 = wx0 * v00;
@@ -1098,7 +1133,13 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             taps_of(top, k, v00, v01);
             taps_of(bot, k, v10, v11);
             float o;
-            if constexpr (CV16) {   // taps outside the source are the border value, none inside = the border value
+            if constexpr (FIX8) {
+              const unsigned vb = (interior >> (8 + 4 * k)) & 15u;
+              const int cv = (int)src.cval;
+              o = fix8_sum((vb & 1u) ? (int)v00 : cv, (vb & 2u) ? (int)v01 : cv, (vb & 4u) ? (int)v10 : cv,
+                           (vb & 8u) ? (int)v11 : cv, tx[k], ty[k]);
+              o = vb ? o : src.cval;
+            } else if constexpr (CV16) {   // taps outside the source are the border value, none inside = the border value
               const unsigned vb = (interior >> (8 + 4 * k)) & 15u;
               o = cv16_sum((vb & 1u) ? v00 : src.cval, (vb & 2u) ? v01 : src.cval, (vb & 4u) ? v10 : src.cval,
                            (vb & 8u) ? v11 : src.cval, 1.f - tx[k], tx[k], 1.f - ty[k], ty[k]);
@@ -1130,7 +1171,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             const int uqk = resolve_idx(col, p.dw, p.cbx);
             src.coord.get(uqk < 0 ? 0 : uqk, rowt < 0 ? 0 : rowt, sx, sy);
             if (!(rowt < 0 || uqk < 0)) {
-              if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
+              if constexpr (FIX8) xp[pos] = (float)sample_u8_fixed<C>(s, sx, sy, (uint8_t)src.cval);
+              else if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
               else xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
             }
           } else {
@@ -1138,7 +1180,8 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
             //  coordinate row itself must be clamped too - a table source has no row past a strip that ends with
             //  the frame: a page fault on a map that ended with its allocation, round 6)
             src.coord.get(col, yb + (t < T ? t : T - 1), sx, sy);
-            if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
+            if constexpr (FIX8) xp[pos] = (float)sample_u8_fixed<C>(s, sx, sy, (uint8_t)src.cval);
+            else if constexpr (CV16) xp[pos] = (float)sample_u16_cv<kLinear, C>(s, nullptr, sx, sy, (uint16_t)src.cval);
             else xp[pos] = sample<ST, kLinear, C>(s, sx, sy, src.cval);
           }
         }
@@ -1195,7 +1238,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
 #endif
     IPA_STAMP(4);
     if (o >= 0 && o < nrows) {
-      if constexpr (CV16) {
+      if constexpr (FIX8) {   // (the samples are whole numbers 0 .. 255 already)
+        const unsigned px = (unsigned)q.x | ((unsigned)q.y << 8) | ((unsigned)q.z << 16) | ((unsigned)q.w << 24);
+        if (writer) pipe_store1(px, 4u * lane, outs8 + (long)o * p.dpitch);
+      } else if constexpr (CV16) {
         const unsigned lo = cv16_round(q.x) | (cv16_round(q.y) << 16), hi = cv16_round(q.z) | (cv16_round(q.w) << 16);
         if (writer) pipe_store2(lo, hi, 8u * lane, outs16 + (long)o * p.dpitch);
       } else {

@@ -289,7 +289,8 @@ template <int K> struct SepFilter {
 template <typename Src, int K> struct sep_shared : std::false_type {};
 template <typename ST, typename Coord, int K> struct sep_shared<SampleRowSrc<ST, kLinear, Coord>, K> {
   static constexpr bool value = IPA_PIPE != 0 && IPA_PIPE_SHARED != 0 &&
-                                (std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value);
+                                (std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value ||
+                                 (std::is_same<ST, uint8_t>::value && K == 1));   // (uint8: the integer strip remap only)
 };
 
 template <typename Src> struct sep_shares_maps : std::false_type {};
@@ -299,13 +300,13 @@ struct sep_shares_maps<SampleRowSrc<ST, I, Coord>> {
                                 (I == kLinear && IPA_PIPE != 0 && IPA_PIPE_SHARED != 0);
 };
 
-// DT: the destination's element type - float32, or (K = 1, uint16 frames with 1/32-px coordinates on the shared-record
-// loop only: wave_pipe.hpp CV16) uint16; the host launches that form only where every strip takes that loop
+// DT: the destination's element type - float32, or (K = 1, integer frames with cv2's own arithmetic on the shared-record
+// loop only: wave_pipe.hpp CV16) uint16 / uint8; the host launches that form only where every strip takes that loop
 template <typename Src, int K, typename DT = float>
 __global__ void __launch_bounds__(256)
 wave_sep_kernel(WaveParams p, Src src, SepTaps<K> w, float xcval) {
-  constexpr bool kCv16 = std::is_same<DT, uint16_t>::value;
-  static_assert(std::is_same<DT, float>::value || (kCv16 && K == 1), "float32 results, or the uint16 strip remap");
+  constexpr bool kCv16 = std::is_same<DT, uint16_t>::value || std::is_same<DT, uint8_t>::value;   // integer results
+  static_assert(std::is_same<DT, float>::value || (kCv16 && K == 1), "float32 results, or the integer strip remaps");
   constexpr int H = K / 2, D = sep_depth<Src, K>::value, HL = sep_geom<K>::HL, OW = sep_geom<K>::OW;
   constexpr bool kRegs = std::is_same<Src, LoadRowSrc>::value;
   __shared__ __attribute__((aligned(16))) float xpose[kRegs ? 1 : 4 * kRowStride * D];

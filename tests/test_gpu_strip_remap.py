@@ -211,3 +211,36 @@ def test_lens_distortion_correct_on_a_uint16_batch(ia, oracle):
         ctx.set_tuning(**old)
     assert np.array_equal(got, ref)
     assert taken(ctx) > before
+
+
+@pytest.mark.parametrize('shape', [(150, 608), (97, 336), (301, 1040), (97, 340), (97, 342)])
+@pytest.mark.parametrize('n', [4, 8, 12, 6])
+def test_uint8_into_uint8_with_cv2_fixed_point(ia, oracle, shape, n):
+    """... and 8-bit camera frames: cv2.remap's 8U bilinear (15-bit fixed-point weights from the 1/32-px fractions, rounded
+    shift - every bilinear remap of uint8 frames is that arithmetic, with or without the q5 flag) on the same strips: one
+    16-bit load per tap row, a lane's four results as one dword.  Integers of the gather kernel and of the oracle."""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w, np.uint8)
+    src[:, 0, 0] = src[:, -1, -1] = 255
+    mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
+    mx = mx - np.float32(15.0)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    expect = n % 4 == 0 and w % 4 == 0          # (rows of whole dwords)
+    for interp in ('linear', 'linear_cv_q5'):
+        for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
+            for name, fn in (('maps', lambda: ops.remap(d, dmx, dmy, interp, border, 17.6)),
+                             ('lens model', lambda: ops.undistort(d, Kc, dist, Kc, interp, border, 17.6))):
+                before = taken(ctx)
+                got = fn().get()
+                assert taken(ctx) == before + (1 if expect else 0), (name, shape, n, interp)
+                old = ctx.set_tuning(strip_remap=0)
+                try:
+                    ref = fn().get()
+                finally:
+                    ctx.set_tuning(**old)
+                assert got.dtype == np.uint8 and np.array_equal(got, ref), (name, interp, border, shape, n)
+    want = oracle.remap(src[n - 1], mx, my, oracle.LINEAR | oracle.Q5, oracle.CONSTANT, 17.6)
+    got = ops.remap(d, dmx, dmy, 'linear', 'constant', 17.6).get()
+    assert np.array_equal(got[n - 1], want), (shape, n)
