@@ -246,7 +246,23 @@ def other_configs(ctx, ia, ops, budget_launches=60):
               B, h, w, ms, (8 * B + 8) * h * w, 1,
               'tile kernel with the map pair as coordinate source (csrc/tile_warp.hpp)',
               **({'bound': 'lds', 'work': 40 * 8 * B * h * w, 'issue': 'lz4q'} if interp == 'lanczos4' else {}))
-    del src, dst, dmx, dmy
+    del src, dst
+    # ... on CAMERA frames (round 6): cv2.remap keeps the element type - uint16 with cv2's 16U arithmetic (what the
+    # wrapper asks for: 'linear_cv_q5'), uint8 with its 8U fixed point - and the float32 ingest of uint16 frames
+    # (transformations.toFloatArray): the marching strips of the chains without a filter (knob strip_remap)
+    f16 = np.round(synth_frames(B, h, w, 260) * 4095).astype(np.uint16)
+    for name, arr, interp, odt, bpp in (('uint16 -> uint16, cv2 16U arithmetic', f16, 'linear_cv_q5', np.uint16, 4),
+                                        ('uint8 -> uint8, cv2 8U fixed point', (f16 >> 4).astype(np.uint8), 'linear', np.uint8, 2),
+                                        ('uint16 -> float32 (toFloatArray ingest)', f16, 'linear', np.float32, 6)):
+        for nb in (B, 64):
+            dsrc = ctx.to_device(arr if nb == B else np.concatenate([arr] * (nb // B)))
+            dd = ctx.empty((nb, h, w), odt)
+            ms = timed_settled(ctx, lambda: ops.remap(dsrc, dmx, dmy, interp, out_dtype=odt, out=dd), budget_launches // (1 if nb == B else 2), 3)
+            entry('LensDistortion.correct 4K %s, %d frames/launch' % (name, nb), nb, h, w, ms, (bpp * nb + 8) * h * w, 1,
+                  'wave_sep_kernel with K = 1 on the shared-record loop (csrc/wave_pipe.hpp CV16 / fused_sep_c.hip); the gather '
+                  'kernels these calls took in rounds 1 - 5: profiles/r06_micro.txt')
+            del dsrc, dd
+    del dmx, dmy
 
     # C3: 4K float32, perspective remap (homography in the kernel: no maps) + separable 9+9
     h, w, B = H4K, W4K, 16
