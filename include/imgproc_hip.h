@@ -91,7 +91,8 @@ int ipa_ctx_synchronize(ipa_ctx* ctx);
  *   the remap -> filter chains (float32 frames, bilinear taps, 3 / 5 / 7 / 9 taps), bit 1 the plain 9 x 9
  *   filter; default 3; the reference obtains its Gaussians separably: scipy.ndimage.gaussian_filter,
  *   filters/fastFilter.py:42).
- *   "strip_remap" (standalone bilinear remaps of uint16 frames into float32 - ipa_remap_dev, ipa_undistort_dev,
+ *   "strip_remap" (standalone bilinear remaps of camera frames - uint16 into float32, uint16 into uint16 with cv2's 16U
+ *   arithmetic (IPA_INTER_LINEAR | IPA_INTER_Q5), uint8 into uint8 with its 8U fixed point; ipa_remap_dev, ipa_undistort_dev,
  *   ipa_warp_perspective_dev - on the marching strips of the chains with no filter: default 1; read-only counter
  *   "strip_remaps").
  *   "sep_u16" (uint16 frames, bilinear remap by maps or a homography -> separable 3 / 5 / 7 / 9-tap filter in one kernel: default 1;
