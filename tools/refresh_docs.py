@@ -60,6 +60,10 @@ tab = '| configuration | ms | frac of 8 TB/s (compulsory bytes) |\n|---|---|---|
     row('C2 1080p float32 undistort + 5x5, 64 frames', find('C2 1080p')),
     row('`LensDistortion.correct` itself: cv2.remap from the map pair, 16 x 4K, bilinear (tile kernel)', find('map pair (linear)'), issue('remaplin') if 'remaplin' in iss else ''),
     row('... Lanczos4', find('map pair (lanczos4)'), issue('remaplz4') if 'remaplz4' in iss else issue('lz4q')),
+    row('... on camera frames (round 6, the strips with K = 1): uint16 -> uint16 with cv2\'s 16U arithmetic, 16 frames (the gather kernel of rounds 1 - 5: 0.400)', find('uint16 -> uint16, cv2 16U arithmetic, 16')),
+    row('... 64 frames (1.61)', find('uint16 -> uint16, cv2 16U arithmetic, 64')),
+    row('... uint8 -> uint8 with cv2\'s 8U fixed point, 64 frames (1.01; 16 frames: 0.155 against 0.259)', find('uint8 -> uint8, cv2 8U fixed point, 64')),
+    row('... uint16 -> float32 (the `toFloatArray` ingest), 64 frames (1.28)', find('uint16 -> float32 (toFloatArray ingest), 64')),
     row('C3 4K perspective warp (bilinear) + separable 9+9, 16 frames, one kernel', find('warp (linear) + separable 9+9, 16'), issue('c3lin')),
     row('... 64 frames per launch', find('warp (linear) + separable 9+9, 64')),
     row('C3 bicubic, two launches (tile warp, filter)', find('warp (cubic) + separable'), '; the tile warp:' + issue('c3cubic')[1:]),
@@ -71,6 +75,7 @@ tab = '| configuration | ms | frac of 8 TB/s (compulsory bytes) |\n|---|---|---|
     row('C5-like 4K: bicubic warp + dense 11x11 (two launches)', find('C5-like')),
     row('C5 8K, 4 frames', find('C5 8K')),
     row('C4 64 x 4K uint16 -> float32 undistort + dense 7x7', find('C4 4K uint16'), issue('c4')),
+    row('... with a 7x7 Gaussian (an outer product: the separable 7 + 7 loop, since round 6 for uint16 frames too)', find('with a 7x7 Gaussian')),
 ])
 e = oc[find('C4 the same chain host')]
 tab += '\n| C4 host -> host, 24 frames through page-locked buffers | %.1f | PCIe-bound (%.1f Gpix/s), never `value` |\n\n' % (e['ms'], e['Mpix_s'] / 1e3)
@@ -97,7 +102,7 @@ p = open('profiles/README.md').read()
 i = p.index('| `r06_bench.json` |')
 j = p.index('| `r06_pmc.csv`, `pmc_summary.json` |')
 p = p[:i] + '''| `r06_bench.json` | the bench line of the library as committed: 64 frames per launch, **%.4f ms/step, frac %.4f** on the separable 5 + 5 loop with short-strip tails (`config.path`, `roofline.kernel`), the dense loop timed beside it in the same process (`roofline.dense_loop`: %.4f ms, %.4f), the class of the batch buffers (`config.probe_src_ms` / `probe_dst_ms` %.3f / %.3f: %s / %s), the first 30 launches one event pair each (`config.first_launch_ms`); `other_configs` with the headline at 128 and 256 frames, C3 at 16 and 64 frames and the measured issue fractions (`issue_counters`) | `tools/r06_evidence.sh` (first line: `python bench.py`) |
-| `r06_bench_profiled_pass.json`, `r06_kernel_stats.csv`, `r06_kernel_stats_by_grid.csv` | ONE process of the final library on that box: `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-configs` - the line that process printed (%.4f ms/step, frac %.4f, probe %.3f / %.3f) and its own per-kernel durations (`wave_sep_kernel<SampleRowSrc<float,1,MapCoord>,5>` %.1f us average over %s launches, which include the 30 single-event launches and the warm-up).  One of four such processes (0.918 - 0.923; `r06_micro.txt`) | `tools/r06_profiled_passes.sh 4`, `python profiles/summarize.py r06 gpurun_out/r06p/pass4 <fetch> <write> --batch 64 --kernel wave_sep_kernel` |
+| `r06_bench_profiled_pass.json`, `r06_kernel_stats.csv`, `r06_kernel_stats_by_grid.csv` | ONE process of the final library (another box): `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-configs` - the line that process printed (%.4f ms/step, frac %.4f, probe %.3f / %.3f) and its own per-kernel durations (`wave_sep_kernel<SampleRowSrc<float,1,MapCoord>,5>` %.1f us average over %s launches, which include the 30 single-event launches and the warm-up).  One of four such processes of that box (0.958 - 0.963; `r06_micro.txt`) | `tools/r06_profiled_passes.sh 4`, `python profiles/summarize.py r06 gpurun_out/r06p/pass3 <fetch> <write> --batch 64 --kernel wave_sep_kernel` |
 | `r06_bench_slow_box_final.json`, `r06_bench_slow_box.json`, `r06_bench_fast_box_before_tail.json` | the same command on other boxes: the library as committed on two slow-class buffers (0.9632 ms, 0.560; twelve more such processes in `r06_micro.txt`: 0.957 - 0.961); earlier in the round, before the short-strip tails: both buffers slow 0.9852 ms (0.547), both fast 0.8968 ms (0.601) | `python bench.py` |
 ''' % (l['ms_per_step'], l['roofline']['frac'], l['roofline']['dense_loop']['ms_per_step'], l['roofline']['dense_loop']['frac'], probe[0], probe[1], cls(probe[0]), cls(probe[1]),
        pp['ms_per_step'], pp['roofline']['frac'], pprobe[0], pprobe[1], avg_us, calls) + p[j:]
@@ -106,14 +111,14 @@ open('profiles/README.md', 'w').write(p)
 
 r = open('README.md').read()
 i = r.index('Fused undistort + 5x5 on 4K float32, 64 frames per launch:')
-j = r.index('Round 6 (`profiles/r06_micro.txt`, `DESIGN.md` section 0):')
+j = r.index('Round 6, second half - what fuzzing')
 r = r[:i] + '''Fused undistort + 5x5 on 4K float32, 64 frames per launch: **%.3f ms per step = %.3f of the HBM peak from
 COMPULSORY bytes in the committed run** (`profiles/r06_bench.json`: a %s-class source and a %s-class result buffer;
-a profiled process of that box: %.3f ms, `rocprofv3` average %.1f us); **0.957 - 0.963 ms = 0.560 - 0.563 when both
+a profiled process on two %s-class buffers: %.3f ms, `rocprofv3` average %.1f us); **0.957 - 0.963 ms = 0.560 - 0.563 when both
 buffers land in a slow region of the device memory** (13 fresh processes) - where round 5 measured 1.009 ms (0.534) and
 rounds 3 - 4 1.09 - 1.10 (0.49).  On two fast-class buffers 0.897 ms (0.601) was measured before the last 2.5 %% went in.
 The spread is the memory's (DESIGN.md section 5: one launch on windows of ONE buffer pair: 0.990 / 0.990 / 0.990 /
 0.896 ms), not the run's.
-''' % (l['ms_per_step'], l['roofline']['frac'], cls(probe[0]), cls(probe[1]), pp['ms_per_step'], avg_us) + r[j:]
+''' % (l['ms_per_step'], l['roofline']['frac'], cls(probe[0]), cls(probe[1]), cls(max(pprobe)), pp['ms_per_step'], avg_us) + r[j:]
 open('README.md', 'w').write(r)
 print('refreshed: headline %.4f ms (%.4f), profiled pass %.4f ms / %.1f us' % (l['ms_per_step'], l['roofline']['frac'], pp['ms_per_step'], avg_us))
