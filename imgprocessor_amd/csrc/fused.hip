@@ -239,7 +239,9 @@ int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int 
   if (dtype == IPA_U16 ? interp != (IPA_INTER_LINEAR | IPA_INTER_Q5)
                        : (dtype != IPA_U8 || (interp & 0xff) != IPA_INTER_LINEAR || (interp & ~(0xff | IPA_INTER_Q5)) != 0))
     return 1;
-  if (n_frames < 4 || n_frames % 4 != 0 || n_frames > 65535) return 1;
+  // (counts that are no multiple of 4: from 7 frames on as a head of whole workgroups + the LAST four frames again -
+  //  as the chains do, fused_impl.hpp::fused_split_tail; 5 and 6 frames stay with the gather kernel)
+  if (n_frames < 4 || (n_frames % 4 != 0 && n_frames < 7) || n_frames > 65535) return 1;
   if (!d_src || !d_dst || !d_mapx || !d_mapy || sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || (dw & 3) != 0) return 1;
   if (src_pitch < sw || dst_pitch < dw || map_pitch < dw || src_pitch >= (1l << 23)) return 1;
   if (((size_t)(sh - 1) * src_pitch + sw) * ipa_dtype_size(dtype) >= (1ull << 31)) return 1;
@@ -256,8 +258,21 @@ int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int 
   const double r = rint(border_value), top = dtype == IPA_U16 ? 65535.0 : 255.0;
   f.cval = r > 0 ? (r < top ? r : top) : 0;
   IPA_HIP(ctx, hipSetDevice(ctx->device));
-  if (dtype == IPA_U16) ipa_fused_sep_launch_c16(ctx, f);
-  else ipa_fused_sep_launch_c8(ctx, f);
+  auto launch = [&](const FusedCall& g) {
+    if (dtype == IPA_U16) ipa_fused_sep_launch_c16(ctx, g);
+    else ipa_fused_sep_launch_c8(ctx, g);
+  };
+  if (n_frames % 4 == 0) {
+    launch(f);
+  } else {
+    FusedCall head = f, tail = f;
+    head.n_frames = n_frames - n_frames % 4;
+    tail.n_frames = 4;
+    tail.src = f.src + (long)(n_frames - 4) * f.src_frame_bytes;
+    tail.p.dst = f.p.dst + (long)(n_frames - 4) * f.p.dst_frame_elems * (long)ipa_dtype_size(dtype);
+    launch(head);
+    launch(tail);
+  }
   IPA_HIP(ctx, hipGetLastError());
   ctx->strip_remaps++;
   return IPA_OK;

@@ -383,8 +383,9 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
                                  border_value);
     if (rc <= 0) return rc;
   }
-  if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
-                                             dst_pitch, n_frames, interp)) {
+  // (a multiple of 4 frames, or from 7 on: the chain then runs whole workgroups + the last four frames again)
+  if ((n_frames % 4 == 0 || n_frames >= 7) && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch,
+                                                                dh, dw, dst_pitch, n_frames, interp)) {
     ctx->strip_remaps++;
     return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, &kOneTap, 1,
                                    &kOneTap, 1, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
@@ -438,8 +439,8 @@ int ipa_warp_perspective_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
                              double border_value) {
   if (!ctx) return IPA_ERR_BAD_ARG;
   IPA_REQUIRE(ctx, M, "null matrix");
-  if (n_frames % 4 == 0 && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch, dh, dw,
-                                             dst_pitch, n_frames, interp) &&
+  if ((n_frames % 4 == 0 || n_frames >= 7) && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch,
+                                                                dh, dw, dst_pitch, n_frames, interp) &&
       warp_row_drift(M, dh, dw) < 0.2) {   // (see ipa_remap_dev; pictures that turn stay with the gather kernels)
     ctx->strip_remaps++;
     return ipa_warp_perspective_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, M, &kOneTap, 1, &kOneTap, 1,

@@ -36,7 +36,7 @@ def rot(deg, h, w):
 
 
 @pytest.mark.parametrize('shape', [(150, 610), (97, 333), (301, 1030)])
-@pytest.mark.parametrize('n', [4, 8, 3])
+@pytest.mark.parametrize('n', [4, 8, 3, 7])
 @pytest.mark.parametrize('interp', ['linear', 'linear_cv_q5'])
 def test_strip_remap_is_the_gather_remap(ia, oracle, shape, n, interp):
     from imgprocessor_amd import ops
@@ -49,9 +49,10 @@ def test_strip_remap_is_the_gather_remap(ia, oracle, shape, n, interp):
     oi = oracle.LINEAR | (oracle.Q5 if interp.endswith('q5') else 0)
     for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
         calls = {
-            'maps': (lambda: ops.remap(d, dmx, dmy, interp, border, 100.0, out_dtype=np.float32), n % 4 == 0),
+            # (counts that are no multiple of 4: from 7 frames on - whole workgroups + the last four frames again)
+            'maps': (lambda: ops.remap(d, dmx, dmy, interp, border, 100.0, out_dtype=np.float32), n % 4 == 0 or n >= 7),
             'lens model': (lambda: ops.undistort(d, Kc, dist, Kc, interp, border, 100.0, out_dtype=np.float32), True),
-            'homography': (lambda: ops.warp_perspective(d, M_UP, (h, w), interp, border, 100.0, out_dtype=np.float32), n % 4 == 0),
+            'homography': (lambda: ops.warp_perspective(d, M_UP, (h, w), interp, border, 100.0, out_dtype=np.float32), n % 4 == 0 or n >= 7),
         }
         for name, (fn, expect) in calls.items():
             before = taken(ctx)
@@ -154,7 +155,7 @@ def test_integer_batches_undistort_through_the_cached_map(ia, oracle, dtype, int
 
 
 @pytest.mark.parametrize('shape', [(150, 612), (97, 336), (301, 1032), (97, 333)])
-@pytest.mark.parametrize('n', [4, 8, 12, 6])
+@pytest.mark.parametrize('n', [4, 8, 12, 6, 7, 9])
 def test_uint16_into_uint16_with_cv2_arithmetic(ia, oracle, shape, n):
     """round 6: cv2.remap on uint16 frames RETURNS uint16 - what LensDistortion.correct gives for camera frames
     (camera/LensDistortion.py:323-326; the wrapper asks for cv2's 16U arithmetic at 1/32-px coordinates,
@@ -168,7 +169,7 @@ def test_uint16_into_uint16_with_cv2_arithmetic(ia, oracle, shape, n):
     mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
     mx = mx - np.float32(15.0)
     d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
-    expect = n % 4 == 0 and w % 4 == 0
+    expect = (n % 4 == 0 or n >= 7) and w % 4 == 0
     for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
         for name, fn in (('maps', lambda: ops.remap(d, dmx, dmy, 'linear_cv_q5', border, 17.6)),
                          ('lens model', lambda: ops.undistort(d, Kc, dist, Kc, 'linear_cv_q5', border, 17.6))):
@@ -214,7 +215,7 @@ def test_lens_distortion_correct_on_a_uint16_batch(ia, oracle):
 
 
 @pytest.mark.parametrize('shape', [(150, 608), (97, 336), (301, 1040), (97, 340), (97, 342)])
-@pytest.mark.parametrize('n', [4, 8, 12, 6])
+@pytest.mark.parametrize('n', [4, 8, 12, 6, 7, 9])
 def test_uint8_into_uint8_with_cv2_fixed_point(ia, oracle, shape, n):
     """... and 8-bit camera frames: cv2.remap's 8U bilinear (15-bit fixed-point weights from the 1/32-px fractions, rounded
     shift - every bilinear remap of uint8 frames is that arithmetic, with or without the q5 flag) on the same strips: one
@@ -227,7 +228,7 @@ def test_uint8_into_uint8_with_cv2_fixed_point(ia, oracle, shape, n):
     mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
     mx = mx - np.float32(15.0)
     d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
-    expect = n % 4 == 0 and w % 4 == 0          # (rows of whole dwords)
+    expect = (n % 4 == 0 or n >= 7) and w % 4 == 0          # (rows of whole dwords)
     for interp in ('linear', 'linear_cv_q5'):
         for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
             for name, fn in (('maps', lambda: ops.remap(d, dmx, dmy, interp, border, 17.6)),
