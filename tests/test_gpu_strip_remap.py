@@ -245,3 +245,41 @@ def test_uint8_into_uint8_with_cv2_fixed_point(ia, oracle, shape, n):
     want = oracle.remap(src[n - 1], mx, my, oracle.LINEAR | oracle.Q5, oracle.CONSTANT, 17.6)
     got = ops.remap(d, dmx, dmy, 'linear', 'constant', 17.6).get()
     assert np.array_equal(got[n - 1], want), (shape, n)
+
+
+@pytest.mark.parametrize('dtype', [np.uint16, np.uint8])
+@pytest.mark.parametrize('pads', [(24, 8, 12), (25, 9, 13), (32, 16, 16), (26, 10, 12)])
+def test_integer_strip_remap_with_pitches(ia, dtype, pads):
+    """the integer forms through the C ABI with pitches and frame strides larger than the frames: rows of whole dwords take
+    the strips, others the gather kernel - the same integers either way, nothing written outside the frames"""
+    from imgprocessor_amd import ops
+    from imgprocessor_amd.device import dtype_id
+    ctx = ia.default_context(0)
+    n, h, w = 8, 130, 512
+    src = frames(n, h, w, dtype)
+    mx, my, _, _ = radial_maps(h, w)
+    interp = 'linear_cv_q5'
+    old = ctx.set_tuning(strip_remap=0)
+    try:
+        want = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), interp, 'constant', 5.0).get()
+    finally:
+        ctx.set_tuning(**old)
+    sp, dp, mp = w + pads[0], w + pads[1], w + pads[2]
+    sbig = np.full((n, h + 5, sp), 7, dtype)
+    sbig[:, :h, :w] = src
+    mbx, mby = np.full((h, mp), -1e9, np.float32), np.full((h, mp), -1e9, np.float32)
+    mbx[:, :w], mby[:, :w] = mx, my
+    dbig = ctx.to_device(np.full((n, h + 3, dp), 201, dtype))
+    dsb, dmbx, dmby = ctx.to_device(sbig), ctx.to_device(mbx), ctx.to_device(mby)
+    before = taken(ctx)
+    ctx._check(ctx._lib.ipa_remap_dev(
+        ctx.handle, dsb.ptr, dtype_id(dtype), h, w, sp, dmbx.ptr, dmby.ptr, mp, dbig.ptr,
+        dtype_id(dtype), h, w, dp, n, (h + 5) * sp, (h + 3) * dp, ops.interp_id(interp),
+        ops.border_id('constant'), C.c_double(5.0)), 'remap')
+    got = dbig.get()
+    assert np.array_equal(got[:, :h, :w], want), (dtype, pads)
+    assert (got[:, h:, :] == 201).all() and (got[:, :, w:] == 201).all(), 'wrote outside'
+    # rows and frames of the result that start on a dword take the strips (uint16 rows then start on any 4 bytes: the
+    # two-dword stores need no more), the others the gather kernel
+    row_bytes = dp * np.dtype(dtype).itemsize
+    assert taken(ctx) - before == (1 if row_bytes % 4 == 0 and ((h + 3) * row_bytes) % 4 == 0 else 0), (dtype, pads)
