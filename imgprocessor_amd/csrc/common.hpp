@@ -158,6 +158,10 @@ void ipa_set_error(ipa_ctx* ctx, const char* fmt, ...);
 int ipa_ws_reserve(ipa_ctx* ctx, size_t bytes);                         // ctx->ws >= bytes
 int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, const double* newK,
                         int h, int w, float** mx, float** my);
+// remap.hip -> fused.hip: the strip remap of integer frames into their own type (1: not a call it covers)
+int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
+                        const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
+                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode, double border_value);
 int ipa_plan_reserve(ipa_ctx* ctx, size_t bytes);                       // ctx->plan >= bytes
 int ipa_tab_upload(ipa_ctx* ctx, const void* host, size_t bytes, void** d);  // stream-ordered
 

@@ -287,11 +287,6 @@ int ipa_lens_map_cached(ipa_ctx* ctx, const double* K, const double* dist5, cons
   return IPA_OK;
 }
 
-int ipa_strip_remap_int(ipa_ctx* ctx, int dtype, const void* d_src, int sh, int sw, long src_pitch, const float* d_mapx,
-                        const float* d_mapy, long map_pitch, void* d_dst, int dh, int dw, long dst_pitch, int n_frames,
-                        long src_frame_stride, long dst_frame_stride, int interp, int border_mode,
-                        double border_value);   // fused.hip (internal, C++ linkage)
-
 extern "C" {
 
 int ipa_build_undistort_map_dev(ipa_ctx* ctx, const double* K, const double* dist5,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """What makes the top-left-corner footprint of tools/fuzz_paths.py seed 63 case 66 come out wrong on the shared-footprint
 loop (round 6)?  Variations of that case, shared loop (frames_wg = 1) against the per-frame kernels (frames_wg = 0):
-    IMGPROC_HIP_LIB=.../libimgproc_hip_r5corner.so python tools/corner_probe.py gpurun_out/r06z/case66.npz
+    IMGPROC_HIP_LIB=.../libimgproc_hip_r5corner.so python tools/corner_probe.py [dump.npz]
 (the r5corner build keeps round 5's rule: make VARIANT=r5corner DEFS=-DIPA_DEBUG_CORNER_AS_ROUND5 ONLY="fused_k3 ...")"""
 import os
 import sys
@@ -13,9 +13,17 @@ import imgprocessor_amd as ia  # noqa: E402
 from imgprocessor_amd import ops  # noqa: E402
 from imgprocessor_amd import _lib  # noqa: E402
 
-d = np.load(sys.argv[1])
-src, M, k7 = d['src'], d['M'], d['k']
-cval = float(d['cval'])
+if len(sys.argv) > 1:          # the fuzzer's own dump (FUZZ_DUMP=... of a run that still mismatches)
+    d = np.load(sys.argv[1])
+    src, M, k7 = d['src'], d['M'], d['k']
+    cval = float(d['cval'])
+else:                          # the case as it was drawn: geometry and matrix of seed 63 / case 66, fresh random frames
+    rng0 = np.random.default_rng(66)
+    src = rng0.random((4, 143, 1052), dtype=np.float32)
+    M = np.array([[1.005, -0.037, -1.459], [0.04, 1.006, -170.734], [0.0, 0.0, 0.997]])
+    k7 = rng0.random((7, 7))
+    k7 /= k7.sum()
+    cval = 0.25
 ctx = ia.default_context(0)
 print('library:', _lib.LIB_PATH)
 plain = dict(ring_remap=0, lens_cache=0, ring_min=1, frames_wg=0, stored_coords=0, pipe=1, tile_warp=0)
