@@ -170,8 +170,9 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
   // (uint16 frames: with maps or a homography - f.coord_kind is set by the caller before it comes here)
   // (one tap - the remap alone - is built for uint16 frames: remap.hip::strip_remap_takes)
-  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9 || (nky == 1 && src_dtype == IPA_U16)) &&
-                          (src_dtype == IPA_F32 || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
+  const bool u8_remap = nky == 1 && nkx == 1 && src_dtype == IPA_U8 && f.coord_kind == 0 && ctx->tune.sep_u16 != 0;
+  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9 || (nky == 1 && src_dtype == IPA_U16) || u8_remap) &&
+                          (src_dtype == IPA_F32 || u8_remap || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
                           base == IPA_INTER_LINEAR && !prefer_two;
   if (!one_kernel) {
     IPA_REQUIRE(ctx, dh > 0 && dw > 0 && n_frames >= 1, "empty image");

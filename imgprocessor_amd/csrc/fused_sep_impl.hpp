@@ -62,6 +62,13 @@ static void fused_sep_interp(ipa_ctx* ctx, const FusedCall& f, const Coord& c, c
       return;
     }
   }
+  // uint8 frames into float32 (8-bit cameras through toFloatArray): the remap alone, with maps
+  if constexpr (K == 1 && std::is_same<Coord, MapCoord>::value) {
+    if (f.src_dt == IPA_U8) {
+      fused_sep_one<uint8_t, kLinear, Coord, K>(ctx, f, c, q);
+      return;
+    }
+  }
   // K = 1 (the remap alone, fused_sep_c.hip) is built for uint16 frames only: float32 frames have the tile kernel
   // (level on maps, 15 - 19 % faster under a homography), and fused.hip does not send them here
   if constexpr (K != 1) fused_sep_one<float, kLinear, Coord, K>(ctx, f, c, q);

@@ -334,14 +334,14 @@ int ipa_build_undistort_map(ipa_ctx* ctx, const double* K, const double* dist5,
 // they are: the tile kernel is level with the strips on maps and 15 - 19 % faster on homographies.
 static bool strip_remap_takes(const ipa_ctx* ctx, const void* d_src, const void* d_dst, int src_dtype, int dst_dtype,
                               int sh, int sw, long src_pitch, int dh, int dw, long dst_pitch, int n_frames,
-                              int interp) {
+                              int interp, bool maps = false) {   // (maps: uint8 frames are built with the map pair only)
   const ipa_tuning& t = ctx->tune;
   if (!t.strip_remap || !t.sep_u16 || !t.frames_wg || !t.frames_inner || !t.pipe) return false;
-  if (src_dtype != IPA_U16 || dst_dtype != IPA_F32 || !d_src || !d_dst) return false;
+  if ((src_dtype != IPA_U16 && !(src_dtype == IPA_U8 && maps)) || dst_dtype != IPA_F32 || !d_src || !d_dst) return false;
   if ((interp & 0xff) != IPA_INTER_LINEAR || (interp & ~(0xff | IPA_INTER_Q5)) != 0) return false;
   // (what the chain kernels' 32-bit offsets hold; anything else stays with the gather kernels and their checks)
   if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || src_pitch < sw || dst_pitch < dw || src_pitch >= (1l << 23)) return false;
-  if (((size_t)(sh - 1) * src_pitch + sw) * 2 >= (1ull << 31) || n_frames < 1 || n_frames > 65535) return false;
+  if (((size_t)(sh - 1) * src_pitch + sw) * ipa_dtype_size(src_dtype) >= (1ull << 31) || n_frames < 1 || n_frames > 65535) return false;
   return true;
 }
 // how far the source row moves along one output row (px per px), at 9 points of the picture
@@ -380,7 +380,7 @@ int ipa_remap_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh, int sw
   }
   // (a multiple of 4 frames, or from 7 on: the chain then runs whole workgroups + the last four frames again)
   if ((n_frames % 4 == 0 || n_frames >= 7) && strip_remap_takes(ctx, d_src, d_dst, src_dtype, dst_dtype, sh, sw, src_pitch,
-                                                                dh, dw, dst_pitch, n_frames, interp)) {
+                                                                dh, dw, dst_pitch, n_frames, interp, true)) {
     ctx->strip_remaps++;
     return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, &kOneTap, 1,
                                    &kOneTap, 1, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,

@@ -790,9 +790,10 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
   // holds both taps (any byte offset, as TapLoad<uint16_t, float> loads it)
   constexpr int NR = sizeof(ST) == 4 ? 2 : 1;
   constexpr int SH = sizeof(ST) == 4 ? 2 : (sizeof(ST) == 2 ? 1 : 0);   // log2 of the element size
-  constexpr bool FIX8 = sizeof(ST) == 1;        // uint8 frames: integer arithmetic, 16-bit tap loads (CV16 only)
-  static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value ||
-                (std::is_same<ST, uint8_t>::value && CV16), "float32 / uint16 frames, uint8 into uint8");
+  constexpr bool kU8 = sizeof(ST) == 1;         // uint8 frames: a tap row is one 16-bit load (both taps, zero-extended)
+  constexpr bool FIX8 = kU8 && CV16;            // ... into uint8: cv2's integer arithmetic (into float32: the float blend)
+  static_assert(std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value || std::is_same<ST, uint8_t>::value,
+                "float32 / uint16 / uint8 frames");
   constexpr int W = IPA_WPB;        // rows per block = waves per workgroup
   // lane order of the samples: interleaved (sample k of lane L = strip pixel L + 64 k: the 64
   // gathers of an instruction walk along the source row) or natural (pixel 4 L + k; measurement
@@ -952,7 +953,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { pipe_gather1(g[2 * k], o, rs); return; }
 #endif
     if constexpr (NR == 2) pipe_gather2(g[2 * k], g[2 * k + 1], o, rs);
-    else if constexpr (FIX8) pipe_gather1_b16(g[k], o, rs);
+    else if constexpr (kU8) pipe_gather1_b16(g[k], o, rs);
     else pipe_gather1(g[k], o, rs);
   };
   auto gather_masked = [&](float (&g)[NS * NR], int k, unsigned o, unsigned long long m) {
@@ -960,7 +961,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { pipe_gather1_masked(g[2 * k], o, rs, m); return; }
 #endif
     if constexpr (NR == 2) pipe_gather2_masked(g[2 * k], g[2 * k + 1], o, rs, m);
-    else if constexpr (FIX8) pipe_gather1_b16_masked(g[k], o, rs, m);
+    else if constexpr (kU8) pipe_gather1_b16_masked(g[k], o, rs, m);
     else pipe_gather1_masked(g[k], o, rs, m);
   };
   auto pin_taps = [&](float (&g)[NS * NR]) {
@@ -978,7 +979,7 @@ __device__ __forceinline__ void wave_run_strip_shared(const WaveParams& p,
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = from_lane_above(v0); return; }
 #endif
     if constexpr (NR == 2) { v0 = g[2 * k]; v1 = g[2 * k + 1]; }
-    else if constexpr (FIX8) { v0 = (float)(__float_as_uint(g[k]) & 0xffu); v1 = (float)((__float_as_uint(g[k]) >> 8) & 0xffu); }
+    else if constexpr (kU8) { v0 = (float)(__float_as_uint(g[k]) & 0xffu); v1 = (float)((__float_as_uint(g[k]) >> 8) & 0xffu); }
     else TapLoad<uint16_t, float>::unpack(__float_as_uint(g[k]), v0, v1);
   };
 

@@ -283,3 +283,36 @@ def test_integer_strip_remap_with_pitches(ia, dtype, pads):
     # two-dword stores need no more), the others the gather kernel
     row_bytes = dp * np.dtype(dtype).itemsize
     assert taken(ctx) - before == (1 if row_bytes % 4 == 0 and ((h + 3) * row_bytes) % 4 == 0 else 0), (dtype, pads)
+
+
+@pytest.mark.parametrize('shape', [(150, 610), (97, 333), (301, 1030)])
+@pytest.mark.parametrize('n', [4, 8, 3, 7])
+def test_uint8_frames_into_float32(ia, oracle, shape, n):
+    """8-bit camera frames through transformations.toFloatArray: uint8 -> float32 bilinear remaps with the map pair (and
+    the lens model by value through its cached map) on the strips - bits of the gather kernel, values of the oracle"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = shape
+    src = frames(n, h, w, np.uint8)
+    src[:, 0, 0] = src[:, -1, -1] = 255
+    mx, my, Kc, dist = radial_maps(h, w, shift=2.3)
+    mx = mx - np.float32(15.0)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    for interp in ('linear', 'linear_cv_q5'):
+        for border in ('constant', 'replicate', 'reflect', 'wrap', 'reflect101'):
+            for name, fn, expect in (('maps', lambda: ops.remap(d, dmx, dmy, interp, border, 9.0, out_dtype=np.float32),
+                                      n % 4 == 0 or n >= 7),
+                                     ('lens model', lambda: ops.undistort(d, Kc, dist, Kc, interp, border, 9.0, out_dtype=np.float32),
+                                      n >= 4 and (n % 4 == 0 or n >= 7))):
+                before = taken(ctx)
+                got = fn().get()
+                assert taken(ctx) == before + (1 if expect else 0), (name, n, shape)
+                old = ctx.set_tuning(strip_remap=0)
+                try:
+                    ref = fn().get()
+                finally:
+                    ctx.set_tuning(**old)
+                same_bits(got, ref, '%s, %s, %s, %d uint8 frames of %d x %d' % (name, interp, border, n, h, w))
+    want = oracle.remap(src[n - 1], mx, my, oracle.LINEAR, oracle.CONSTANT, 9.0, out_dtype=np.float32)
+    got = ops.remap(d, dmx, dmy, 'linear', 'constant', 9.0, out_dtype=np.float32).get()
+    assert_close(got[n - 1], want, 1e-5, 1e-5 * 255, 'uint8 -> float32 vs oracle')
