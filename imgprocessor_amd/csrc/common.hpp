@@ -65,7 +65,7 @@ struct ipa_tuning {
                           // loops wherever those cover the call: bit 0 the remap -> filter chains, bit 1 the plain filter
   int strip_remap = 1;    // bilinear remaps of uint16 frames into float32 on the marching strips of the chains, no filter
                           // (remap.hip::strip_remap_takes; 0: the gather kernels of rounds 1 - 5)
-  int sep_u16 = 1;        // bilinear remap (maps, homographies) -> separable 3 / 5 / 7 / 9-tap filter on uint16 frames in ONE kernel
+  int sep_u16 = 1;        // integer frames (uint16: maps, homographies; uint8: maps): bilinear remap -> separable 3 / 5 / 7 / 9-tap filter on uint16 frames in ONE kernel
                           // (float32 frames always were; 0: two launches through the workspace, as in rounds 1 - 5)
   int stored_coords = 4;  // bicubic / Lanczos4 remaps of >= this many float32 frames from a coordinate source given
                           // by value (homography, lens model) that the ring kernel does not take: the coordinates

@@ -42,11 +42,11 @@ static int inv3f(const double* m, double* o) {
 // = 10 instead of K * K = 25 multiply-adds per pixel on the same strips.  Knob rank1_sep bit 0; the two loops
 // differ by the order of a float32 sum only (both within 1e-5 of the oracle's double sum).
 static bool rank1_chain(ipa_ctx* ctx, const double* kernel, int kh, int kw, int src_dtype, int dst_dtype,
-                        int interp, double* ky, double* kx, bool maps = false) {
+                        int interp, double* ky, double* kx, bool maps = false, bool u8_maps = false) {
   if (!(ctx->tune.rank1_sep & 1) || !kernel || kh != kw) return false;
   if (!(kh == 3 || kh == 5 || kh == 7 || kh == 9)) return false;
   // (uint16 frames: where the separable chain is one kernel for them - maps, homographies; knob sep_u16)
-  const bool src_ok = src_dtype == IPA_F32 || (src_dtype == IPA_U16 && maps && ctx->tune.sep_u16 != 0);
+  const bool src_ok = src_dtype == IPA_F32 || ((src_dtype == IPA_U16 || (src_dtype == IPA_U8 && u8_maps)) && maps && ctx->tune.sep_u16 != 0);
   if (!src_ok || dst_dtype != IPA_F32 || (interp & 0xff) != IPA_INTER_LINEAR) return false;
   return ipa_rank1_factor(kernel, kh, kw, ky, kx);
 }
@@ -170,9 +170,10 @@ static int fused_sep_common(ipa_ctx* ctx, FusedCall& f, TwoLaunch two, const voi
   // strip make it slower than two launches (4K, 9 taps: 813 vs 694 us) -> two launches
   // (uint16 frames: with maps or a homography - f.coord_kind is set by the caller before it comes here)
   // (one tap - the remap alone - is built for uint16 frames: remap.hip::strip_remap_takes)
-  const bool u8_remap = nky == 1 && nkx == 1 && src_dtype == IPA_U8 && f.coord_kind == 0 && ctx->tune.sep_u16 != 0;
-  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9 || (nky == 1 && src_dtype == IPA_U16) || u8_remap) &&
-                          (src_dtype == IPA_F32 || u8_remap || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
+  // (uint8 frames: with maps only)
+  const bool u8_maps = src_dtype == IPA_U8 && f.coord_kind == 0 && ctx->tune.sep_u16 != 0;
+  const bool one_kernel = nky == nkx && (nky == 3 || nky == 5 || nky == 7 || nky == 9 || (nky == 1 && src_dtype != IPA_F32)) &&
+                          (src_dtype == IPA_F32 || u8_maps || (src_dtype == IPA_U16 && f.coord_kind != 1 && ctx->tune.sep_u16 != 0)) &&
                           base == IPA_INTER_LINEAR && !prefer_two;
   if (!one_kernel) {
     IPA_REQUIRE(ctx, dh > 0 && dw > 0 && n_frames >= 1, "empty image");
@@ -418,7 +419,7 @@ int ipa_remap_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int sh,
   IPA_REQUIRE(ctx, d_mapx && d_mapy && map_pitch >= dw, "bad map arguments");
   {
     double ky[9], kx[9];
-    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx, true)) {
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx, true, true)) {
       ctx->rank1_routed++;
       return ipa_remap_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, d_mapx, d_mapy, map_pitch, ky, kh,
                                      kx, kw, d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,
@@ -494,7 +495,7 @@ int ipa_undistort_conv2d_dev(ipa_ctx* ctx, const void* d_src, int src_dtype, int
   IPA_REQUIRE(ctx, K && dist5 && newK, "K, dist5 and newK must be given");
   {
     double ky[9], kx[9];
-    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx, ctx->tune.lens_cache != 0)) {
+    if (rank1_chain(ctx, kernel, kh, kw, src_dtype, dst_dtype, interp, ky, kx, ctx->tune.lens_cache != 0, ctx->tune.lens_cache != 0)) {
       ctx->rank1_routed++;
       return ipa_undistort_sepconv2d_dev(ctx, d_src, src_dtype, sh, sw, src_pitch, K, dist5, newK, ky, kh, kx, kw,
                                          d_dst, dst_dtype, dh, dw, dst_pitch, n_frames, src_frame_stride,

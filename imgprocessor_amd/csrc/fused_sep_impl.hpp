@@ -62,8 +62,8 @@ static void fused_sep_interp(ipa_ctx* ctx, const FusedCall& f, const Coord& c, c
       return;
     }
   }
-  // uint8 frames into float32 (8-bit cameras through toFloatArray): the remap alone, with maps
-  if constexpr (K == 1 && std::is_same<Coord, MapCoord>::value) {
+  // uint8 frames into float32 (8-bit cameras through toFloatArray), with maps: the remap alone and + separable filter
+  if constexpr (std::is_same<Coord, MapCoord>::value) {
     if (f.src_dt == IPA_U8) {
       fused_sep_one<uint8_t, kLinear, Coord, K>(ctx, f, c, q);
       return;

@@ -290,7 +290,7 @@ template <typename Src, int K> struct sep_shared : std::false_type {};
 template <typename ST, typename Coord, int K> struct sep_shared<SampleRowSrc<ST, kLinear, Coord>, K> {
   static constexpr bool value = IPA_PIPE != 0 && IPA_PIPE_SHARED != 0 &&
                                 (std::is_same<ST, float>::value || std::is_same<ST, uint16_t>::value ||
-                                 (std::is_same<ST, uint8_t>::value && K == 1));   // (uint8 frames: the strip remaps only)
+                                 std::is_same<ST, uint8_t>::value);
 };
 
 template <typename Src> struct sep_shares_maps : std::false_type {};

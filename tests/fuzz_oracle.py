@@ -86,7 +86,7 @@ def main():
                 break
         # the fused chain (remap -> K x K filter in one kernel) on the same case: float32 and uint16
         # frames, every interpolation the fused entry point takes
-        if dt in (np.float32, np.uint16) and iname != 'nearest':
+        if iname != 'nearest':     # (round 6: every element type - two launches where no fused kernel is built)
             try:
                 gotf = ops.remap_conv2d(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), kern,
                                         iname, bname, cval, cmode).get()
@@ -108,7 +108,7 @@ def main():
                                               K, cmode, d))
                         break
         # ... and the separable form (remap -> ky then kx), 3 / 5 / 7 / 9 / 13 taps per axis
-        if dt in (np.float32, np.uint16) and iname != 'nearest':
+        if iname != 'nearest':
             ny_, nx_ = int(sep[0]), int(sep[1])
             if ny_ < dh and nx_ < dw:
                 ky_, kx_ = sepw[:ny_] / sepw[:ny_].sum(), sepw[:nx_][::-1] / sepw[:nx_].sum()

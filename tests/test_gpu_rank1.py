@@ -251,3 +251,33 @@ def test_short_strips_at_the_end_of_every_xcd_share(ia, n, shape):
     # (8 frames = 2 groups: no chunks; 20 frames = 5 chunks of one group, which do not map onto the 8 XCDs' block
     # ranges: uniform strips; the others must have taken the geometry at least once)
     assert (used == {0}) == (n in (8, 20)), used
+
+
+@pytest.mark.parametrize('n', [1, 3, 4, 8])
+@pytest.mark.parametrize('K', [3, 5, 7, 9])
+def test_uint8_frames_take_the_one_kernel_separable_chain(ia, oracle, n, K):
+    """... and 8-bit camera frames (round 6): map-based bilinear remap -> separable K + K filter in one kernel, the
+    outer-product K x K route with it; against the oracle, with the two-launch form (knob sep_u16 = 0) beside it"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 150, 610
+    src = frames(n, h, w, np.uint8)
+    mx, my, Kc, dist = radial_maps(h, w, shift=3.3)
+    mx = mx - np.float32(20.0)
+    ky, kx = gauss(K), gauss(K, 0.8)
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    got = ops.remap_sepconv2d(d, dmx, dmy, ky, kx, 'linear', 'constant', 100.0).get()
+    before = routed(ctx)
+    dense_call = ops.remap_conv2d(d, dmx, dmy, np.outer(ky, kx), 'linear', 'constant', 100.0).get()
+    assert routed(ctx) == before + 1, 'uint8 frames + maps + outer product: the separable chain'
+    old = ctx.set_tuning(sep_u16=0)
+    try:
+        two = ops.remap_sepconv2d(d, dmx, dmy, ky, kx, 'linear', 'constant', 100.0).get()
+    finally:
+        ctx.set_tuning(**old)
+    same_bits(got, two, 'one kernel against the two launches')
+    for f in range(n):
+        mid = oracle.remap(src[f], mx, my, oracle.LINEAR, oracle.CONSTANT, 100.0, out_dtype=np.float32)
+        want = oracle.sepconv2d(mid, ky, kx)
+        for name, a in (('one kernel', got), ('routed dense call', dense_call)):
+            assert_close(a[f], want, 1e-5, 1e-5 * 255, '%s, %d+%d taps, frame %d of %d' % (name, K, K, f, n))
