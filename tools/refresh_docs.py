@@ -103,6 +103,7 @@ i = p.index('| `r06_bench.json` |')
 j = p.index('| `r06_pmc.csv`, `pmc_summary.json` |')
 p = p[:i] + '''| `r06_bench.json` | the bench line of the library as committed: 64 frames per launch, **%.4f ms/step, frac %.4f** on the separable 5 + 5 loop with short-strip tails (`config.path`, `roofline.kernel`), the dense loop timed beside it in the same process (`roofline.dense_loop`: %.4f ms, %.4f), the class of the batch buffers (`config.probe_src_ms` / `probe_dst_ms` %.3f / %.3f: %s / %s), the first 30 launches one event pair each (`config.first_launch_ms`); `other_configs` with the headline at 128 and 256 frames, C3 at 16 and 64 frames and the measured issue fractions (`issue_counters`) | `tools/r06_evidence.sh` (first line: `python bench.py`) |
 | `r06_bench_profiled_pass.json`, `r06_kernel_stats.csv`, `r06_kernel_stats_by_grid.csv` | ONE process of the final library (another box): `rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu --no-configs` - the line that process printed (%.4f ms/step, frac %.4f, probe %.3f / %.3f) and its own per-kernel durations (`wave_sep_kernel<SampleRowSrc<float,1,MapCoord>,5>` %.1f us average over %s launches, which include the 30 single-event launches and the warm-up).  One of four such processes of that box (0.958 - 0.963; `r06_micro.txt`) | `tools/r06_profiled_passes.sh 4`, `python profiles/summarize.py r06 gpurun_out/r06p/pass3 <fetch> <write> --batch 64 --kernel wave_sep_kernel` |
+| `r06_bench_final_library_other_box.json` | `python bench.py --no-cpu` of the library at the very end of the round (the uint8 chains in as well) on another box: **0.8976 ms/step, frac 0.601** (probe 0.427 / 0.378: a slow-class source, a fast-class result buffer - the result buffer is the one that matters: the strip-shaped store stream) | `python bench.py --no-cpu` |
 | `r06_bench_slow_box_final.json`, `r06_bench_slow_box.json`, `r06_bench_fast_box_before_tail.json` | the same command on other boxes: the library as committed on two slow-class buffers (0.9632 ms, 0.560; twelve more such processes in `r06_micro.txt`: 0.957 - 0.961); earlier in the round, before the short-strip tails: both buffers slow 0.9852 ms (0.547), both fast 0.8968 ms (0.601) | `python bench.py` |
 ''' % (l['ms_per_step'], l['roofline']['frac'], l['roofline']['dense_loop']['ms_per_step'], l['roofline']['dense_loop']['frac'], probe[0], probe[1], cls(probe[0]), cls(probe[1]),
        pp['ms_per_step'], pp['roofline']['frac'], pprobe[0], pprobe[1], avg_us, calls) + p[j:]
