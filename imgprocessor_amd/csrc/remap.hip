@@ -329,9 +329,11 @@ int ipa_build_undistort_map(ipa_ctx* ctx, const double* K, const double* dist5,
 // the marching strips of the fused chains with NO filter (wave_sep_kernel, K = 1: 256-px strips, no halo, both
 // passes the identity; fused_sep_c.hip): the gather kernels these calls took stream 64 x 4K in 1.28 ms, the strips in
 // 0.90 (maps; -30 %), lens model 1.42 -> 0.89, homography 1.16 -> 1.07; identical bits (tools/strip_remap_probe.py).
-// Batches of a multiple of 4 frames (the shared-footprint loop) for maps and homographies that do not turn the
-// picture; the lens model by value at any count (its map is evaluated once and cached).  float32 frames stay where
-// they are: the tile kernel is level with the strips on maps and 15 - 19 % faster on homographies.
+// Batches of a multiple of 4 frames (the shared-footprint loop; from 7 frames on any count: whole workgroups + the last
+// four frames again) for maps and homographies that do not turn the picture; the lens model by value at any count (its
+// map is evaluated once and cached).  uint8 frames (8-bit cameras) the same with maps: 1.28 -> 0.93 ms.  float32 frames
+// stay where they are: the tile kernel is level with the strips on maps and 15 - 19 % faster on homographies.
+// (The knob sep_u16 is required too: with it off the chain entry would come back here through its two-launch form.)
 static bool strip_remap_takes(const ipa_ctx* ctx, const void* d_src, const void* d_dst, int src_dtype, int dst_dtype,
                               int sh, int sw, long src_pitch, int dh, int dw, long dst_pitch, int n_frames,
                               int interp, bool maps = false) {   // (maps: uint8 frames are built with the map pair only)
