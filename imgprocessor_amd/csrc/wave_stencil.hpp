@@ -410,7 +410,7 @@ template <typename ST, int INTERP, typename Coord> struct SampleRowSrc {
     static constexpr bool kShared = IPA_PIPE && K <= IPA_PIPE_MAX_K && INTERP == kLinear &&
                                     ((std::is_same<ST, float>::value &&
                                       (K <= 5 || !std::is_same<Coord, MapCoord>::value)) ||
-                                     std::is_same<ST, uint16_t>::value);
+                                     std::is_same<ST, uint16_t>::value || std::is_same<ST, uint8_t>::value);
     static constexpr bool kPiped = kShared && coord_is_table<Coord>::value && sizeof(C) == 4;
     static constexpr int value =
         INTERP == kLinear ? (K >= 9 ? IPA_SAMPLE_DEPTH_BIG : (kShared ? 1 : IPA_SAMPLE_DEPTH)) : 1;
