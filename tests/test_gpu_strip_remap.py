@@ -316,3 +316,27 @@ def test_uint8_frames_into_float32(ia, oracle, shape, n):
     want = oracle.remap(src[n - 1], mx, my, oracle.LINEAR, oracle.CONSTANT, 9.0, out_dtype=np.float32)
     got = ops.remap(d, dmx, dmy, 'linear', 'constant', 9.0, out_dtype=np.float32).get()
     assert_close(got[n - 1], want, 1e-5, 1e-5 * 255, 'uint8 -> float32 vs oracle')
+
+
+@pytest.mark.parametrize('dtype', [np.uint16, np.uint8])
+def test_full_size_camera_batch_every_frame(ia, oracle, dtype):
+    """16 x 4K camera frames through LensDistortion.correct's remap at full size, every frame against the oracle's integers
+    (the size other_configs of bench.py times: 'LensDistortion.correct 4K uint16 -> uint16 ...')"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w, n = 2160, 3840, 16
+    Kc = np.array([[float(w), 0, (w - 1) / 2.0], [0, float(w), (h - 1) / 2.0], [0, 0, 1.0]])
+    dist = np.array([-0.12, 0.03, 1e-3, -5e-4, 0.0])
+    newK = Kc.copy()
+    newK[0, 0] *= 0.97
+    newK[1, 1] *= 0.97              # a rim of border pixels, all four source corners inside the picture
+    mx, my = oracle.build_undistort_map(Kc, dist, newK, h, w)
+    rng = np.random.default_rng(11)
+    top = 65535 if dtype == np.uint16 else 255
+    src = rng.integers(0, top + 1, (n, h, w), dtype=dtype)
+    before = taken(ctx)
+    got = ops.remap(ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my), 'linear_cv_q5', 'constant', 7.0).get()
+    assert taken(ctx) == before + 1
+    for f in range(n):
+        want = oracle.remap(src[f], mx, my, oracle.LINEAR | oracle.Q5, oracle.CONSTANT, 7.0)
+        assert np.array_equal(got[f], want), (np.dtype(dtype).name, f, int(np.abs(got[f].astype(np.int64) - want).max()))
