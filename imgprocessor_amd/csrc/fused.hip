@@ -65,6 +65,7 @@ static bool dense_chain_built(int src_dtype, int coord_kind, int interp, int kh,
   if (src_dtype == IPA_F32)
     return base == IPA_INTER_LINEAR || base == IPA_INTER_CUBIC_CV || base == IPA_INTER_CUBIC_KEYS;
   if (src_dtype == IPA_U16) return base == IPA_INTER_LINEAR && coord_kind != 2;
+  if (src_dtype == IPA_U8) return base == IPA_INTER_LINEAR && coord_kind == 0;   // (8-bit camera frames, maps)
   return false;
 }
 static int big_kernel_tmp(ipa_ctx* ctx, int src_dtype, int coord_kind, int interp, int kh, int kw, int dst_dtype,

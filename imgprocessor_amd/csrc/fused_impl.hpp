@@ -159,6 +159,11 @@ template <int K> static int fused_launch_k(ipa_ctx* ctx, const FusedCall& f) {
     IPA_UNSUPPORTED(ctx, "fused remap+filter on uint16 frames is built for INTER_LINEAR with "
                          "maps or the analytic lens model; use ipa_remap_dev + ipa_conv2d_dev");
   }
+  if (f.src_dt == IPA_U8 && f.dst_dt == IPA_F32 && f.interp_base == IPA_INTER_LINEAR && f.coord_kind == 0) {
+    // 8-bit camera frames (round 6): bilinear, map-based
+    fused_launch_one<uint8_t, kLinear, MapCoord, K>(ctx, f, f.map);
+    return IPA_OK;
+  }
   IPA_UNSUPPORTED(ctx, "fused remap+filter: src dtype %d -> dst dtype %d not supported "
                        "(float32->float32 and uint16->float32 are)", f.src_dt, f.dst_dt);
 }

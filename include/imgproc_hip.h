@@ -331,8 +331,8 @@ int ipa_interleave_dev(ipa_ctx* ctx, const void* d_src, int dtype, int h, int w,
  * remapped pixels (incl. the filter halo, resolved with conv_border_*) are
  * produced into LDS and filtered there; the intermediate image never touches
  * HBM.  dst dtype is IPA_F32 (src may be u8/u16/f32) or IPA_F64 (src f64).
- * One kernel is built for float32 frames (bilinear, both bicubics) and uint16 frames (bilinear;
- * maps or the lens model) with square 3 .. 11 kernels; every OTHER combination the standalone
+ * One kernel is built for float32 frames (bilinear, both bicubics), uint16 frames (bilinear;
+ * maps or the lens model) and uint8 frames (bilinear, maps; 3 .. 7) with square 3 .. 11 kernels; every OTHER combination the standalone
  * entry points accept (Lanczos4 / nearest taps, uint8 frames, uint16 frames under a homography or
  * with bicubic taps, rectangular / even / larger kernels) runs as what it is - remap into the
  * context workspace, then ipa_conv2d_dev - with the bits of the two calls (round 6; these

@@ -28,7 +28,7 @@ CASES = [
     (np.uint16, 'linear', (3, 3), ('warp',)),
     (np.uint16, 'cubic', (5, 5), ('map', 'warp', 'lens')),
     (np.uint16, 'lanczos4', (7, 7), ('map', 'warp', 'lens')),
-    (np.uint8, 'linear', (3, 3), ('map', 'warp', 'lens')),
+    (np.uint8, 'linear', (3, 3), ('warp',)),                      # (with maps: one kernel since the end of round 6)
     (np.uint8, 'linear_cv_q5', (9, 9), ('map', 'warp')),
     (np.float32, 'lanczos4', (5, 5), ('map', 'warp', 'lens')),
     (np.float32, 'nearest', (3, 3), ('map', 'warp')),
@@ -94,3 +94,31 @@ def test_what_the_two_calls_reject_is_still_rejected(ia):
     f64 = ctx.to_device(frames(1, 40, 80).astype(np.float64))     # (float64 frames: remap -> float32 is not a conversion
     with pytest.raises((NotImplementedError, ValueError, TypeError)):   #  the standalone entry point makes either)
         ops.remap_conv2d(f64, ctx.to_device(mx), ctx.to_device(my), kern(3))
+
+
+@pytest.mark.parametrize('n', [1, 4, 7, 8])
+@pytest.mark.parametrize('K', [3, 5, 7])
+def test_uint8_frames_dense_chain_in_one_kernel(ia, oracle, K, n):
+    """8-bit camera frames + maps + a dense K x K kernel (round 6, the last addition): the chain kernels of the uint16
+    frames with 16-bit tap loads; against the oracle, and against remap -> filter as two calls within summation order"""
+    from imgprocessor_amd import ops
+    ctx = ia.default_context(0)
+    h, w = 150, 610
+    src = np.round(frames(n, h, w, np.float32) * 255).astype(np.uint8)
+    mx, my, Kc, dist = radial_maps(h, w, shift=3.3)
+    mx = mx - np.float32(20.0)
+    k = np.random.default_rng(8).random((K, K))
+    k /= k.sum()
+    d, dmx, dmy = ctx.to_device(src), ctx.to_device(mx), ctx.to_device(my)
+    for border, cmode in (('constant', 'reflect'), ('replicate', 'constant'), ('reflect', 'wrap')):
+        got = ops.remap_conv2d(d, dmx, dmy, k, 'linear', border, 9.0, cmode).get().reshape((n, h, w))
+        got_l = ops.undistort_conv2d(d, Kc, dist, Kc, k, 'linear', border, 9.0, cmode).get().reshape((n, h, w))
+        two = ops.conv2d(ops.remap(d, dmx, dmy, 'linear', border, 9.0, out_dtype=np.float32), k, cmode).get().reshape((n, h, w))
+        assert np.abs(got - two).max() <= 2e-6 * 255
+        bo = {'constant': oracle.CONSTANT, 'replicate': oracle.REPLICATE, 'reflect': oracle.REFLECT}[border]
+        umx, umy = oracle.build_undistort_map(Kc, dist, Kc, h, w)
+        for f in (0, n - 1):
+            want = oracle.conv2d(oracle.remap(src[f], mx, my, oracle.LINEAR, bo, 9.0, out_dtype=np.float32), k, cmode)
+            assert np.abs(got[f] - want).max() <= 1e-5 * 255, (K, n, border, f)
+            want = oracle.conv2d(oracle.remap(src[f], umx, umy, oracle.LINEAR, bo, 9.0, out_dtype=np.float32), k, cmode)
+            assert np.abs(got_l[f] - want).max() <= 1e-5 * 255, (K, n, border, f, 'lens')
